@@ -1,0 +1,259 @@
+"""ctypes view of oracle/libcpq_oracle.so (CPU oracle: test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+_REF = None
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class FilterSpec(C.Structure):
+    _fields_ = [("sampleRate", C.c_double), ("hcMode", C.c_int), ("lcMode", C.c_int),
+                ("tailMode", C.c_int), ("tailEnabled", C.c_int), ("tailStartSeconds", C.c_double),
+                ("tailStrength", C.c_double), ("tailL1L2Multiplier", C.c_int),
+                ("applySpectrumFilter", C.c_int)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        s = cls(48000.0, 1, 0, 1, 1, 0.085, 1.0, 8, 0)
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+
+class NucPlan(C.Structure):
+    _fields_ = [("numLayers", C.c_int), ("partSize", C.c_int * 3), ("offset", C.c_int * 3),
+                ("len", C.c_int * 3), ("numPartsIR", C.c_int * 3), ("numParts", C.c_int * 3),
+                ("partsPerCallback", C.c_int * 3), ("outputDelay", C.c_int * 3),
+                ("gain", C.c_double * 3), ("directTaps", C.c_int), ("latency", C.c_int),
+                ("ltiValid", C.c_int), ("doneCallback", C.c_int * 3), ("lag", C.c_int * 3)]
+
+
+class SvfCoeffs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("g", "k", "a1", "a2", "a3", "m0", "m1", "m2")]
+
+
+class EqBand(C.Structure):
+    _fields_ = [("frequency", C.c_float), ("gain", C.c_float), ("q", C.c_float),
+                ("enabled", C.c_int), ("type", C.c_int), ("channelMode", C.c_int)]
+
+
+class EqParams(C.Structure):
+    _fields_ = [("bands", EqBand * 20), ("totalGainDb", C.c_float), ("agcEnabled", C.c_int),
+                ("nonlinearSaturation", C.c_float), ("filterStructure", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "libcpq_oracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(
+            os.path.join(ORACLE_DIR, "cpq_oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libcpq_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    L.orc_splitmix64.restype = C.c_uint64
+    L.orc_splitmix64.argtypes = [C.c_uint64]
+    L.orc_rand_pm1.restype = C.c_double
+    L.orc_rand_pm1.argtypes = [C.c_uint64] * 4
+    L.orc_gen_pcm.argtypes = [c_double_p, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int64]
+    L.orc_gen_ir.argtypes = [c_double_p, C.c_int, C.c_uint64, C.c_int, C.c_int]
+    L.orc_fft_create.restype = C.c_void_p
+    L.orc_fft_create.argtypes = [C.c_int]
+    L.orc_fft_destroy.argtypes = [C.c_void_p]
+    L.orc_fft_fwd_ccs.argtypes = [C.c_void_p, c_double_p, c_double_p]
+    L.orc_fft_inv_ccs.argtypes = [C.c_void_p, c_double_p, c_double_p]
+    L.orc_nuc_plan_compute.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(FilterSpec), C.POINTER(NucPlan)]
+    L.orc_nuc_heff.argtypes = [c_double_p, C.c_int, C.c_int, C.c_double, C.POINTER(FilterSpec), c_double_p, C.c_int]
+    L.orc_nuc_create.restype = C.c_void_p
+    L.orc_nuc_destroy.argtypes = [C.c_void_p]
+    L.orc_nuc_set_impulse.argtypes = [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_double, C.c_int,
+                                      C.POINTER(FilterSpec)]
+    L.orc_nuc_add.argtypes = [C.c_void_p, c_double_p, C.c_int]
+    L.orc_nuc_get.argtypes = [C.c_void_p, c_double_p, C.c_int]
+    L.orc_nuc_reset.argtypes = [C.c_void_p]
+    L.orc_nuc_latency.argtypes = [C.c_void_p]
+    L.orc_nuc_get_plan.argtypes = [C.c_void_p, C.POINTER(NucPlan)]
+    L.orc_nuc_run.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int]
+    L.orc_direct_conv_at.argtypes = [c_double_p, C.c_int64, c_double_p, C.c_int,
+                                     C.POINTER(C.c_int64), C.c_int, c_double_p]
+    L.orc_eq_params_default.argtypes = [C.POINTER(EqParams)]
+    L.orc_svf_design.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, C.POINTER(SvfCoeffs)]
+    L.orc_fast_tanh_scalar.restype = C.c_double
+    L.orc_fast_tanh_scalar.argtypes = [C.c_double]
+    L.orc_fast_tanh_v128.restype = C.c_double
+    L.orc_fast_tanh_v128.argtypes = [C.c_double]
+    L.orc_svf_band_stereo_lane.argtypes = [c_double_p, C.c_int64, C.POINTER(SvfCoeffs), c_double_p, C.c_double]
+    L.orc_svf_band_mono.argtypes = [c_double_p, C.c_int64, C.POINTER(SvfCoeffs), c_double_p, C.c_double]
+    L.orc_eq_process_stereo.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, C.POINTER(EqParams),
+                                        C.c_double, c_double_p]
+    L.orc_equal_power_sin.restype = C.c_double
+    L.orc_equal_power_sin.argtypes = [C.c_double]
+    _LIB = L
+    return L
+
+
+def ref_probe():
+    """oracle/_ref/libcpq_ref_probe.so: the reference's own stand-alone headers, or None."""
+    global _REF
+    if _REF is not None:
+        return _REF
+    so = os.path.join(ORACLE_DIR, "_ref", "libcpq_ref_probe.so")
+    if not os.path.exists(so):
+        if os.path.isdir("/root/reference/src"):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+        if not os.path.exists(so):
+            return None
+    R = C.CDLL(so)
+    for n in ("ref_fast_tanh_scalar", "ref_fast_tanh_v128", "ref_fast_tanh_softclip_scalar"):
+        getattr(R, n).restype = C.c_double
+        getattr(R, n).argtypes = [C.c_double]
+    R.ref_eq_params_default.argtypes = [C.POINTER(EqParams)]
+    _REF = R
+    return R
+
+
+def dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+# ------------------------------------------------------------------ helpers
+def gen_pcm(n, seed=0xC0FFEE, stream=0, channel=0, start=0):
+    x = np.empty(n, dtype=np.float64)
+    lib().orc_gen_pcm(dp(x), n, seed, stream, channel, start)
+    return x
+
+
+def gen_ir(length, seed=0x1257, stream=0, channel=0):
+    h = np.empty(length, dtype=np.float64)
+    lib().orc_gen_ir(dp(h), length, seed, stream, channel)
+    return h
+
+
+def plan(ir_len, block, direct=False, spec=None):
+    p = NucPlan()
+    rc = lib().orc_nuc_plan_compute(ir_len, block, int(direct), C.byref(spec) if spec is not None else None,
+                                    C.byref(p))
+    if rc != 0:
+        raise ValueError("plan failed")
+    return p
+
+
+def heff(ir, block, scale=1.0, spec=None):
+    ir = np.ascontiguousarray(ir, dtype=np.float64)
+    sp = C.byref(spec) if spec is not None else None
+    need = lib().orc_nuc_heff(dp(ir), len(ir), block, scale, sp, None, 0)
+    out = np.zeros(need, dtype=np.float64)
+    lib().orc_nuc_heff(dp(ir), len(ir), block, scale, sp, dp(out), need)
+    return out
+
+
+class Nuc:
+    """Stateful restatement of MKLNonUniformConvolver (one mono channel)."""
+
+    def __init__(self):
+        self._h = lib().orc_nuc_create()
+
+    def close(self):
+        if self._h:
+            lib().orc_nuc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_impulse(self, ir, block, scale=1.0, direct=False, spec=None):
+        ir = np.ascontiguousarray(ir, dtype=np.float64)
+        return bool(lib().orc_nuc_set_impulse(self._h, dp(ir), len(ir), block, scale, int(direct),
+                                              C.byref(spec) if spec is not None else None))
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().orc_nuc_add(self._h, dp(x), len(x))
+
+    def get(self, n):
+        y = np.empty(n, dtype=np.float64)
+        got = lib().orc_nuc_get(self._h, dp(y), n)
+        return y, got
+
+    def run(self, x, block):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nb = len(x) // block
+        y = np.empty(nb * block, dtype=np.float64)
+        lib().orc_nuc_run(self._h, dp(x), dp(y), block, nb)
+        return y
+
+    def reset(self):
+        lib().orc_nuc_reset(self._h)
+
+    def latency(self):
+        return lib().orc_nuc_latency(self._h)
+
+    def plan(self):
+        p = NucPlan()
+        lib().orc_nuc_get_plan(self._h, C.byref(p))
+        return p
+
+
+def direct_conv_at(x, h, idx):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.ascontiguousarray(h, dtype=np.float64)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    y = np.empty(len(idx), dtype=np.float64)
+    lib().orc_direct_conv_at(dp(x), len(x), dp(h), len(h), idx.ctypes.data_as(C.POINTER(C.c_int64)), len(idx), dp(y))
+    return y
+
+
+def svf_design(btype, freq, gain_db, q, sr):
+    c = SvfCoeffs()
+    lib().orc_svf_design(btype, freq, gain_db, q, sr, C.byref(c))
+    return c
+
+
+def eq_params_default():
+    p = EqParams()
+    lib().orc_eq_params_default(C.byref(p))
+    return p
+
+
+BENCH_GAINS_DB = [3, -2, 4, -3, 2, -4, 3, -2, 1.5, -1.5, 2, -2, 3, -3, 1, -1, 2, -2, 1, -1]
+DEFAULT_FREQS = [25.0, 40.0, 63.0, 100.0, 160.0, 250.0, 400.0, 630.0, 1000.0, 1600.0,
+                 2500.0, 4000.0, 6300.0, 10000.0, 11000.0, 12500.0, 14000.0, 16500.0, 18000.0, 19500.0]
+
+
+def eq_params_bench(saturation=0.2):
+    """SURVEY.md 8(d) EQ bench preset: EQProcessor::DEFAULT_FREQS, Q 1.41, alternating gains,
+    band 0 LowShelf, band 19 HighShelf, rest Peaking, Stereo, Serial, AGC off, 0 dB total."""
+    p = eq_params_default()
+    for i in range(20):
+        b = p.bands[i]
+        b.frequency = DEFAULT_FREQS[i]
+        b.gain = BENCH_GAINS_DB[i]
+        b.q = 1.41
+        b.enabled = 1
+        b.type = 0 if i == 0 else (2 if i == 19 else 1)
+        b.channelMode = 0
+    p.nonlinearSaturation = saturation
+    return p
+
+
+def eq_process_stereo(xl, xr, params, sr=48000.0, block=512, state=None):
+    yl = np.array(xl, dtype=np.float64, copy=True)
+    yr = np.array(xr, dtype=np.float64, copy=True)
+    if state is None:
+        state = np.zeros(2 * 20 * 2, dtype=np.float64)
+    lib().orc_eq_process_stereo(dp(yl), dp(yr), len(yl), block, C.byref(params), sr, dp(state))
+    return yl, yr, state
