@@ -1,0 +1,125 @@
+"""ctypes binding of libconvopeq_mi355x.so (the C ABI declared in include/convopeq_mi355x.h).
+
+The library is the product; this module only loads it.  There is no Python or CPU fallback: if the
+shared object is missing or a symbol is absent, import fails loudly.
+"""
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libconvopeq_mi355x.so")
+
+CPQ_OK = 0
+CPQ_ERR_INVALID_ARG = -1
+CPQ_ERR_NO_DEVICE = -2
+CPQ_ERR_OOM = -3
+CPQ_ERR_DEVICE = -4
+CPQ_ERR_UNSUPPORTED = -5
+CPQ_ERR_NOT_READY = -6
+CPQ_ALL_STREAMS = -1
+CPQ_SEM_REFERENCE = 0
+CPQ_SEM_EXACT = 1
+CPQ_ORDER_CONV_THEN_EQ = 0
+CPQ_ORDER_EQ_THEN_CONV = 1
+KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4}
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class FilterSpec(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("hc_mode", C.c_int32), ("lc_mode", C.c_int32),
+                ("tail_mode", C.c_int32), ("tail_enabled", C.c_int32), ("tail_start_seconds", C.c_double),
+                ("tail_strength", C.c_double), ("tail_l1l2_multiplier", C.c_int32), ("reserved", C.c_int32)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        s = cls(48000.0, 1, 0, 1, 1, 0.085, 1.0, 8, 0)
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+
+class NucPlan(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("part_size", C.c_int32 * 3), ("offset", C.c_int32 * 3),
+                ("len", C.c_int32 * 3), ("num_parts_ir", C.c_int32 * 3), ("num_parts", C.c_int32 * 3),
+                ("parts_per_callback", C.c_int32 * 3), ("output_delay", C.c_int32 * 3),
+                ("gain", C.c_double * 3), ("direct_taps", C.c_int32), ("latency", C.c_int32),
+                ("lti_valid", C.c_int32), ("done_callback", C.c_int32 * 3), ("lag", C.c_int32 * 3),
+                ("heff_len", C.c_int32)]
+
+
+class SvfCoeffs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("g", "k", "a1", "a2", "a3", "m0", "m1", "m2")]
+
+
+class EqBand(C.Structure):
+    _fields_ = [("frequency", C.c_float), ("gain", C.c_float), ("q", C.c_float),
+                ("enabled", C.c_int32), ("type", C.c_int32), ("channel_mode", C.c_int32)]
+
+
+class EqParams(C.Structure):
+    _fields_ = [("bands", EqBand * 20), ("total_gain_db", C.c_float), ("agc_enabled", C.c_int32),
+                ("nonlinear_saturation", C.c_float), ("filter_structure", C.c_int32)]
+
+
+class EngineDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_streams", C.c_int32),
+                ("block_size", C.c_int32), ("max_ir_len", C.c_int32), ("max_blocks_per_call", C.c_int32),
+                ("semantics", C.c_int32), ("mac_tile", C.c_int32), ("sample_rate", C.c_double)]
+
+
+# every symbol include/convopeq_mi355x.h declares: (restype, argtypes)
+_E = C.c_void_p
+SYMBOLS = {
+    "cpq_abi_version": (C.c_int32, []),
+    "cpq_status_string": (C.c_char_p, [C.c_int32]),
+    "cpq_last_error": (C.c_char_p, [_E]),
+    "cpq_nuc_plan_compute": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(FilterSpec), C.POINTER(NucPlan)]),
+    "cpq_nuc_heff": (C.c_int32, [c_double_p, C.c_int32, C.c_int32, C.c_double, C.POINTER(FilterSpec), c_double_p, C.c_int32]),
+    "cpq_eq_design_svf": (C.c_int32, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_double, C.POINTER(SvfCoeffs)]),
+    "cpq_eq_params_default": (None, [C.POINTER(EqParams)]),
+    "cpq_engine_create": (C.c_int32, [C.POINTER(EngineDesc), C.POINTER(_E)]),
+    "cpq_engine_destroy": (None, [_E]),
+    "cpq_engine_set_stream": (C.c_int32, [_E, C.c_void_p]),
+    "cpq_engine_synchronize": (C.c_int32, [_E]),
+    "cpq_engine_arena_bytes": (C.c_int64, [_E]),
+    "cpq_engine_prepare": (C.c_int32, [_E, C.c_double, C.c_int32]),
+    "cpq_engine_set_order": (C.c_int32, [_E, C.c_int32]),
+    "cpq_conv_set_impulse": (C.c_int32, [_E, C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_int32, C.POINTER(FilterSpec)]),
+    "cpq_conv_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
+    "cpq_conv_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_conv_reset": (C.c_int32, [_E]),
+    "cpq_conv_is_ready": (C.c_int32, [_E]),
+    "cpq_conv_latency": (C.c_int32, [_E]),
+    "cpq_conv_get_plan": (C.c_int32, [_E, C.POINTER(NucPlan)]),
+    "cpq_eq_set_params": (C.c_int32, [_E, C.c_int32, C.POINTER(EqParams)]),
+    "cpq_eq_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
+    "cpq_eq_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_eq_reset": (C.c_int32, [_E]),
+    "cpq_engine_process_block": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
+    "cpq_engine_process_block_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_profile_enable": (C.c_int32, [_E, C.c_int32]),
+    "cpq_profile_reset": (C.c_int32, [_E]),
+    "cpq_profile_read": (C.c_int32, [_E, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "cpq_kernel_name": (C.c_char_p, [C.c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C convopeq_amd/csrc` (or __graft_entry__.build()). "
+            "convopeq_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)        # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,701 @@
+// cpq_api.cpp -- C ABI of libconvopeq_mi355x.so (see include/convopeq_mi355x.h).
+//
+// Host side of the engine: the device arena (the reference's per-buffer mkl_malloc manager,
+// src/AlignedAllocation.h:22-163 + src/MKLNonUniformConvolver.h:288-365, collapsed into one HBM
+// allocation laid out from (streams, partitions, ring slots, blocks per call)), the per-call kernel
+// sequence, and the prepare/set_impulse/set_params control surface.  No CPU fallback exists: without a
+// HIP device cpq_engine_create fails with CPQ_ERR_NO_DEVICE and nothing else can be called.
+#include "convopeq_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_design.hpp"
+#include "kernels.hpp"
+
+using cpq::kBands;
+using cpq::kP;
+
+namespace {
+
+std::string g_createError;
+std::mutex g_createErrorMutex;
+
+struct ProfileSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> freeList;
+    int64_t launches = 0;
+    double totalMs = 0.0;
+};
+
+}  // namespace
+
+struct cpq_engine {
+    cpq_engine_desc desc{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string lastError;
+
+    // geometry
+    int nCh = 0;          // 2 * streams
+    int kCap = 0;         // partition capacity per IR slot (multiple of kMacMaxTile)
+    int hRows = 0;        // kCap + prefetch rows allocated per IR slot
+    int ringSlots = 0;    // FDL ring slots per channel (power of two)
+    int tMax = 0;
+    int macTile = 16;
+
+    // device arena
+    char* arena = nullptr;
+    int64_t arenaBytes = 0;
+    double2* X = nullptr;       // [nCh][ringSlots][kP]       FDL ring of packed spectra
+    double2* XDN = nullptr;     // [nCh][ringSlots]           (DC, Nyquist) of every FDL slot
+    double2* H = nullptr;       // [nCh][hRows][kP]           IR partition spectra per IR slot
+    double2* HDN = nullptr;     // [nCh][hRows]
+    double2* Y = nullptr;       // [nCh][tMax][kP]            accumulated output spectra of the call
+    double* hist[2] = { nullptr, nullptr };   // [nCh][kP]    overlap history, ping-pong
+    double* stageIn = nullptr;  // [nCh][tMax*kP]             staging for the host-pointer entry points
+    double* stageOut = nullptr;
+    double* mid = nullptr;      // [nCh][tMax*kP]             conv <-> EQ hand-off (not used when in place)
+    double* heffDev = nullptr;  // staging for one h_eff upload
+    int64_t heffCap = 0;
+    double2* tw512 = nullptr;
+    double2* tw1024 = nullptr;
+    int* irSlot = nullptr;      // [nCh] device
+    double* svfCoef = nullptr;  // [nCh][20][6]
+    int* svfFlags = nullptr;    // [nCh][20]
+    double* svfSatGain = nullptr;   // [nCh][2]
+    double* svfState = nullptr; // [nCh][20][2]
+
+    // run-time state
+    int head = 0;               // ring slot of the next block
+    int histSel = 0;
+    int kActive = 0;            // max partitions over the loaded IRs (multiple of kMacMaxTile)
+    int kMaxReal = 0;           // max real partition count (DC/Nyquist loop bound)
+    std::vector<int> irSlotHost;
+    std::vector<char> irLoaded; // per channel
+    std::vector<int> irParts;   // per IR slot: partitions in use
+    cpq_nuc_plan plan{};        // plan of the most recent set_impulse
+    bool planValid = false;
+    bool eqSet = false;
+    int order = CPQ_ORDER_CONV_THEN_EQ;
+    double sampleRate = 48000.0;
+
+    // profiling
+    bool profiling = false;
+    ProfileSlot prof[CPQ_K_COUNT];
+};
+
+namespace {
+
+int fail(cpq_engine* e, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (e) e->lastError = buf;
+    else { std::lock_guard<std::mutex> lk(g_createErrorMutex); g_createError = buf; }
+    return code;
+}
+
+#define CPQ_HIP(e, call)                                                                             \
+    do {                                                                                             \
+        hipError_t err__ = (call);                                                                   \
+        if (err__ != hipSuccess)                                                                     \
+            return fail((e), CPQ_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(err__));      \
+    } while (0)
+
+int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+int64_t alignUp(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+cpq::FftTables tables(const cpq_engine* e) { return cpq::FftTables{ e->tw512, e->tw1024 }; }
+
+struct ProfScope {
+    cpq_engine* e;
+    int id;
+    hipEvent_t stop = nullptr;
+    ProfScope(cpq_engine* eng, int kid) : e(eng), id(kid)
+    {
+        if (!e->profiling) return;
+        ProfileSlot& s = e->prof[id];
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!s.freeList.empty()) { ev = s.freeList.back(); s.freeList.pop_back(); }
+        else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+        hipEventRecord(ev.first, e->stream);
+        stop = ev.second;
+        s.pending.push_back(ev);
+    }
+    ~ProfScope() { if (stop) hipEventRecord(stop, e->stream); }
+};
+
+int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int* T)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (!in || !out) return fail(e, CPQ_ERR_INVALID_ARG, "null buffer");
+    if (nSamples <= 0 || nSamples % e->desc.block_size != 0)
+        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d is not a positive multiple of block_size=%d", nSamples,
+                    e->desc.block_size);
+    const int t = nSamples / e->desc.block_size;
+    if (t > e->tMax)
+        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d exceeds max_blocks_per_call=%d blocks", nSamples, e->tMax);
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+        return fail(e, CPQ_ERR_INVALID_ARG, "buffers must be 16-byte aligned");
+    *T = t;
+    return CPQ_OK;
+}
+
+// --- enqueue helpers (device pointers, no sync) -----------------------------------------------------
+int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
+{
+    if (!cpq_conv_is_ready(e)) return fail(e, CPQ_ERR_NOT_READY, "set_impulse has not covered every stream");
+    const int64_t stride = (int64_t)T * kP;
+    {
+        ProfScope p(e, CPQ_K_RFFT_FWD);
+        cpq::launch_rfft_fwd_ols(e->stream, dIn, stride, e->hist[e->histSel], e->hist[e->histSel ^ 1], e->X, e->XDN,
+                                 tables(e), e->nCh, T, e->head, e->ringSlots);
+    }
+    {
+        ProfScope p(e, CPQ_K_FDL_MAC);
+        cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->nCh, e->kActive, e->ringSlots,
+                            e->head, T, (int64_t)e->hRows * kP);
+    }
+    {
+        ProfScope p(e, CPQ_K_DCNYQ);
+        cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN, e->irSlot, e->Y, e->nCh, e->kMaxReal, e->ringSlots,
+                                  e->head, T, e->hRows);
+    }
+    {
+        ProfScope p(e, CPQ_K_RFFT_INV);
+        cpq::launch_rfft_inv_ols(e->stream, e->Y, dOut, stride, tables(e), e->nCh, T);
+    }
+    CPQ_HIP(e, hipGetLastError());
+    e->head = (e->head + T) & (e->ringSlots - 1);
+    e->histSel ^= 1;
+    return CPQ_OK;
+}
+
+int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
+{
+    if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
+    {
+        ProfScope p(e, CPQ_K_SVF);
+        cpq::launch_svf_cascade(e->stream, dIn, dOut, (int64_t)T * kP, e->nCh, T * kP, e->svfCoef, e->svfFlags,
+                                e->svfSatGain, e->svfState);
+    }
+    CPQ_HIP(e, hipGetLastError());
+    return CPQ_OK;
+}
+
+template <typename F>
+int viaStaging(cpq_engine* e, const double* in, double* out, int nSamples, F&& body)
+{
+    int T = 0;
+    int rc = checkCall(e, in, out, nSamples, &T);
+    if (rc != CPQ_OK) return rc;
+    const size_t bytes = (size_t)e->nCh * nSamples * sizeof(double);
+    CPQ_HIP(e, hipSetDevice(e->device));
+    CPQ_HIP(e, hipMemcpyAsync(e->stageIn, in, bytes, hipMemcpyHostToDevice, e->stream));
+    rc = body(e->stageIn, e->stageOut, T);
+    if (rc != CPQ_OK) return rc;
+    CPQ_HIP(e, hipMemcpyAsync(out, e->stageOut, bytes, hipMemcpyDeviceToHost, e->stream));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    return CPQ_OK;
+}
+
+int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
+{
+    CPQ_HIP(e, hipSetDevice(e->device));
+    if (conv) {
+        CPQ_HIP(e, hipMemsetAsync(e->X, 0, (size_t)e->nCh * e->ringSlots * kP * sizeof(double2), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->XDN, 0, (size_t)e->nCh * e->ringSlots * sizeof(double2), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->hist[0], 0, (size_t)e->nCh * kP * sizeof(double), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * kP * sizeof(double), e->stream));
+        e->head = 0;
+        e->histSel = 0;
+    }
+    if (eq) CPQ_HIP(e, hipMemsetAsync(e->svfState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    return CPQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cpq_abi_version(void) { return CPQ_ABI_VERSION; }
+
+const char* cpq_status_string(int32_t s)
+{
+    switch (s) {
+        case CPQ_OK: return "ok";
+        case CPQ_ERR_INVALID_ARG: return "invalid argument";
+        case CPQ_ERR_NO_DEVICE: return "no usable HIP device";
+        case CPQ_ERR_OOM: return "out of device memory";
+        case CPQ_ERR_DEVICE: return "HIP runtime error";
+        case CPQ_ERR_UNSUPPORTED: return "not supported by this engine version";
+        case CPQ_ERR_NOT_READY: return "engine not ready";
+        default: return "unknown status";
+    }
+}
+
+const char* cpq_last_error(const cpq_engine* e)
+{
+    if (e) return e->lastError.c_str();
+    std::lock_guard<std::mutex> lk(g_createErrorMutex);
+    static thread_local std::string copy;
+    copy = g_createError;
+    return copy.c_str();
+}
+
+const char* cpq_kernel_name(int32_t id)
+{
+    switch (id) {
+        case CPQ_K_RFFT_FWD: return "k_rfft_fwd_ols";
+        case CPQ_K_FDL_MAC: return "k_fdl_mac";
+        case CPQ_K_DCNYQ: return "k_fdl_mac_dcnyq";
+        case CPQ_K_RFFT_INV: return "k_rfft_inv_ols";
+        case CPQ_K_SVF: return "k_svf_cascade";
+        default: return "?";
+    }
+}
+
+// ------------------------------------------------------------------ host-only helpers
+int32_t cpq_nuc_plan_compute(int32_t irLen, int32_t blockSize, int32_t direct, const cpq_filter_spec* spec,
+                             cpq_nuc_plan* plan)
+{
+    return cpq::computeNucPlan(irLen, blockSize, direct != 0, spec, plan);
+}
+
+int32_t cpq_nuc_heff(const double* ir, int32_t irLen, int32_t blockSize, double scale, const cpq_filter_spec* spec,
+                     double* heff, int32_t cap)
+{
+    if (!ir) return CPQ_ERR_INVALID_ARG;
+    std::vector<double> h;
+    cpq_nuc_plan p;
+    const int rc = cpq::buildHeff(ir, irLen, blockSize, scale, spec, h, &p);
+    if (rc != CPQ_OK) return rc;
+    if (heff && cap > 0) std::memcpy(heff, h.data(), sizeof(double) * (size_t)std::min<int>(cap, (int)h.size()));
+    return (int32_t)h.size();
+}
+
+int32_t cpq_eq_design_svf(int32_t type, float freq, float gainDb, float q, double sr, cpq_svf_coeffs* out)
+{
+    if (!out) return CPQ_ERR_INVALID_ARG;
+    cpq::designSvf(type, freq, gainDb, q, sr, out);
+    return CPQ_OK;
+}
+
+void cpq_eq_params_default(cpq_eq_params* p) { if (p) cpq::defaultEqParams(p); }
+
+// ------------------------------------------------------------------------------ engine
+int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
+{
+    if (!d || !out) return fail(nullptr, CPQ_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (d->struct_size != (int32_t)sizeof(cpq_engine_desc))
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "struct_size %d != %zu", d->struct_size, sizeof(cpq_engine_desc));
+    if (d->n_streams <= 0 || d->max_ir_len <= 0 || d->max_blocks_per_call <= 0)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "n_streams, max_ir_len and max_blocks_per_call must be positive");
+    if (d->block_size < 64 || d->block_size > 2048 || (d->block_size & (d->block_size - 1)))
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 2048]");
+    if (d->block_size != kP)
+        return fail(nullptr, CPQ_ERR_UNSUPPORTED, "this version implements block_size == %d only", kP);
+    if (d->semantics != CPQ_SEM_REFERENCE && d->semantics != CPQ_SEM_EXACT)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "bad semantics");
+    if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "mac_tile must be 0, 4, 8 or 16");
+
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+        return fail(nullptr, CPQ_ERR_NO_DEVICE, "no HIP device visible: the gfx950 kernels cannot run (no CPU fallback)");
+    if (d->device < 0 || d->device >= nDev)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "device %d out of range (%d visible)", d->device, nDev);
+    if (hipSetDevice(d->device) != hipSuccess) return fail(nullptr, CPQ_ERR_NO_DEVICE, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) != hipSuccess)
+        return fail(nullptr, CPQ_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, CPQ_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", d->device,
+                    prop.gcnArchName);
+
+    cpq_engine* e = new (std::nothrow) cpq_engine();
+    if (!e) return fail(nullptr, CPQ_ERR_OOM, "host allocation failed");
+    e->desc = *d;
+    e->device = d->device;
+    e->sampleRate = d->sample_rate > 0.0 ? d->sample_rate : 48000.0;
+    e->nCh = 2 * d->n_streams;
+    e->tMax = d->max_blocks_per_call;
+    e->macTile = d->mac_tile ? d->mac_tile : 16;
+
+    // partition capacity from the longest h_eff the plan can produce for max_ir_len
+    cpq_nuc_plan pl;
+    if (cpq::computeNucPlan(d->max_ir_len, d->block_size, false, nullptr, &pl) != CPQ_OK) {
+        delete e;
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "cannot plan max_ir_len=%d", d->max_ir_len);
+    }
+    const int taps = (d->semantics == CPQ_SEM_REFERENCE) ? std::max(pl.heff_len, d->max_ir_len) : d->max_ir_len;
+    const int kReal = (taps + kP - 1) / kP;
+    e->kCap = (int)alignUp(kReal, cpq::kMacMaxTile);
+    e->hRows = e->kCap + cpq::kMacMaxTile;   // zero rows read by the prefetch past the last partition
+    e->ringSlots = nextPow2(e->kCap + cpq::kMacMaxTile + e->tMax);
+    e->heffCap = (int64_t)e->kCap * kP;
+
+    // ---- arena layout
+    struct Item { void** ptr; int64_t bytes; };
+    const int64_t nCh = e->nCh;
+    const int64_t callSamples = (int64_t)e->tMax * kP;
+    Item items[] = {
+        { (void**)&e->X, nCh * e->ringSlots * kP * (int64_t)sizeof(double2) },
+        { (void**)&e->XDN, nCh * e->ringSlots * (int64_t)sizeof(double2) },
+        { (void**)&e->H, nCh * e->hRows * kP * (int64_t)sizeof(double2) },
+        { (void**)&e->HDN, nCh * e->hRows * (int64_t)sizeof(double2) },
+        { (void**)&e->Y, nCh * e->tMax * kP * (int64_t)sizeof(double2) },
+        { (void**)&e->hist[0], nCh * kP * (int64_t)sizeof(double) },
+        { (void**)&e->hist[1], nCh * kP * (int64_t)sizeof(double) },
+        { (void**)&e->stageIn, nCh * callSamples * (int64_t)sizeof(double) },
+        { (void**)&e->stageOut, nCh * callSamples * (int64_t)sizeof(double) },
+        { (void**)&e->mid, nCh * callSamples * (int64_t)sizeof(double) },
+        { (void**)&e->heffDev, e->heffCap * (int64_t)sizeof(double) },
+        { (void**)&e->tw512, 512 * (int64_t)sizeof(double2) },
+        { (void**)&e->tw1024, 512 * (int64_t)sizeof(double2) },
+        { (void**)&e->irSlot, nCh * (int64_t)sizeof(int) },
+        { (void**)&e->svfCoef, nCh * kBands * 6 * (int64_t)sizeof(double) },
+        { (void**)&e->svfFlags, nCh * kBands * (int64_t)sizeof(int) },
+        { (void**)&e->svfSatGain, nCh * 2 * (int64_t)sizeof(double) },
+        { (void**)&e->svfState, nCh * kBands * 2 * (int64_t)sizeof(double) },
+    };
+    int64_t total = 0;
+    for (const Item& it : items) total += alignUp(it.bytes, 256);
+    if (hipMalloc((void**)&e->arena, (size_t)total) != hipSuccess) {
+        (void)hipGetLastError();
+        delete e;
+        return fail(nullptr, CPQ_ERR_OOM, "device arena of %lld bytes could not be allocated", (long long)total);
+    }
+    e->arenaBytes = total;
+    int64_t off = 0;
+    for (const Item& it : items) { *it.ptr = e->arena + off; off += alignUp(it.bytes, 256); }
+
+    // everything starts zero: FDL, history, IR spectra (incl. padding rows), SVF state
+    if (hipMemset(e->arena, 0, (size_t)total) != hipSuccess) {
+        cpq_engine_destroy(e);
+        return fail(nullptr, CPQ_ERR_DEVICE, "hipMemset of the arena failed");
+    }
+    // twiddles in extended precision on the host, rounded once (SURVEY.md section 7 "hard parts")
+    std::vector<double2> w512(512), w1024(512);
+    const long double twoPi = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < 512; ++m) {
+        const long double a = -twoPi * m / 512.0L, b = -twoPi * m / 1024.0L;
+        w512[m] = make_double2((double)cosl(a), (double)sinl(a));
+        w1024[m] = make_double2((double)cosl(b), (double)sinl(b));
+    }
+    if (hipMemcpy(e->tw512, w512.data(), 512 * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->tw1024, w1024.data(), 512 * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) {
+        cpq_engine_destroy(e);
+        return fail(nullptr, CPQ_ERR_DEVICE, "twiddle upload failed");
+    }
+    e->irSlotHost.assign(e->nCh, 0);
+    for (int c = 0; c < e->nCh; ++c) e->irSlotHost[c] = c;
+    e->irLoaded.assign(e->nCh, 0);
+    e->irParts.assign(e->nCh, 0);
+    if (hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice) != hipSuccess) {
+        cpq_engine_destroy(e);
+        return fail(nullptr, CPQ_ERR_DEVICE, "irSlot upload failed");
+    }
+    *out = e;
+    return CPQ_OK;
+}
+
+void cpq_engine_destroy(cpq_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& s : e->prof) {
+        for (auto& ev : s.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+        for (auto& ev : s.freeList) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    }
+    if (e->arena) (void)hipFree(e->arena);
+    delete e;
+}
+
+int32_t cpq_engine_set_stream(cpq_engine* e, void* s)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    e->stream = reinterpret_cast<hipStream_t>(s);
+    return CPQ_OK;
+}
+
+int32_t cpq_engine_synchronize(cpq_engine* e)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    return CPQ_OK;
+}
+
+int64_t cpq_engine_arena_bytes(const cpq_engine* e) { return e ? e->arenaBytes : 0; }
+
+int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (sampleRate <= 0.0) return fail(e, CPQ_ERR_INVALID_ARG, "sample rate must be positive");
+    if (maxBlock <= 0 || maxBlock > e->desc.block_size * e->tMax)
+        return fail(e, CPQ_ERR_INVALID_ARG, "max_block %d exceeds block_size*max_blocks_per_call", maxBlock);
+    e->sampleRate = sampleRate;
+    return zeroRuntimeState(e, true, true);
+}
+
+int32_t cpq_engine_set_order(cpq_engine* e, int32_t order)
+{
+    if (!e || (order != CPQ_ORDER_CONV_THEN_EQ && order != CPQ_ORDER_EQ_THEN_CONV)) return CPQ_ERR_INVALID_ARG;
+    e->order = order;
+    return CPQ_OK;
+}
+
+// --------------------------------------------------------------------------- convolver
+int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, const double* irR, int32_t irLen,
+                             double scale, int32_t direct, const cpq_filter_spec* spec)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (!irL || !irR || irLen <= 0) return fail(e, CPQ_ERR_INVALID_ARG, "null impulse or non-positive length");
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (irLen > e->desc.max_ir_len) return fail(e, CPQ_ERR_INVALID_ARG, "ir_len %d > max_ir_len %d", irLen, e->desc.max_ir_len);
+    if (spec) return fail(e, CPQ_ERR_UNSUPPORTED, "non-NULL FilterSpec (per-partition HC/LC spectral gains) is not implemented");
+    if (direct) return fail(e, CPQ_ERR_UNSUPPORTED, "direct head is not implemented");
+
+    CPQ_HIP(e, hipSetDevice(e->device));
+    const double* irs[2] = { irL, irR };
+    // IR slots: stream s owns slots 2s, 2s+1; CPQ_ALL_STREAMS shares slots 0 and 1 between all streams
+    const int slotBase = (stream == CPQ_ALL_STREAMS) ? 0 : 2 * stream;
+    std::vector<double> heff;
+    for (int ch = 0; ch < 2; ++ch) {
+        cpq_nuc_plan pl;
+        int rc;
+        if (e->desc.semantics == CPQ_SEM_REFERENCE) {
+            rc = cpq::buildHeff(irs[ch], irLen, e->desc.block_size, scale, nullptr, heff, &pl);
+            if (rc != CPQ_OK) return fail(e, rc, "layer plan failed");
+            if (!pl.lti_valid)
+                return fail(e, CPQ_ERR_UNSUPPORTED,
+                            "the reference drops tail blocks for this IR length / block size (time-varying output)");
+        } else {
+            rc = cpq::computeNucPlan(irLen, e->desc.block_size, false, nullptr, &pl);
+            if (rc != CPQ_OK) return fail(e, rc, "layer plan failed");
+            heff.assign(irs[ch], irs[ch] + irLen);
+            if (std::abs(scale - 1.0) > 1e-12) for (double& v : heff) v *= scale;
+        }
+        const int parts = ((int)heff.size() + kP - 1) / kP;
+        if (parts > e->kCap) return fail(e, CPQ_ERR_INVALID_ARG, "h_eff needs %d partitions, capacity %d", parts, e->kCap);
+        const int slot = slotBase + ch;
+        CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        double2* Hs = e->H + (int64_t)slot * e->hRows * kP;
+        double2* HDNs = e->HDN + (int64_t)slot * e->hRows;
+        // stale partitions of a longer previous IR in this slot become zero rows
+        if (e->irParts[slot] > parts) {
+            CPQ_HIP(e, hipMemsetAsync(Hs + (int64_t)parts * kP, 0, (size_t)(e->irParts[slot] - parts) * kP * sizeof(double2), e->stream));
+            CPQ_HIP(e, hipMemsetAsync(HDNs + parts, 0, (size_t)(e->irParts[slot] - parts) * sizeof(double2), e->stream));
+        }
+        cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Hs, HDNs, tables(e), parts);
+        CPQ_HIP(e, hipGetLastError());
+        CPQ_HIP(e, hipStreamSynchronize(e->stream));   // heffDev is reused for the next channel
+        e->irParts[slot] = parts;
+        e->plan = pl;
+        e->planValid = true;
+    }
+    if (stream == CPQ_ALL_STREAMS) {
+        for (int c = 0; c < e->nCh; ++c) { e->irSlotHost[c] = c & 1; e->irLoaded[c] = 1; }
+    } else {
+        for (int ch = 0; ch < 2; ++ch) { e->irSlotHost[2 * stream + ch] = 2 * stream + ch; e->irLoaded[2 * stream + ch] = 1; }
+    }
+    CPQ_HIP(e, hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice));
+    int kMax = 0;
+    for (int c = 0; c < e->nCh; ++c) if (e->irLoaded[c]) kMax = std::max(kMax, e->irParts[e->irSlotHost[c]]);
+    e->kMaxReal = kMax;
+    e->kActive = (int)alignUp(kMax, cpq::kMacMaxTile);
+    return CPQ_OK;
+}
+
+int32_t cpq_conv_is_ready(const cpq_engine* e)
+{
+    if (!e) return 0;
+    for (char l : e->irLoaded) if (!l) return 0;
+    return 1;
+}
+
+int32_t cpq_conv_latency(const cpq_engine* e) { return (e && e->planValid) ? e->plan.latency : 0; }
+
+int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan)
+{
+    if (!e || !plan || !e->planValid) return CPQ_ERR_NOT_READY;
+    *plan = e->plan;
+    return CPQ_OK;
+}
+
+int32_t cpq_conv_reset(cpq_engine* e) { return e ? zeroRuntimeState(e, true, false) : CPQ_ERR_INVALID_ARG; }
+
+int32_t cpq_conv_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
+{
+    int T = 0;
+    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    if (rc != CPQ_OK) return rc;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    return enqueueConv(e, dIn, dOut, T);
+}
+
+int32_t cpq_conv_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
+{
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueConv(e, a, b, T); });
+}
+
+// ---------------------------------------------------------------------------------- EQ
+int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
+{
+    if (!e || !p) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (p->agc_enabled) return fail(e, CPQ_ERR_UNSUPPORTED, "AGC is not implemented");
+    if (p->filter_structure != 0) return fail(e, CPQ_ERR_UNSUPPORTED, "parallel filter structure is not implemented");
+    for (int b = 0; b < kBands; ++b)
+        if (p->bands[b].enabled && (p->bands[b].channel_mode < 0 || p->bands[b].channel_mode > 2))
+            return fail(e, CPQ_ERR_UNSUPPORTED, "band %d: Mid/Side channel modes are not implemented", b);
+
+    // createCoeffCache: bandActive = enabled && sr > 0; coefficients only for active bands
+    // (src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90)
+    double coef[2][kBands][6];
+    int flags[2][kBands];
+    for (int b = 0; b < kBands; ++b) {
+        const cpq_eq_band& bp = p->bands[b];
+        const bool active = bp.enabled && e->sampleRate > 0.0;
+        cpq_svf_coeffs c{ 0, 0, 0, 0, 0, 1, 0, 0 };
+        if (active) cpq::designSvf(bp.type, bp.frequency, bp.gain, bp.q, e->sampleRate, &c);
+        for (int ch = 0; ch < 2; ++ch) {
+            const double v[6] = { c.a1, c.a2, c.a3, c.m0, c.m1, c.m2 };
+            std::memcpy(coef[ch][b], v, sizeof(v));
+            // Stereo -> both channels through the packed SSE2+FMA kernel; Left/Right -> one channel, scalar kernel
+            const bool on = active && (bp.channel_mode == 0 || bp.channel_mode == 1 + ch);
+            flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0);
+        }
+    }
+    const double satGain[2] = { (double)p->nonlinear_saturation, cpq::totalGainLinear(p->total_gain_db) };
+
+    CPQ_HIP(e, hipSetDevice(e->device));
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    std::vector<double> hc((size_t)(s1 - s0) * 2 * kBands * 6), hs((size_t)(s1 - s0) * 2 * 2);
+    std::vector<int> hf((size_t)(s1 - s0) * 2 * kBands);
+    for (int s = s0; s < s1; ++s)
+        for (int ch = 0; ch < 2; ++ch) {
+            const size_t ci = (size_t)(s - s0) * 2 + ch;
+            std::memcpy(&hc[ci * kBands * 6], coef[ch], sizeof(coef[ch]));
+            std::memcpy(&hf[ci * kBands], flags[ch], sizeof(flags[ch]));
+            hs[ci * 2] = satGain[0];
+            hs[ci * 2 + 1] = satGain[1];
+        }
+    const size_t c0 = (size_t)s0 * 2;
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    CPQ_HIP(e, hipMemcpy(e->svfCoef + c0 * kBands * 6, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
+    CPQ_HIP(e, hipMemcpy(e->svfFlags + c0 * kBands, hf.data(), hf.size() * sizeof(int), hipMemcpyHostToDevice));
+    CPQ_HIP(e, hipMemcpy(e->svfSatGain + c0 * 2, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (stream == CPQ_ALL_STREAMS || e->desc.n_streams == 1) e->eqSet = true;
+    else e->eqSet = true;   // unset streams keep all-bands-inactive (pass-through) coefficients
+    return CPQ_OK;
+}
+
+int32_t cpq_eq_reset(cpq_engine* e) { return e ? zeroRuntimeState(e, false, true) : CPQ_ERR_INVALID_ARG; }
+
+int32_t cpq_eq_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
+{
+    int T = 0;
+    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    if (rc != CPQ_OK) return rc;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    return enqueueEq(e, dIn, dOut, T);
+}
+
+int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
+{
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueEq(e, a, b, T); });
+}
+
+// ------------------------------------------------------------------------ whole path
+static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
+{
+    int rc;
+    if (e->order == CPQ_ORDER_CONV_THEN_EQ) {
+        rc = enqueueConv(e, a, b, T);
+        if (rc == CPQ_OK) rc = enqueueEq(e, b, b, T);
+    } else {
+        rc = enqueueEq(e, a, e->mid, T);
+        if (rc == CPQ_OK) rc = enqueueConv(e, e->mid, b, T);
+    }
+    return rc;
+}
+
+int32_t cpq_engine_process_block_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
+{
+    int T = 0;
+    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    if (rc != CPQ_OK) return rc;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    return enqueueBoth(e, dIn, dOut, T);
+}
+
+int32_t cpq_engine_process_block(cpq_engine* e, const double* in, double* out, int32_t nSamples)
+{
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueBoth(e, a, b, T); });
+}
+
+// -------------------------------------------------------------------------- profiling
+int32_t cpq_profile_enable(cpq_engine* e, int32_t on)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    e->profiling = on != 0;
+    return CPQ_OK;
+}
+
+static int drainProfile(cpq_engine* e)
+{
+    CPQ_HIP(e, hipSetDevice(e->device));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    for (auto& s : e->prof) {
+        for (auto& ev : s.pending) {
+            float ms = 0.0f;
+            CPQ_HIP(e, hipEventElapsedTime(&ms, ev.first, ev.second));
+            s.totalMs += ms;
+            s.launches += 1;
+            s.freeList.push_back(ev);
+        }
+        s.pending.clear();
+    }
+    return CPQ_OK;
+}
+
+int32_t cpq_profile_reset(cpq_engine* e)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    const int rc = drainProfile(e);
+    for (auto& s : e->prof) { s.launches = 0; s.totalMs = 0.0; }
+    return rc;
+}
+
+int32_t cpq_profile_read(cpq_engine* e, int32_t id, int64_t* launches, double* totalMs)
+{
+    if (!e || id < 0 || id >= CPQ_K_COUNT) return CPQ_ERR_INVALID_ARG;
+    const int rc = drainProfile(e);
+    if (rc != CPQ_OK) return rc;
+    if (launches) *launches = e->prof[id].launches;
+    if (totalMs) *totalMs = e->prof[id].totalMs;
+    return CPQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// fft_kernels.hip -- wave-level fp64 real FFT kernels for gfx950 (CDNA4, wave64).
+//
+// One wavefront computes one 1024-point real transform as a 512-point complex FFT: 8 complex points
+// per lane in registers, three radix-8 passes, two exchanges through 9 KB of LDS whose strides (72 and
+// 66 complex) keep every ds_read_b128/ds_write_b128 lane group on distinct banks, then the real-FFT
+// split.  The overlap-save framing of the reference (copy [prev|cur], src/MKLNonUniformConvolver.cpp:
+// 1256-1258), its CCS de-interleave (:132-139, :1270-1283) and the output half selection (:1332) are
+// fused into the loads/stores, so a frame is read once from HBM and a spectrum written once.
+//
+// Replaces ippsFFTFwd_RToCCS_64f / ippsFFTInv_CCSToR_64f (src/FFTBackend.cpp:123-150) with the same
+// scaling convention (IPP_FFT_DIV_INV_BY_N: forward unscaled, inverse 1/N, :33-35).
+//
+// Spectrum layout ("packed"): 512 complex per transform; bin k (1..511) = X[k]; bin 0 = (X[0], X[512])
+// (DC and Nyquist are both real), so a spectrum is exactly 8 KB and a wave stores 1 KB per instruction.
+#include "kernels.hpp"
+
+namespace cpq {
+
+namespace {
+
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// a * w (INV = false) or a * conj(w) (INV = true)
+template <bool INV>
+__device__ __forceinline__ double2 cmulw(double2 a, double2 w)
+{
+    if (INV) return make_double2(fma(a.x, w.x, a.y * w.y), fma(a.y, w.x, -(a.x * w.y)));
+    return make_double2(fma(a.x, w.x, -(a.y * w.y)), fma(a.x, w.y, a.y * w.x));
+}
+
+// 4-point DFT of (t0..t3) -> (t0..t3), natural order
+template <bool INV>
+__device__ __forceinline__ void dft4(double2& t0, double2& t1, double2& t2, double2& t3)
+{
+    const double2 e0 = cadd(t0, t2), e1 = csub(t0, t2);
+    const double2 o0 = cadd(t1, t3), d = csub(t1, t3);
+    const double2 o1 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);   // * (+i) / * (-i)
+    t0 = cadd(e0, o0);
+    t1 = cadd(e1, o1);
+    t2 = csub(e0, o0);
+    t3 = csub(e1, o1);
+}
+
+// 8-point DFT in registers: v[p] <- sum_a W8^(a p) v[a], natural order in and out
+template <bool INV>
+__device__ __forceinline__ void dft8(double2 (&v)[8])
+{
+    constexpr double h = 0.70710678118654752440;
+    double2 s0 = cadd(v[0], v[4]), d0 = csub(v[0], v[4]);
+    double2 s1 = cadd(v[1], v[5]), d1 = csub(v[1], v[5]);
+    double2 s2 = cadd(v[2], v[6]), d2 = csub(v[2], v[6]);
+    double2 s3 = cadd(v[3], v[7]), d3 = csub(v[3], v[7]);
+    if (INV) {
+        d1 = make_double2(h * (d1.x - d1.y), h * (d1.x + d1.y));
+        d2 = make_double2(-d2.y, d2.x);
+        d3 = make_double2(-h * (d3.x + d3.y), h * (d3.x - d3.y));
+    } else {
+        d1 = make_double2(h * (d1.x + d1.y), h * (d1.y - d1.x));
+        d2 = make_double2(d2.y, -d2.x);
+        d3 = make_double2(h * (d3.y - d3.x), -h * (d3.x + d3.y));
+    }
+    dft4<INV>(s0, s1, s2, s3);
+    dft4<INV>(d0, d1, d2, d3);
+    v[0] = s0; v[2] = s1; v[4] = s2; v[6] = s3;
+    v[1] = d0; v[3] = d1; v[5] = d2; v[7] = d3;
+}
+
+constexpr int kLdsPerWave = 72 * 8;   // complex elements
+
+// 512-point complex FFT of one wave.  In: v[j] = z[lane + 64 j].  Out: v[r] = Z[lane + 64 r].
+// n = 64a + 8b + c, k = p + 8q + 64r:
+//   pass 1 over a (registers), twiddle W512^((8b+c) p); exchange -> lane (p, c), registers over b
+//   pass 2 over b, twiddle W64^(c q);                   exchange -> lane (p + 8q), registers over c
+//   pass 3 over c.
+template <bool INV>
+__device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, const double2* __restrict__ tw512,
+                                             int lane)
+{
+    dft8<INV>(v);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], tw512[lane * p]);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) lds[72 * p + lane] = v[p];
+    __syncthreads();
+    const int pp = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) v[b] = lds[72 * pp + 8 * b + cc];
+    __syncthreads();
+    dft8<INV>(v);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tw512[8 * cc * q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds[66 * cc + pp + 8 * q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = lds[66 * c + lane];
+    dft8<INV>(v);
+}
+
+// real-FFT split: Z (512-pt FFT of even+i*odd samples) -> packed spectrum of the 1024-pt real frame
+__device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, const double2* __restrict__ tw1024,
+                                                 int lane, double2* __restrict__ spec, double2* __restrict__ dcnyq)
+{
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lds[lane + 64 * r] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        const double2 zk = v[r];
+        const double2 zm = lds[(512 - k) & 511];
+        const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Z[k] + conj Z[512-k]) / 2
+        const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));   // (Z[k] - conj Z[512-k]) / 2
+        const double2 o = make_double2(d.y, -d.x);                                  // -i d
+        const double2 w = tw1024[k];
+        double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
+        if (k == 0) {
+            xk = make_double2(zk.x + zk.y, zk.x - zk.y);   // (DC, Nyquist)
+            *dcnyq = xk;
+        }
+        spec[k] = xk;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ in, int64_t chStride,
+                                                     const double* __restrict__ histOld,
+                                                     double* __restrict__ histNew, double2* __restrict__ X,
+                                                     double2* __restrict__ XDN, FftTables tw, int T, int head,
+                                                     int ringMask)
+{
+    __shared__ double2 lds[kLdsPerWave];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x / T;
+    const int t = blockIdx.x - c * T;
+    const double* cur = in + (int64_t)c * chStride + (int64_t)t * kP;
+    const double* prev = (t > 0) ? (cur - kP) : (histOld + (int64_t)c * kP);
+
+    double2 v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2*>(prev + 2 * (lane + 64 * j));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 + j] = *reinterpret_cast<const double2*>(cur + 2 * (lane + 64 * j));
+    if (t == T - 1) {   // overlap history for the next call (prevInputBuf, NUC.cpp:1258)
+        double* hn = histNew + (int64_t)c * kP;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(hn + 2 * (lane + 64 * j)) = v[4 + j];
+    }
+    wave_cfft512<false>(v, lds, tw.tw512, lane);
+    const int slot = (head + t) & ringMask;
+    const int64_t row = (int64_t)c * (ringMask + 1) + slot;
+    wave_split_store(v, lds, tw.tw1024, lane, X + row * kP, XDN + row);
+}
+
+__global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ heff, int heffLen,
+                                                   double2* __restrict__ H, double2* __restrict__ HDN, FftTables tw)
+{
+    __shared__ double2 lds[kLdsPerWave];
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x;
+    double2 v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = k * kP + 2 * (lane + 64 * j);
+        v[j] = make_double2(i < heffLen ? heff[i] : 0.0, (i + 1) < heffLen ? heff[i + 1] : 0.0);
+    }
+#pragma unroll
+    for (int j = 4; j < 8; ++j) v[j] = make_double2(0.0, 0.0);   // zero-padded second half (NUC.cpp:921-928)
+    wave_cfft512<false>(v, lds, tw.tw512, lane);
+    wave_split_store(v, lds, tw.tw1024, lane, H + (int64_t)k * kP, HDN + k);
+}
+
+__global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__ Y, double* __restrict__ out,
+                                                     int64_t chStride, FftTables tw, int T)
+{
+    __shared__ double2 lds[kLdsPerWave];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x / T;
+    const int t = blockIdx.x - c * T;
+    const double2* y = Y + (int64_t)blockIdx.x * kP;
+
+    double2 v[8];
+    const double2 y0 = y[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = lane + 64 * j;
+        const double2 yk = y[k];
+        const double2 ym = y[(512 - k) & 511];
+        const double2 e = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y - ym.y));
+        const double2 d = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y + ym.y));
+        const double2 w = tw.tw1024[k];
+        const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));   // d * conj(w)
+        double2 z = make_double2(e.x - o.y, e.y + o.x);                                          // E + i O
+        if (k == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
+        v[j] = z;
+    }
+    wave_cfft512<true>(v, lds, tw.tw512, lane);
+    // second half of the 1024-sample frame: z[n], n = lane + 64 r, r = 4..7  (NUC.cpp:1332)
+    double* o = out + (int64_t)c * chStride + (int64_t)t * kP;
+    constexpr double s = 1.0 / 512.0;
+#pragma unroll
+    for (int r = 4; r < 8; ++r)
+        *reinterpret_cast<double2*>(o + 2 * (lane + 64 * (r - 4))) = make_double2(v[r].x * s, v[r].y * s);
+}
+
+}  // namespace
+
+void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
+                         double* histNew, double2* X, double2* XDN, FftTables tw, int nCh, int T, int head,
+                         int ringSlots)
+{
+    hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
+                       tw, T, head, ringSlots - 1);
+}
+
+void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN, FftTables tw,
+                       int nParts)
+{
+    hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
+}
+
+void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int nCh,
+                         int T)
+{
+    hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
+}
+
+}  // namespace cpq

@@ -1,0 +1,197 @@
+// host_design.cpp -- host-side (non-GPU) design math of libconvopeq_mi355x:
+//   * the layer plan MKLNonUniformConvolver::SetImpulse derives and the closed-form effective
+//     impulse response h_eff that makes the reference's observable output one linear convolution
+//   * EQProcessor::calcSVFCoeffs
+// Product code: never calls into oracle/.  Reference citations are relative to the reference tree.
+#include "host_design.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace cpq {
+
+namespace {
+
+template <typename T>
+T limit(T lo, T hi, T v) { return v < lo ? lo : (hi < v ? hi : v); }   // juce::jlimit
+
+int nextPow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+constexpr int kL0MaxParts = 32;   // src/MKLNonUniformConvolver.h:392
+constexpr int kL1MaxParts = 64;   // src/MKLNonUniformConvolver.h:393
+constexpr int kMaxDirectTaps = 32;  // src/MKLNonUniformConvolver.cpp:689
+
+}  // namespace
+
+// src/MKLNonUniformConvolver.cpp:626-684 (tail profile), :689-695 (direct head), :738-758 (layers),
+// :784-786 (slots), :988-994 (partsPerCallback), :1005-1024 (B13 output delay)
+int computeNucPlan(int irLen, int blockSize, bool enableDirectHead, const cpq_filter_spec* spec,
+                   cpq_nuc_plan* out)
+{
+    if (irLen <= 0 || blockSize <= 0 || out == nullptr) return CPQ_ERR_INVALID_ARG;
+    cpq_nuc_plan p;
+    std::memset(&p, 0, sizeof(p));
+
+    const int tailMode = spec ? limit(0, 2, static_cast<int>(spec->tail_mode)) : 1;
+    const bool tailEnabled = (tailMode != 2) && (spec ? spec->tail_enabled != 0 : true);
+    const double fsTail = spec ? spec->sample_rate : 48000.0;
+    double tailStart = spec ? limit(0.01, 0.80, spec->tail_start_seconds) : 0.085;
+    const double userStrength = spec ? limit(0.0, 2.0, spec->tail_strength) : 1.0;
+    double strength = userStrength;
+    int mult = spec ? limit(2, 16, static_cast<int>(spec->tail_l1l2_multiplier)) : 8;
+    const double s01 = limit(0.0, 1.0, userStrength * 0.5);
+    double g1 = 1.0, g2 = 1.0;
+
+    if (!tailEnabled || tailMode == 2) {
+        g1 = g2 = 0.0;
+    } else if (tailMode == 0) {
+        tailStart = limit(0.01, 0.80, std::max(tailStart, 0.055));
+        mult = limit(2, 16, std::max(mult, 6));
+        strength = limit(0.0, 2.0, userStrength);
+        g1 = limit(0.0, 2.0, strength * (0.95 - 0.25 * s01));
+        g2 = limit(0.0, 2.0, strength * (0.80 - 0.45 * s01));
+    } else {
+        tailStart = limit(0.01, 0.80, std::max(tailStart, 0.12));
+        strength = limit(0.0, 2.0, std::max(strength, 1.25));
+        mult = limit(2, 16, std::max(mult, 8));
+        g1 = limit(0.0, 2.0, strength * (1.05 + 0.20 * s01));
+        g2 = limit(0.0, 2.0, strength * (0.82 + 0.12 * s01));
+    }
+
+    const int p0 = nextPow2(std::max(blockSize, 64));
+    p.direct_taps = enableDirectHead ? std::min(irLen, std::min(p0, kMaxDirectTaps)) : 0;
+    const int partOf[3] = { p0, p0 * mult, p0 * mult * mult };
+
+    const int l0Cap = kL0MaxParts * p0;
+    const int l0Wanted = limit(p0, l0Cap, static_cast<int>(std::llround(tailStart * fsTail)));
+    const int l0 = std::min(irLen, tailEnabled ? l0Wanted : l0Cap);
+    const int l1 = tailEnabled ? std::max(0, std::min(irLen - l0, kL1MaxParts * partOf[1])) : 0;
+    const int l2 = tailEnabled ? std::max(0, irLen - l0 - l1) : 0;
+    const int lenOf[3] = { l0, l1, l2 };
+    const int offOf[3] = { 0, l0, l0 + l1 };
+    const double gainOf[3] = { 1.0, g1, g2 };
+
+    int n = 0, before = 0;
+    p.lti_valid = (blockSize == p0) ? 1 : 0;
+    int heffLen = 0;
+    for (int li = 0; li < 3; ++li) {
+        if (lenOf[li] <= 0) continue;
+        p.part_size[n] = partOf[li];
+        p.offset[n] = offOf[li];
+        p.len[n] = lenOf[li];
+        p.num_parts_ir[n] = (lenOf[li] + partOf[li] - 1) / partOf[li];
+        p.num_parts[n] = nextPow2(p.num_parts_ir[n]);
+        p.gain[n] = gainOf[li];
+        p.output_delay[n] = before;
+        if (li > 0) {
+            const int blocksPerPart = (partOf[li] + blockSize - 1) / blockSize;
+            int ppc = std::max(1, (p.num_parts_ir[n] + blocksPerPart - 1) / blocksPerPart);
+            ppc = std::min(ppc, p.num_parts_ir[n]);
+            p.parts_per_callback[n] = ppc;
+            // first tail block: input complete at callback blocksPerPart-1, MAC spread over
+            // ceil(numPartsIR/ppc) callbacks starting there, written + read in the last of them
+            p.done_callback[n] = (blocksPerPart - 1) + ((p.num_parts_ir[n] + ppc - 1) / ppc - 1);
+            p.lag[n] = p.done_callback[n] * blockSize - p.offset[n];
+            if (p.part_size[n] > p.output_delay[n]) p.lti_valid = 0;   // reader skips blocks (:1658-1666)
+        }
+        heffLen = std::max(heffLen, p.offset[n] + p.lag[n] + p.len[n]);
+        before += lenOf[li];
+        ++n;
+    }
+    if (n == 0) return CPQ_ERR_INVALID_ARG;
+    p.num_layers = n;
+    p.latency = p0;
+    p.heff_len = heffLen;
+    *out = p;
+    return CPQ_OK;
+}
+
+int buildHeff(const double* ir, int irLen, int blockSize, double scale, const cpq_filter_spec* spec,
+              std::vector<double>& heff, cpq_nuc_plan* planOut)
+{
+    cpq_nuc_plan p;
+    const int rc = computeNucPlan(irLen, blockSize, false, spec, &p);
+    if (rc != CPQ_OK) return rc;
+    heff.assign(static_cast<size_t>(p.heff_len), 0.0);
+    // cblas_dscal of every partition spectrum (:939-940) == scaling the taps
+    const bool scaled = std::abs(scale - 1.0) > 1e-12;
+    for (int l = 0; l < p.num_layers; ++l) {
+        const int at = p.offset[l] + p.lag[l];
+        for (int i = 0; i < p.len[l]; ++i) {
+            const int d = at + i;
+            if (d < 0) continue;
+            const double tap = scaled ? ir[p.offset[l] + i] * scale : ir[p.offset[l] + i];
+            heff[static_cast<size_t>(d)] += p.gain[l] * tap;
+        }
+    }
+    if (planOut) *planOut = p;
+    return CPQ_OK;
+}
+
+// src/eqprocessor/EQProcessor.Coefficients.cpp:84-96 (clamps, float), :101-130, :431-618
+void designSvf(int type, float freq, float gainDb, float q, double sr, cpq_svf_coeffs* c)
+{
+    auto bypass = [c]() { c->a1 = 1.0; c->a2 = 0.0; c->a3 = 0.0; c->m0 = 1.0; c->m1 = 0.0; c->m2 = 0.0; };
+    *c = cpq_svf_coeffs{ 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0 };
+    if (sr <= 0.0) { bypass(); return; }
+
+    const float nyquist = static_cast<float>(sr * 0.5);
+    const float fMax = std::min(20000.0f, nyquist * 0.95f);
+    freq = limit(20.0f, fMax, freq);
+    q = limit(0.01f, 20.0f, q);
+    gainDb = limit(-48.0f, 48.0f, gainDb);
+
+    const double f = freq, gdb = gainDb, Q = q;
+    const double pi = 3.141592653589793238462643383279502884;   // juce::MathConstants<double>::pi
+    double A = 1.0, g = 0.0, k = 0.0;
+    switch (type) {
+        case 0: A = std::pow(10.0, gdb / 40.0); g = std::tan(pi * f / sr) / std::sqrt(A); k = 1.0 / Q; break;
+        case 1: A = std::pow(10.0, gdb / 40.0); g = std::tan(pi * f / sr); k = 1.0 / (Q * A); break;
+        case 2: A = std::pow(10.0, gdb / 40.0); g = std::tan(pi * f / sr) * std::sqrt(A); k = 1.0 / Q; break;
+        case 3: case 4: g = std::tan(pi * f / sr); k = 1.0 / Q; break;
+        default: return;   // `return {}`
+    }
+    if (!std::isfinite(g) || !std::isfinite(k)) { bypass(); return; }
+    const double den = 1.0 + g * (g + k);
+    if (std::abs(den) < 1.0e-15) { bypass(); return; }
+    c->a1 = 1.0 / den;
+    c->a2 = g * c->a1;
+    c->a3 = g * c->a2;
+    switch (type) {
+        case 0: c->m0 = 1.0;   c->m1 = k * (A - 1.0);     c->m2 = A * A - 1.0; break;
+        case 1: c->m0 = 1.0;   c->m1 = (A - 1.0 / A) / Q; c->m2 = 0.0; break;
+        case 2: c->m0 = A * A; c->m1 = k * (1.0 - A) * A; c->m2 = 1.0 - A * A; break;
+        case 3: c->m0 = 0.0;   c->m1 = 0.0;               c->m2 = 1.0; break;
+        case 4: c->m0 = 1.0;   c->m1 = -k;                c->m2 = -1.0; break;
+    }
+}
+
+// src/core/EQParameters.h:31-46
+void defaultEqParams(cpq_eq_params* p)
+{
+    static const float f[CPQ_NUM_BANDS] = { 20.0f, 32.0f, 50.0f, 80.0f, 125.0f, 200.0f, 315.0f, 500.0f,
+                                            800.0f, 1250.0f, 2000.0f, 3150.0f, 5000.0f, 8000.0f, 12500.0f,
+                                            16000.0f, 19000.0f, 20000.0f, 22000.0f, 24000.0f };
+    std::memset(p, 0, sizeof(*p));
+    for (int i = 0; i < CPQ_NUM_BANDS; ++i)
+        p->bands[i] = cpq_eq_band{ f[i], 0.0f, 0.707f, 1, 1, 0 };
+    p->total_gain_db = 0.0f;
+    p->agc_enabled = 0;
+    p->nonlinear_saturation = 0.2f;
+    p->filter_structure = 0;
+}
+
+// juce::Decibels::decibelsToGain<double> as used by storeTotalGainDb (src/eqprocessor/EQProcessor.h:447-451)
+double totalGainLinear(float db)
+{
+    const double d = db;
+    return d > -100.0 ? std::pow(10.0, d * 0.05) : 0.0;
+}
+
+}  // namespace cpq

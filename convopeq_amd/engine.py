@@ -1,0 +1,172 @@
+"""Host-side harness over the C ABI (tests / bench plumbing).
+
+`BatchedEngine` mirrors the reference's processor surface for the hot path, batched over S stereo streams:
+  prepare_to_play(sample_rate, max_block)   <- ConvolverProcessor/EQProcessor::prepareToPlay
+  set_impulse(stream, ir_l, ir_r, ...)      <- StereoConvolver::init -> MKLNonUniformConvolver::SetImpulse
+  set_eq_params(stream, params)             <- EQProcessor::createCoeffCache + process(block, params, cache)
+  process(...) / conv_process / eq_process  <- ConvolverProcessor::process / EQProcessor::process
+All numerical work happens in libconvopeq_mi355x.so on the GPU; numpy is only the host buffer type.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+
+
+class CpqError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"cpq status {status} ({K.load().cpq_status_string(status).decode()}): {msg}")
+        self.status = status
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(K.c_double_p)
+
+
+def nuc_plan(ir_len, block, direct=False, spec=None):
+    p = K.NucPlan()
+    rc = K.load().cpq_nuc_plan_compute(ir_len, block, int(direct), C.byref(spec) if spec is not None else None,
+                                       C.byref(p))
+    if rc != 0:
+        raise CpqError(rc, "cpq_nuc_plan_compute")
+    return p
+
+
+def nuc_heff(ir, block, scale=1.0, spec=None):
+    ir = np.ascontiguousarray(ir, dtype=np.float64)
+    sp = C.byref(spec) if spec is not None else None
+    n = K.load().cpq_nuc_heff(_dp(ir), len(ir), block, scale, sp, None, 0)
+    if n < 0:
+        raise CpqError(n, "cpq_nuc_heff")
+    out = np.zeros(n, dtype=np.float64)
+    K.load().cpq_nuc_heff(_dp(ir), len(ir), block, scale, sp, _dp(out), n)
+    return out
+
+
+def design_svf(btype, freq, gain_db, q, sr):
+    c = K.SvfCoeffs()
+    rc = K.load().cpq_eq_design_svf(btype, freq, gain_db, q, sr, C.byref(c))
+    if rc != 0:
+        raise CpqError(rc, "cpq_eq_design_svf")
+    return c
+
+
+def eq_params_default():
+    p = K.EqParams()
+    K.load().cpq_eq_params_default(C.byref(p))
+    return p
+
+
+class BatchedEngine:
+    def __init__(self, n_streams, block_size=512, max_ir_len=131072, max_blocks_per_call=64,
+                 semantics=K.CPQ_SEM_REFERENCE, device=0, sample_rate=48000.0, mac_tile=0):
+        self._lib = K.load()
+        self._h = K._E()
+        d = K.EngineDesc(C.sizeof(K.EngineDesc), device, n_streams, block_size, max_ir_len, max_blocks_per_call,
+                         semantics, mac_tile, sample_rate)
+        rc = self._lib.cpq_engine_create(C.byref(d), C.byref(self._h))
+        if rc != 0:
+            raise CpqError(rc, self._lib.cpq_last_error(None).decode())
+        self.n_streams = n_streams
+        self.n_channels = 2 * n_streams
+        self.block_size = block_size
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cpq_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CpqError(rc, self._lib.cpq_last_error(self._h).decode())
+
+    # ---- control surface
+    def set_stream(self, hip_stream_ptr):
+        self._ck(self._lib.cpq_engine_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self._lib.cpq_engine_synchronize(self._h))
+
+    def arena_bytes(self):
+        return self._lib.cpq_engine_arena_bytes(self._h)
+
+    def prepare_to_play(self, sample_rate, max_block):
+        self._ck(self._lib.cpq_engine_prepare(self._h, sample_rate, max_block))
+
+    def set_order(self, order):
+        self._ck(self._lib.cpq_engine_set_order(self._h, order))
+
+    def set_impulse(self, stream, ir_l, ir_r, scale=1.0, direct_head=False, spec=None):
+        ir_l = np.ascontiguousarray(ir_l, dtype=np.float64)
+        ir_r = np.ascontiguousarray(ir_r, dtype=np.float64)
+        assert len(ir_l) == len(ir_r)
+        self._ck(self._lib.cpq_conv_set_impulse(self._h, stream, _dp(ir_l), _dp(ir_r), len(ir_l), scale,
+                                                int(direct_head), C.byref(spec) if spec is not None else None))
+
+    def set_eq_params(self, stream, params):
+        self._ck(self._lib.cpq_eq_set_params(self._h, stream, C.byref(params)))
+
+    def conv_reset(self):
+        self._ck(self._lib.cpq_conv_reset(self._h))
+
+    def eq_reset(self):
+        self._ck(self._lib.cpq_eq_reset(self._h))
+
+    def is_ready(self):
+        return bool(self._lib.cpq_conv_is_ready(self._h))
+
+    def latency(self):
+        return self._lib.cpq_conv_latency(self._h)
+
+    def plan(self):
+        p = K.NucPlan()
+        self._ck(self._lib.cpq_conv_get_plan(self._h, C.byref(p)))
+        return p
+
+    # ---- host-buffer processing: x is [n_channels, n_samples] float64
+    def _host(self, fn, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        y = np.empty_like(x)
+        self._ck(fn(self._h, _dp(x), _dp(y), x.shape[1]))
+        return y
+
+    def conv_process(self, x):
+        return self._host(self._lib.cpq_conv_process, x)
+
+    def eq_process(self, x):
+        return self._host(self._lib.cpq_eq_process, x)
+
+    def process(self, x):
+        return self._host(self._lib.cpq_engine_process_block, x)
+
+    # ---- device-pointer processing (no sync): raw HBM addresses
+    def conv_process_device(self, d_in, d_out, n_samples):
+        self._ck(self._lib.cpq_conv_process_device(self._h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples))
+
+    def eq_process_device(self, d_in, d_out, n_samples):
+        self._ck(self._lib.cpq_eq_process_device(self._h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples))
+
+    def process_device(self, d_in, d_out, n_samples):
+        self._ck(self._lib.cpq_engine_process_block_device(self._h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples))
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        self._ck(self._lib.cpq_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self._lib.cpq_profile_reset(self._h))
+
+    def profile_read(self):
+        out = {}
+        for name, kid in K.KERNEL_IDS.items():
+            n = C.c_int64()
+            ms = C.c_double()
+            self._ck(self._lib.cpq_profile_read(self._h, kid, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out

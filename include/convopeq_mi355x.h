@@ -1,0 +1,228 @@
+/*
+ * convopeq_mi355x.h -- C ABI of libconvopeq_mi355x.so
+ *
+ * MI355X-native (gfx950) batched drop-in for ONE hot path of lonewolf-jp/ConvoPeq:
+ * the fp64 impulse-response convolver plus the 20-band TPT-SVF parametric EQ,
+ * batched over S independent stereo streams (channel c = 2*stream + {0:L,1:R}).
+ *
+ * Boundary: this header is what the reference's FFI for the path would bind.
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the reference tree).  Plain pointers and sizes only; no C++/torch types; no
+ * exceptions cross the ABI; every call returns a cpq_status (0 = ok, <0 = error)
+ * unless noted.  One host thread per engine handle; handles are independent
+ * (one per GPU / per process).
+ *
+ * PCM layout: planar [stream][channel][sample] fp64, i.e. channel c starts at
+ * c * nSamples doubles.  The *_device entry points take device (HBM) pointers
+ * and enqueue on the engine's stream without synchronising; the host-pointer
+ * twins stage through the engine's device arena and return when the result is
+ * in host memory.
+ */
+#ifndef CONVOPEQ_MI355X_H
+#define CONVOPEQ_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPQ_ABI_VERSION 1
+
+typedef enum {
+    CPQ_OK               =  0,
+    CPQ_ERR_INVALID_ARG  = -1,
+    CPQ_ERR_NO_DEVICE    = -2,   /* no gfx950 device / HIP runtime failure at create */
+    CPQ_ERR_OOM          = -3,
+    CPQ_ERR_DEVICE       = -4,   /* a HIP call failed; see cpq_last_error() */
+    CPQ_ERR_UNSUPPORTED  = -5,   /* valid in the reference, not implemented by this engine yet */
+    CPQ_ERR_NOT_READY    = -6    /* process before set_impulse / prepare */
+} cpq_status;
+
+#define CPQ_ALL_STREAMS (-1)
+#define CPQ_NUM_BANDS   20       /* EQProcessor::NUM_BANDS, src/eqprocessor/EQProcessor.h:153 */
+
+/* what "the convolution" means for IRs longer than the reference's layer 0 */
+typedef enum {
+    /* y = x * h_eff: the closed form of MKLNonUniformConvolver's observable output (tail-layer
+     * contouring gains and the constant layer lags of the distributed-MAC schedule and the B13 delay
+     * line, src/MKLNonUniformConvolver.cpp:626-684,988-994,1497-1545,1653-1688).
+     * Valid iff the reference itself is LTI for the configuration (cpq_nuc_plan.lti_valid). */
+    CPQ_SEM_REFERENCE = 0,
+    /* y = x * h: the mathematically exact linear convolution (== reference whenever irLen <= layer 0) */
+    CPQ_SEM_EXACT = 1
+} cpq_semantics;
+
+typedef enum { CPQ_ORDER_CONV_THEN_EQ = 0, CPQ_ORDER_EQ_THEN_CONV = 1 } cpq_order;
+
+/* POD mirror of convo::FilterSpec, src/MKLNonUniformConvolver.h:123-133 */
+typedef struct {
+    double  sample_rate;
+    int32_t hc_mode;                 /* HCMode: 0 Sharp, 1 Natural, 2 Soft (src/OutputFilter.h:75-80) */
+    int32_t lc_mode;                 /* LCMode: 0 Natural, 1 Soft         (src/OutputFilter.h:85-89) */
+    int32_t tail_mode;               /* 0 air absorption, 1 layer tail contouring, 2 bypass */
+    int32_t tail_enabled;
+    double  tail_start_seconds;
+    double  tail_strength;
+    int32_t tail_l1l2_multiplier;
+    int32_t reserved;
+} cpq_filter_spec;
+
+/* The layer plan SetImpulse derives (src/MKLNonUniformConvolver.cpp:738-758,784-786,988-994,
+ * 1005-1024) plus the A6 closed-form lags.  Host-only computation, no GPU needed. */
+typedef struct {
+    int32_t num_layers;
+    int32_t part_size[3];
+    int32_t offset[3];
+    int32_t len[3];
+    int32_t num_parts_ir[3];
+    int32_t num_parts[3];
+    int32_t parts_per_callback[3];
+    int32_t output_delay[3];
+    double  gain[3];
+    int32_t direct_taps;
+    int32_t latency;                 /* MKLNonUniformConvolver::getLatency(), src/MKLNonUniformConvolver.h:242 */
+    int32_t lti_valid;
+    int32_t done_callback[3];
+    int32_t lag[3];
+    int32_t heff_len;                /* taps of h_eff */
+} cpq_nuc_plan;
+
+/* POD mirror of EQCoeffsSVF, src/eqprocessor/EQProcessor.h:91-96 */
+typedef struct { double g, k, a1, a2, a3, m0, m1, m2; } cpq_svf_coeffs;
+
+/* POD mirror of convo::EQBandParams / convo::EQParameters, src/core/EQParameters.h:13-47 */
+typedef struct {
+    float   frequency;
+    float   gain;
+    float   q;
+    int32_t enabled;
+    int32_t type;                    /* 0 LowShelf, 1 Peaking, 2 HighShelf, 3 LowPass, 4 HighPass */
+    int32_t channel_mode;            /* 0 Stereo, 1 Left, 2 Right (3 Mid / 4 Side: CPQ_ERR_UNSUPPORTED) */
+} cpq_eq_band;
+
+typedef struct {
+    cpq_eq_band bands[CPQ_NUM_BANDS];
+    float   total_gain_db;
+    int32_t agc_enabled;             /* must be 0 (AGC: CPQ_ERR_UNSUPPORTED) */
+    float   nonlinear_saturation;    /* default 0.2 */
+    int32_t filter_structure;        /* 0 Serial (1 Parallel: CPQ_ERR_UNSUPPORTED) */
+} cpq_eq_params;
+
+typedef struct {
+    int32_t struct_size;             /* sizeof(cpq_engine_desc) */
+    int32_t device;                  /* HIP device ordinal */
+    int32_t n_streams;               /* S stereo streams -> 2*S channels */
+    int32_t block_size;              /* B: the caller's block / callQuantum; power of two, 64..2048;
+                                        partition size P == B (layer-0 partSize of the reference) */
+    int32_t max_ir_len;              /* longest IR (taps) any stream will be given */
+    int32_t max_blocks_per_call;     /* T_max: a process call carries 1..T_max blocks of B samples
+                                        (reference: up to 524288 samples per process(),
+                                        src/convolver/ConvolverProcessor.Runtime.cpp:609,667-682) */
+    int32_t semantics;               /* cpq_semantics */
+    int32_t mac_tile;                /* 0 = default; else outputs per lane in the FDL MAC kernel (4/8/16) */
+    double  sample_rate;
+} cpq_engine_desc;
+
+typedef struct cpq_engine cpq_engine;
+
+/* ------------------------------------------------------------------ library */
+int32_t     cpq_abi_version(void);
+const char* cpq_status_string(int32_t status);
+/* last error text of this handle (or of the last failed create when e == NULL) */
+const char* cpq_last_error(const cpq_engine* e);
+
+/* ------------------------------------------------- host-only design helpers */
+/* MKLNonUniformConvolver::SetImpulse layer plan (src/MKLNonUniformConvolver.cpp:626-684,738-758).
+ * spec may be NULL (reference default: tail mode 1, start 0.085 s, strength 1, multiplier 8). */
+int32_t cpq_nuc_plan_compute(int32_t ir_len, int32_t block_size, int32_t enable_direct_head,
+                             const cpq_filter_spec* spec, cpq_nuc_plan* plan);
+/* h_eff for one mono IR; writes min(cap, plan.heff_len) taps, returns heff_len or <0. */
+int32_t cpq_nuc_heff(const double* ir, int32_t ir_len, int32_t block_size, double scale,
+                     const cpq_filter_spec* spec, double* heff, int32_t cap);
+/* EQProcessor::calcSVFCoeffs (src/eqprocessor/EQProcessor.Coefficients.cpp:101-130,431-618) */
+int32_t cpq_eq_design_svf(int32_t type, float freq, float gain_db, float q, double sample_rate,
+                          cpq_svf_coeffs* out);
+/* convo::EQParameters::EQParameters() defaults (src/core/EQParameters.h:31-46) */
+void    cpq_eq_params_default(cpq_eq_params* p);
+
+/* ------------------------------------------------------------------- engine */
+/* replaces: construction of StereoConvolver + 2 MKLNonUniformConvolver + EQProcessor per stream
+ * and every per-buffer aligned allocation under them (src/AlignedAllocation.h:22-163,
+ * src/MKLNonUniformConvolver.h:288-365): one device arena sized from the descriptor. */
+int32_t cpq_engine_create(const cpq_engine_desc* desc, cpq_engine** out);
+void    cpq_engine_destroy(cpq_engine* e);
+/* hipStream_t the engine enqueues on (NULL = default stream). */
+int32_t cpq_engine_set_stream(cpq_engine* e, void* hip_stream);
+int32_t cpq_engine_synchronize(cpq_engine* e);
+/* bytes of the device arena */
+int64_t cpq_engine_arena_bytes(const cpq_engine* e);
+
+/* replaces ConvolverProcessor::prepareToPlay(double,int) (src/convolver/ConvolverProcessor.Lifecycle.cpp:211-402)
+ * and EQProcessor::prepareToPlay(double,int) (src/eqprocessor/EQProcessor.Core.cpp:679-826):
+ * publishes the rate, zeroes all run-time state (FDL, overlap history, SVF state). max_block must
+ * not exceed block_size * max_blocks_per_call. */
+int32_t cpq_engine_prepare(cpq_engine* e, double sample_rate, int32_t max_block);
+int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
+
+/* ---------------------------------------------------------------- convolver */
+/* replaces StereoConvolver::init (src/ConvolverProcessor.h:741-814) -> 2 x
+ * MKLNonUniformConvolver::SetImpulse(impulse, irLen, blockSize, scale, enableDirectHead, filterSpec)
+ * (src/MKLNonUniformConvolver.h:197-200).  stream = index or CPQ_ALL_STREAMS (one shared stereo IR).
+ * The caller keeps ownership of ir_l/ir_r (copied).  spec must be NULL in this version: a non-NULL
+ * FilterSpec makes the reference apply per-partition HC/LC spectral gains (:336-443) that depend on its
+ * own partition sizes -> CPQ_ERR_UNSUPPORTED.  enable_direct_head must be 0 (-> CPQ_ERR_UNSUPPORTED). */
+int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* ir_l, const double* ir_r,
+                             int32_t ir_len, double scale, int32_t enable_direct_head,
+                             const cpq_filter_spec* spec);
+/* replaces the per-quantum MKLNonUniformConvolver::Add + Get pair (src/MKLNonUniformConvolver.h:208,218;
+ * call site StereoConvolver::process, src/convolver/ConvolverProcessor.Runtime.cpp:1159-1184) for every
+ * channel of every stream and every B-sample quantum in the call.  n_samples = T*B, 1 <= T <= T_max.
+ * in == out is allowed. */
+int32_t cpq_conv_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);
+int32_t cpq_conv_process_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+/* MKLNonUniformConvolver::Reset (src/MKLNonUniformConvolver.h:224) for all channels */
+int32_t cpq_conv_reset(cpq_engine* e);
+/* MKLNonUniformConvolver::isReady / getLatency (src/MKLNonUniformConvolver.h:229,242) */
+int32_t cpq_conv_is_ready(const cpq_engine* e);
+int32_t cpq_conv_latency(const cpq_engine* e);
+int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan);
+
+/* ----------------------------------------------------------------------- EQ */
+/* replaces EQProcessor::createCoeffCache(params, sr, maxBlock, gen) (src/eqprocessor/
+ * EQProcessor.ProcessingCache.cpp:56-93) + the (EQParameters, EQCoeffCache*) arguments of process(). */
+int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* params);
+/* replaces EQProcessor::process(AudioBlock<double>&, const EQParameters&, const EQCoeffCache*)
+ * (src/eqprocessor/EQProcessor.Processing.cpp:1019-1276), serial structure, steady total gain. */
+int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);
+int32_t cpq_eq_process_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+/* zero filterState (EQProcessor::prepareToPlay, src/eqprocessor/EQProcessor.Core.cpp:769) */
+int32_t cpq_eq_reset(cpq_engine* e);
+
+/* ------------------------------------------------------- whole path per call */
+/* replaces the DSPCore routing of convolverRt().process(block) and eqRt().process(block, params, cache)
+ * (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:386-451) in the configured order. */
+int32_t cpq_engine_process_block(cpq_engine* e, const double* in, double* out, int32_t n_samples);
+int32_t cpq_engine_process_block_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+
+/* ---------------------------------------------------------------- profiling */
+/* Per-kernel HIP-event timing on the engine's stream (counterpart of the reference's CONV_TIME /
+ * EQ_TIME diagnostics, src/convolver/ConvolverProcessor.Runtime.cpp:679-721). */
+typedef enum {
+    CPQ_K_RFFT_FWD = 0,   /* k_rfft_fwd_ols */
+    CPQ_K_FDL_MAC  = 1,   /* k_fdl_mac      */
+    CPQ_K_DCNYQ    = 2,   /* k_fdl_mac_dcnyq */
+    CPQ_K_RFFT_INV = 3,   /* k_rfft_inv_ols */
+    CPQ_K_SVF      = 4,   /* k_svf_cascade  */
+    CPQ_K_COUNT    = 5
+} cpq_kernel_id;
+int32_t     cpq_profile_enable(cpq_engine* e, int32_t on);
+int32_t     cpq_profile_reset(cpq_engine* e);
+/* synchronises the stream, then returns launches and summed milliseconds of one kernel */
+int32_t     cpq_profile_read(cpq_engine* e, int32_t kernel_id, int64_t* launches, double* total_ms);
+const char* cpq_kernel_name(int32_t kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONVOPEQ_MI355X_H */
