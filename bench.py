@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native ConvoPeq hot path.
+
+Metric (BASELINE.json): Mega stereo-samples/s convolved (131072-tap IR, blk=512), fp64.
+One *step* = one pass of the hot path over one batch: every one of S stereo streams pushes T blocks of 512
+samples through the convolver (131072-tap private IR per channel, reference semantics) and, unless --no-eq,
+the 20-band SVF EQ -- one cpq_engine_process_block_device() call with inputs already resident in HBM.
+
+N = 1 runs BASELINE.json configs[1] (256 stereo streams).  N > 1 (launched by torch.distributed.run, one rank
+per GPU) keeps the per-GPU workload fixed (weak scaling, streams sharded across ranks, no data-path
+collective); the only collective is the final RCCL all-reduce of the counters.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+B = 512
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (fp64 vector FMA)
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def rand_pm1(seed, stream, channel, idx):
+    with np.errstate(over="ignore"):
+        key = np.uint64(seed) ^ (np.uint64(stream) << np.uint64(40)) ^ (np.uint64(channel) << np.uint64(32))
+        u = splitmix64(key ^ idx.astype(np.uint64))
+    return (u >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
+
+
+def gen_pcm(n, stream, channel, start=0, seed=0xC0FFEE):
+    return 0.25 * rand_pm1(seed, stream, channel, np.arange(start, start + n, dtype=np.uint64))
+
+
+def gen_ir(length, stream, channel, seed=0x1257):
+    i = np.arange(length, dtype=np.uint64)
+    return 0.05 * rand_pm1(seed, stream, channel, i) * np.exp(-6.9 * i.astype(np.float64) / length)
+
+
+def bench_eq_params(amd, saturation):
+    """SURVEY.md 8(d) EQ bench preset."""
+    freqs = [25.0, 40.0, 63.0, 100.0, 160.0, 250.0, 400.0, 630.0, 1000.0, 1600.0, 2500.0, 4000.0, 6300.0,
+             10000.0, 11000.0, 12500.0, 14000.0, 16500.0, 18000.0, 19500.0]
+    gains = [3, -2, 4, -3, 2, -4, 3, -2, 1.5, -1.5, 2, -2, 3, -3, 1, -1, 2, -2, 1, -1]
+    p = amd.eq_params_default()
+    for i in range(20):
+        b = p.bands[i]
+        b.frequency, b.gain, b.q = freqs[i], gains[i], 1.41
+        b.enabled, b.channel_mode = 1, 0
+        b.type = 0 if i == 0 else (2 if i == 19 else 1)
+    p.nonlinear_saturation = saturation
+    return p
+
+
+# ----------------------------------------------------------------------------- CPU baseline (oracle, "port")
+def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
+    """Times the CPU oracle (restatement of the reference NUC + SVF EQ) on the host cores of this box.
+    Bounded sample: one stereo stream per thread, each with its own 131072-tap IRs, blocks of 512."""
+    import oracle_lib as O
+    O.lib()
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    n_blocks = 1024                       # per thread and pass: 524288 samples per channel
+    po = O.eq_params_bench(saturation)
+    done = [0] * cores
+    stop_at = [0.0]
+
+    def work(tid):
+        irs = [O.gen_ir(ir_len, stream=tid, channel=ch) for ch in range(2)]
+        nucs = [O.Nuc(), O.Nuc()]
+        for ch in range(2):
+            nucs[ch].set_impulse(irs[ch], B)
+        x = [O.gen_pcm(n_blocks * B, stream=tid, channel=ch) for ch in range(2)]
+        state = np.zeros(80)
+        barrier.wait()
+        while True:
+            y = [nucs[ch].run(x[ch], B) for ch in range(2)]
+            if use_eq:
+                O.eq_process_stereo(y[0], y[1], po, state=state)
+            done[tid] += n_blocks * B
+            if time.perf_counter() >= stop_at[0]:
+                break
+
+    barrier = threading.Barrier(cores + 1)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    stop_at[0] = time.perf_counter() + 3600.0
+    barrier.wait()
+    t0 = time.perf_counter()
+    stop_at[0] = t0 + target_seconds
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = sum(done)
+    return {"value": round(total / dt / 1e6, 3), "unit": "Mega stereo-samples/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} stereo streams (one per thread), {ir_len}-tap IR each, blk {B}, "
+                      f"{total // cores} samples per stream, conv{'+EQ' if use_eq else ''}, {dt:.1f} s wall; "
+                      "oracle = C restatement of the reference NUC schedule (own radix-2 FFT, not IPP)"}
+
+
+def load_pmc_traffic(path, kernel):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 PMC summary (profiles/*.json), or None."""
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=256, help="stereo streams per GPU")
+    ap.add_argument("--ir-len", type=int, default=131072)
+    ap.add_argument("--blocks-per-call", type=int, default=64)
+    ap.add_argument("--mac-tile", type=int, default=0)
+    ap.add_argument("--no-eq", action="store_true")
+    ap.add_argument("--saturation", type=float, default=0.2)
+    ap.add_argument("--shared-ir", action="store_true")
+    ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    args = ap.parse_args()
+
+    import torch
+    import convopeq_amd as amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    S, T, L = args.streams, args.blocks_per_call, args.ir_len
+    n = T * B
+    use_eq = not args.no_eq
+    eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T,
+                            semantics=amd.CPQ_SEM_EXACT if args.exact else amd.CPQ_SEM_REFERENCE,
+                            device=local_rank, mac_tile=args.mac_tile)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+
+    # synthetic IRs and PCM; stream ids are global so every rank convolves different streams
+    t_setup = time.perf_counter()
+    g0 = rank * S
+    if args.shared_ir:
+        eng.set_impulse(amd.CPQ_ALL_STREAMS, gen_ir(L, 0, 0), gen_ir(L, 0, 1))
+    else:
+        for s in range(S):
+            eng.set_impulse(s, gen_ir(L, g0 + s, 0), gen_ir(L, g0 + s, 1))
+    if use_eq:
+        eng.set_eq_params(amd.CPQ_ALL_STREAMS, bench_eq_params(amd, args.saturation))
+    host = np.empty((2 * S, n))
+    for s in range(S):
+        for ch in range(2):
+            host[2 * s + ch] = gen_pcm(n, g0 + s, ch)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.empty_like(d_in)
+    plan = eng.plan()
+    k_parts = (plan.heff_len + B - 1) // B if not args.exact else (L + B - 1) // B
+    setup_s = time.perf_counter() - t_setup
+
+    def step():
+        if use_eq:
+            eng.process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        else:
+            eng.conv_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    eng.profile_reset()
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+
+    samples = float(S) * n * args.steps          # stereo samples this rank processed
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        ss = torch.tensor([samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+        elapsed, samples = tt.item(), ss.item()
+
+    if rank == 0:
+        n_ch = 2 * S
+        mac_n, mac_ms = prof["k_fdl_mac"]
+        mac_avg_s = (mac_ms / max(mac_n, 1)) * 1e-3
+        # algorithmic HBM bytes of one k_fdl_mac launch under the T-block time-batched uniform schedule
+        # (DESIGN.md section 4): every FDL row the call needs is read once, every IR row once, every output row written once
+        spec_bytes = B * 16
+        ir_rows = (2 if args.shared_ir else n_ch) * k_parts
+        mac_bytes = (n_ch * (k_parts + T - 1) + ir_rows + n_ch * T) * spec_bytes
+        mac_flops = 8.0 * n_ch * T * k_parts * B
+        achieved = mac_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
+        out = {
+            "metric": "Mega stereo-samples/s convolved (131072-tap IR, blk=512)",
+            "value": round(samples / elapsed / 1e6, 3),
+            "unit": "Mega stereo-samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{S} stereo streams per GPU, {L}-tap IR "
+                            f"({'one shared stereo IR' if args.shared_ir else 'private IR per channel'}), blk {B}, "
+                            f"fp64 overlap-save conv{' + 20-band SVF EQ (sat %.1f)' % args.saturation if use_eq else ''}"
+                            f" [BASELINE.json configs[1]{'' if (S == 256 and L == 131072) else ' (modified)'}]",
+                "streams_per_gpu": S, "ir_taps": L, "block": B, "blocks_per_call": T,
+                "schedule": f"uniform P=512, K={k_parts} partitions of "
+                            f"{'h' if args.exact else 'h_eff (reference NUC semantics)'}, {T}-block time batching",
+                "eq": use_eq, "parallelism": f"streams sharded, {world} rank(s)",
+                "gb_per_s_of_samples": round(samples / elapsed * 16 / 1e9, 3),
+            },
+            "roofline": {
+                "kernel": "k_fdl_mac", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": load_pmc_traffic(args.pmc_json, "k_fdl_mac"),
+                "algorithmic_bytes_per_launch": mac_bytes, "avg_launch_ms": round(mac_avg_s * 1e3, 4),
+                "launches": mac_n,
+                "fp64_vector": {"achieved_tflops": round(mac_flops / mac_avg_s / 1e12, 3) if mac_avg_s > 0 else 0.0,
+                                "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+            },
+            "kernels_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof.items()},
+            "setup_s": round(setup_s, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(L, use_eq, args.saturation)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
