@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--blocks-per-call", type=int, default=64)
     ap.add_argument("--mac-tile", type=int, default=0)
     ap.add_argument("--no-eq", action="store_true")
+    ap.add_argument("--eq-only", action="store_true", help="diagnostic: time the EQ kernel alone")
     ap.add_argument("--saturation", type=float, default=0.2)
     ap.add_argument("--shared-ir", action="store_true")
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
@@ -190,7 +191,9 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     def step():
-        if use_eq:
+        if args.eq_only:
+            eng.eq_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        elif use_eq:
             eng.process_device(d_in.data_ptr(), d_out.data_ptr(), n)
         else:
             eng.conv_process_device(d_in.data_ptr(), d_out.data_ptr(), n)

@@ -21,7 +21,10 @@ CPQ_SEM_REFERENCE = 0
 CPQ_SEM_EXACT = 1
 CPQ_ORDER_CONV_THEN_EQ = 0
 CPQ_ORDER_EQ_THEN_CONV = 1
-KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4}
+KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4,
+              "k_svf_cascade_tp": 5}
+CPQ_EQ_MODE_AUTO = 0
+CPQ_EQ_MODE_SEQUENTIAL = 1
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -95,6 +98,7 @@ SYMBOLS = {
     "cpq_eq_set_params": (C.c_int32, [_E, C.c_int32, C.POINTER(EqParams)]),
     "cpq_eq_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_eq_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_eq_set_mode": (C.c_int32, [_E, C.c_int32]),
     "cpq_eq_reset": (C.c_int32, [_E]),
     "cpq_engine_process_block": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_engine_process_block_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -74,6 +74,7 @@ struct cpq_engine {
     int* svfFlags = nullptr;    // [nCh][20]
     double* svfSatGain = nullptr;   // [nCh][2]
     double* svfState = nullptr; // [nCh][20][2]
+    double* svfTp = nullptr;    // [streams][20][kSvfTpTableDoubles]  time-parallel kernel tables
 
     // run-time state
     int head = 0;               // ring slot of the next block
@@ -86,6 +87,8 @@ struct cpq_engine {
     cpq_nuc_plan plan{};        // plan of the most recent set_impulse
     bool planValid = false;
     bool eqSet = false;
+    std::vector<char> eqTpSafe; // per stream: time-parallel kernel proven guard-free
+    int eqMode = CPQ_EQ_MODE_AUTO;
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
 
@@ -187,7 +190,13 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
 int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
-    {
+    bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO);
+    for (char s : e->eqTpSafe) tp = tp && s;
+    if (tp) {
+        ProfScope p(e, CPQ_K_SVF_TP);
+        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, (int64_t)T * kP, e->nCh, T * kP, e->svfCoef, e->svfFlags,
+                                   e->svfSatGain, e->svfState, e->svfTp);
+    } else {
         ProfScope p(e, CPQ_K_SVF);
         cpq::launch_svf_cascade(e->stream, dIn, dOut, (int64_t)T * kP, e->nCh, T * kP, e->svfCoef, e->svfFlags,
                                 e->svfSatGain, e->svfState);
@@ -265,6 +274,7 @@ const char* cpq_kernel_name(int32_t id)
         case CPQ_K_DCNYQ: return "k_fdl_mac_dcnyq";
         case CPQ_K_RFFT_INV: return "k_rfft_inv_ols";
         case CPQ_K_SVF: return "k_svf_cascade";
+        case CPQ_K_SVF_TP: return "k_svf_cascade_tp";
         default: return "?";
     }
 }
@@ -373,6 +383,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->svfFlags, nCh * kBands * (int64_t)sizeof(int) },
         { (void**)&e->svfSatGain, nCh * 2 * (int64_t)sizeof(double) },
         { (void**)&e->svfState, nCh * kBands * 2 * (int64_t)sizeof(double) },
+        { (void**)&e->svfTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
     };
     int64_t total = 0;
     for (const Item& it : items) total += alignUp(it.bytes, 256);
@@ -407,6 +418,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     for (int c = 0; c < e->nCh; ++c) e->irSlotHost[c] = c;
     e->irLoaded.assign(e->nCh, 0);
     e->irParts.assign(e->nCh, 0);
+    e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
     if (hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice) != hipSuccess) {
         cpq_engine_destroy(e);
         return fail(nullptr, CPQ_ERR_DEVICE, "irSlot upload failed");
@@ -573,11 +585,16 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     // (src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90)
     double coef[2][kBands][6];
     int flags[2][kBands];
+    std::vector<double> tp((size_t)kBands * cpq::kSvfTpTableDoubles, 0.0);
+    bool tpSafe = true;
     for (int b = 0; b < kBands; ++b) {
         const cpq_eq_band& bp = p->bands[b];
         const bool active = bp.enabled && e->sampleRate > 0.0;
         cpq_svf_coeffs c{ 0, 0, 0, 0, 0, 1, 0, 0 };
-        if (active) cpq::designSvf(bp.type, bp.frequency, bp.gain, bp.q, e->sampleRate, &c);
+        if (active) {
+            cpq::designSvf(bp.type, bp.frequency, bp.gain, bp.q, e->sampleRate, &c);
+            tpSafe = cpq::buildSvfTpTables(c, &tp[(size_t)b * cpq::kSvfTpTableDoubles]) && tpSafe;
+        }
         for (int ch = 0; ch < 2; ++ch) {
             const double v[6] = { c.a1, c.a2, c.a3, c.m0, c.m1, c.m2 };
             std::memcpy(coef[ch][b], v, sizeof(v));
@@ -593,6 +610,7 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
     std::vector<double> hc((size_t)(s1 - s0) * 2 * kBands * 6), hs((size_t)(s1 - s0) * 2 * 2);
     std::vector<int> hf((size_t)(s1 - s0) * 2 * kBands);
+    std::vector<double> ht((size_t)(s1 - s0) * tp.size());
     for (int s = s0; s < s1; ++s)
         for (int ch = 0; ch < 2; ++ch) {
             const size_t ci = (size_t)(s - s0) * 2 + ch;
@@ -601,13 +619,22 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             hs[ci * 2] = satGain[0];
             hs[ci * 2 + 1] = satGain[1];
         }
+    for (int s = s0; s < s1; ++s) std::memcpy(&ht[(size_t)(s - s0) * tp.size()], tp.data(), tp.size() * sizeof(double));
+    for (int s = s0; s < s1; ++s) e->eqTpSafe[s] = tpSafe ? 1 : 0;
     const size_t c0 = (size_t)s0 * 2;
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     CPQ_HIP(e, hipMemcpy(e->svfCoef + c0 * kBands * 6, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->svfFlags + c0 * kBands, hf.data(), hf.size() * sizeof(int), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->svfSatGain + c0 * 2, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (stream == CPQ_ALL_STREAMS || e->desc.n_streams == 1) e->eqSet = true;
-    else e->eqSet = true;   // unset streams keep all-bands-inactive (pass-through) coefficients
+    CPQ_HIP(e, hipMemcpy(e->svfTp + (size_t)s0 * tp.size(), ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->eqSet = true;   // streams never given parameters keep all bands inactive (pass-through)
+    return CPQ_OK;
+}
+
+int32_t cpq_eq_set_mode(cpq_engine* e, int32_t mode)
+{
+    if (!e || (mode != CPQ_EQ_MODE_AUTO && mode != CPQ_EQ_MODE_SEQUENTIAL)) return CPQ_ERR_INVALID_ARG;
+    e->eqMode = mode;
     return CPQ_OK;
 }
 

@@ -194,4 +194,74 @@ double totalGainLinear(float db)
     return d > -100.0 ? std::pow(10.0, d * 0.05) : 0.0;
 }
 
+// State-space form of one TPT-SVF band (src/eqprocessor/EQProcessor.Processing.cpp:228-241):
+//   ic' = A ic + Bv v0,   y_lin = C ic + D v0
+//   A = [[2 a1 - 1, -2 a2], [2 a2, 1 - 2 a3]],  Bv = [2 a2, 2 a3],  C = [m1 a1 + m2 a2, -m1 a2 + m2 (1 - a3)]
+bool buildSvfTpTables(const cpq_svf_coeffs& c, double* out)
+{
+    typedef long double ld;
+    const ld a1 = c.a1, a2 = c.a2, a3 = c.a3, m1 = c.m1, m2 = c.m2;
+    const ld A[4] = { 2 * a1 - 1, -2 * a2, 2 * a2, 1 - 2 * a3 };
+    const ld C[2] = { m1 * a1 + m2 * a2, -m1 * a2 + m2 * (1 - a3) };
+    auto mul = [](const ld* x, const ld* y, ld* z) {
+        const ld r[4] = { x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3],
+                          x[2] * y[0] + x[3] * y[2], x[2] * y[1] + x[3] * y[3] };
+        for (int i = 0; i < 4; ++i) z[i] = r[i];
+    };
+    auto power = [&](long n, ld* r) {   // r = A^n by binary powering
+        ld acc[4] = { 1, 0, 0, 1 }, base[4] = { A[0], A[1], A[2], A[3] };
+        while (n > 0) {
+            if (n & 1) mul(base, acc, acc);
+            mul(base, base, base);
+            n >>= 1;
+        }
+        for (int q = 0; q < 4; ++q) r[q] = acc[q];
+    };
+    // layout: struct TpLcTables { Mk[6][4]; Mw[4]; P[64][4]; G[16][2]; } for LC = 16 then LC = 2 (svf_kernels.hip)
+    const int lcs[2] = { 16, 2 };
+    constexpr int kPerLc = 6 * 4 + 4 + 64 * 4 + 16 * 2;
+    for (int li = 0; li < 2; ++li) {
+        double* o = out + li * kPerLc;
+        const int lc = lcs[li];
+        ld M[4];
+        for (int k = 0; k < 6; ++k) {
+            power((long)lc << k, M);
+            for (int q = 0; q < 4; ++q) o[k * 4 + q] = (double)M[q];
+        }
+        power((long)lc * 64, M);
+        for (int q = 0; q < 4; ++q) o[24 + q] = (double)M[q];
+        for (int c = 0; c < 64; ++c) {
+            power((long)lc * (c + 1), M);
+            for (int q = 0; q < 4; ++q) o[28 + c * 4 + q] = (double)M[q];
+        }
+        ld P[4] = { 1, 0, 0, 1 };
+        for (int i = 0; i < 16; ++i) {
+            o[28 + 256 + 2 * i] = (double)(C[0] * P[0] + C[1] * P[2]);
+            o[28 + 256 + 2 * i + 1] = (double)(C[0] * P[1] + C[1] * P[3]);
+            mul(A, P, P);
+        }
+    }
+    for (int i = 0; i < 2 * kPerLc; ++i) if (!std::isfinite(out[i])) return false;
+
+    // guard-freedom proof: sup_n |A^n|_inf (carried state) and the l1 gain input -> state must keep every
+    // state below 1e15 for |input|, |carried state| < 1e9 (one decade of margin)
+    ld Q[4] = { 1, 0, 0, 1 };
+    ld s[2] = { 2 * a2, 2 * a3 };
+    ld kappa = 1, l1 = 0;
+    const long maxIter = 1L << 23;
+    long n = 0;
+    for (; n < maxIter; ++n) {
+        l1 += std::max(std::fabs(s[0]), std::fabs(s[1]));
+        const ld t0 = A[0] * s[0] + A[1] * s[1], t1 = A[2] * s[0] + A[3] * s[1];
+        s[0] = t0; s[1] = t1;
+        mul(A, Q, Q);
+        const ld nq = std::max(std::fabs(Q[0]) + std::fabs(Q[1]), std::fabs(Q[2]) + std::fabs(Q[3]));
+        kappa = std::max(kappa, nq);
+        if (!(nq < 1e30L)) return false;
+        if (nq < 1e-22L && std::max(std::fabs(s[0]), std::fabs(s[1])) < 1e-22L) break;
+    }
+    if (n >= maxIter) return false;
+    return (kappa + l1) < 1.0e5L;
+}
+
 }  // namespace cpq

@@ -14,5 +14,9 @@ int    buildHeff(const double* ir, int irLen, int blockSize, double scale, const
 void   designSvf(int type, float freq, float gainDb, float q, double sr, cpq_svf_coeffs* c);
 void   defaultEqParams(cpq_eq_params* p);
 double totalGainLinear(float db);
+// Tables of the time-parallel SVF kernel for one band (kSvfTpTableDoubles doubles, layout TpBandTables in
+// svf_kernels.hip: 2x2 powers of the state matrix and the state-to-output response).  Returns false when the state guards of the reference could
+// trip for inputs / carried states below 1e9 (or the filter does not decay), i.e. the kernel must not be used.
+bool   buildSvfTpTables(const cpq_svf_coeffs& c, double* out);
 
 }  // namespace cpq

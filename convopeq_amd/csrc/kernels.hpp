@@ -46,4 +46,16 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
                         int nSamples, const double* coef, const int* flags, const double* satGain,
                         double* state);
 
+// Time-parallel SVF cascade: one 4-wave workgroup per channel, 256 chunks of a span in flight per band
+// (zero-state chunk runs + state scan + linear state response), span resident in LDS across the 20 bands.
+// nSamples must be a multiple of 512.  tables: kSvfTpTableDoubles doubles per (stream, band):
+// for each chunk length LC in {16, 2}: Mk[6][4] = A^(LC 2^k), Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)),
+// G[16][2] = C A^i.
+constexpr int kSvfTpLc[2] = { 16, 2 };
+constexpr int kSvfTpLcDoubles = 6 * 4 + 4 + 64 * 4 + 16 * 2;
+constexpr int kSvfTpTableDoubles = 2 * kSvfTpLcDoubles;
+void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh,
+                           int nSamples, const double* coef, const int* flags, const double* satGain,
+                           double* state, const void* tables);
+
 }  // namespace cpq

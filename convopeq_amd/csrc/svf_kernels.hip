@@ -24,9 +24,10 @@ constexpr int kChPerWave = 3;
 // sanitizeFiniteInRangeV(v, 0, 1e15): non-finite or |v| >= 1e15 -> 0  (Processing.cpp:90-101)
 __device__ __forceinline__ double sanitize(double v)
 {
-    const bool ok = ((v - v) == 0.0) && (fabs(v) < 1.0e15);
-    return ok ? v : 0.0;
+    // |v| < 1e15 is false for NaN and for +-Inf, so the reference's separate finiteness test is implied
+    return (fabs(v) < 1.0e15) ? v : 0.0;
 }
+
 
 // in and out may alias (in-place processing like the reference): no __restrict__ on them.
 __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* out,
@@ -138,6 +139,303 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Time-parallel variant.
+//
+// Inside one band the state update is LINEAR in (v0, ic1eq, ic2eq): the fastTanh blend, the +-100 clamp and
+// the output guard act on the band OUTPUT only and never feed back into the state (Processing.cpp:228-262).
+// So one band over a span of 64*W chunks of LC samples can be run as
+//   1. every lane runs the reference recurrence over its own chunk from ZERO state  -> y_zs, end state e
+//   2. chunk start states by a scan of S_c = M S_(c-1) + e_c, M = A^LC: 6 Kogge-Stone steps inside each wave,
+//      then the W wave totals are chained (W-1 2x2 products) and folded in with per-lane powers A^(LC (c+1));
+//      all matrix powers are precomputed on the host in extended precision
+//   3. y_lin[i] = y_zs[i] + (C A^i) . s0_chunk, then saturation blend / guard / clamp exactly as the reference.
+// Bands remain sequential (the nonlinearity sits between them); the span lives in LDS for all 20 bands, so
+// HBM sees one read and one write per sample.  One workgroup of W waves per channel: 64*W-way time
+// parallelism per band, W*channels waves in flight (2 per SIMD at 256 streams, W = 4).
+//
+// The state guards of the reference (non-finite or >= 1e15 -> 0) cannot trip when the span input is finite and
+// below kTpInputBound and the incoming state is below it too (the host proves state gain * bound < 1e15 per
+// band before enabling this kernel); otherwise the span is run by the guarded sequential path below.
+// Result differs from the sequential recurrence by rounding only (measured <= 3e-15 abs over 20 bands).
+
+constexpr double kTpInputBound = 1.0e9;
+constexpr int kTpWaves = 4;                  // waves per channel
+constexpr int kTpChunks = 64 * kTpWaves;     // chunks (= threads) per span
+constexpr int kTpLcMain = 16;                // samples per chunk, main spans (4096 samples)
+constexpr int kTpLcTail = 2;                 // samples per chunk, 512-sample remainder spans
+constexpr int kTpStride = kTpLcMain + 1;     // LDS row stride in doubles (odd: chunk rows on distinct banks)
+
+// per (stream, band); one block per chunk length (kTpLcMain, kTpLcTail); must match host buildSvfTpTables()
+struct TpLcTables {
+    double Mk[6][4];     // A^(LC*2^k), row-major 2x2: in-wave scan steps
+    double Mw[4];        // A^(LC*64): one whole wave of chunks
+    double P[64][4];     // A^(LC*(c+1)): carries the wave's start state to the end of chunk c
+    double G[16][2];     // C*A^i, i < LC
+};
+struct TpBandTables { TpLcTables t[2]; };
+
+// num / den for the fastTanh Pade: den in [27, 209.25], |num| <= 212.7, so the range scaling and special-case
+// fix-up of the generic fp64 division (v_div_scale / v_div_fmas / v_div_fixup, which serialise on VCC) are
+// no-ops and are omitted; what remains is the same Newton + residual sequence, so the quotient equals the IEEE
+// result for every normal-range quotient and independent divisions can be interleaved.
+__device__ __forceinline__ double pade_div(double num, double den)
+{
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    const double q = num * r;
+    return fma(fma(-den, q, num), r, q);
+}
+
+// Output stage of one band for N independent samples (blend with fastTanh, output guard, clamp), written
+// stage by stage so that independent operations are adjacent in program order.
+template <bool MONO, bool SAT, int N>
+__device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double oneMinusSat)
+{
+    if (SAT) {
+        double xc[N], num[N], den[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) xc[j] = MONO ? y[j] : fmin(fmax(y[j], -4.5), 4.5);
+#pragma unroll
+        for (int j = 0; j < N; ++j) { const double x2 = xc[j] * xc[j]; num[j] = xc[j] * (27.0 + x2); den[j] = 27.0 + 9.0 * x2; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) num[j] = pade_div(num[j], den[j]);
+        if (MONO) {
+            // scalar fastTanh: +-1 beyond the clip threshold (FastTanhApprox.h:101-107)
+#pragma unroll
+            for (int j = 0; j < N; ++j) { num[j] = (y[j] >= 4.5) ? 1.0 : num[j]; num[j] = (y[j] <= -4.5) ? -1.0 : num[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) y[j] = (y[j] * oneMinusSat) + (num[j] * sat);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) y[j] = sanitize(y[j]);
+    if (MONO) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) { y[j] = (y[j] < -100.0) ? -100.0 : y[j]; y[j] = (y[j] > 100.0) ? 100.0 : y[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) y[j] = fmin(fmax(y[j], -100.0), 100.0);
+    }
+}
+
+template <int LC, bool MONO, bool SAT>
+__device__ __forceinline__ void tp_band(double* buf, double* wtot, int tid, const double* __restrict__ cf,
+                                        const TpLcTables* __restrict__ tb, double sat, double* sState)
+{
+    constexpr int U = (LC < 8) ? LC : 8;
+    const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
+    const double oneMinusSat = 1.0 - sat;
+    const int lane = tid & 63, wave = tid >> 6;
+    double* row = buf + tid * kTpStride;
+
+    // ---- 1. zero-state run of this thread's chunk (reference operation order)
+    double ic1 = 0.0, ic2 = 0.0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < LC; i0 += U) {
+        double v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const double v0 = v[j];
+            const double v3 = v0 - ic2;
+            if (MONO) {
+                const double v1 = a1 * ic1 + a2 * v3;
+                const double v2 = ic2 + a2 * ic1 + a3 * v3;
+                ic1 = 2.0 * v1 - ic1;
+                ic2 = 2.0 * v2 - ic2;
+                v[j] = m0 * v0 + m1 * v1 + m2 * v2;
+            } else {
+                const double v1 = fma(a1, ic1, a2 * v3);
+                const double v2 = fma(a2, ic1, fma(a3, v3, ic2));
+                ic1 = fma(2.0, v1, -ic1);
+                ic2 = fma(2.0, v2, -ic2);
+                v[j] = fma(m0, v0, fma(m1, v1, m2 * v2));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
+    }
+
+    // ---- 2. chunk start states.  In-wave inclusive scan of S_c = M S_(c-1) + e_c (zero incoming state) ...
+    double sx = ic1, sy = ic2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double* Mk = tb->Mk[k];
+        const double px = __shfl_up(sx, 1 << k);
+        const double py = __shfl_up(sy, 1 << k);
+        if (lane >= (1 << k)) {
+            const double nx = fma(Mk[1], py, fma(Mk[0], px, sx));
+            const double ny = fma(Mk[3], py, fma(Mk[2], px, sy));
+            sx = nx;
+            sy = ny;
+        }
+    }
+    if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
+    __syncthreads();
+    // ... state at the start of this wave's segment: chain the totals of the preceding waves
+    double bx = sState[0], by = sState[1];
+    const double mw0 = tb->Mw[0], mw1 = tb->Mw[1], mw2 = tb->Mw[2], mw3 = tb->Mw[3];
+    double endx = bx, endy = by;             // becomes the state after the whole span
+#pragma unroll
+    for (int w = 0; w < kTpWaves; ++w) {
+        const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
+        const double nx = fma(mw1, endy, fma(mw0, endx, tx));
+        const double ny = fma(mw3, endy, fma(mw2, endx, ty));
+        endx = nx; endy = ny;
+        if (w + 1 == wave) { bx = endx; by = endy; }
+    }
+    // ... fold the wave's start state into every chunk end state, then shift to chunk START states
+    {
+        const double* Pc = tb->P[lane];
+        sx = fma(Pc[1], by, fma(Pc[0], bx, sx));
+        sy = fma(Pc[3], by, fma(Pc[2], bx, sy));
+    }
+    double s0x = __shfl_up(sx, 1), s0y = __shfl_up(sy, 1);
+    if (lane == 0) { s0x = bx; s0y = by; }
+    __syncthreads();                          // all threads have read sState / wtot
+    if (tid == 0) { sState[0] = endx; sState[1] = endy; }
+
+    // ---- 3. add the state response, then the output nonlinearity of the reference
+#pragma unroll 1
+    for (int i0 = 0; i0 < LC; i0 += U) {
+        double v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = fma(tb->G[i0 + j][1], s0y, fma(tb->G[i0 + j][0], s0x, v[j]));
+        tp_nonlinear<MONO, SAT, U>(v, sat, oneMinusSat);
+#pragma unroll
+        for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
+    }
+    __syncthreads();
+}
+
+// guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
+// with every guard, used when the span input or the carried state is outside the proven-safe range.
+template <bool MONO>
+__device__ void tp_band_guarded(double* buf, int lc, const double* __restrict__ cf, double sat, double* sState)
+{
+    const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
+    const double oneMinusSat = 1.0 - sat;
+    double ic1 = sState[0], ic2 = sState[1];
+    for (int c = 0; c < kTpChunks; ++c)
+        for (int i = 0; i < lc; ++i) {
+            const double v0 = buf[c * kTpStride + i];
+            const double v3 = v0 - ic2;
+            double y[1];
+            if (MONO) {
+                const double v1 = a1 * ic1 + a2 * v3;
+                const double v2 = ic2 + a2 * ic1 + a3 * v3;
+                ic1 = 2.0 * v1 - ic1;
+                ic2 = 2.0 * v2 - ic2;
+                y[0] = m0 * v0 + m1 * v1 + m2 * v2;
+            } else {
+                const double v1 = fma(a1, ic1, a2 * v3);
+                const double v2 = fma(a2, ic1, fma(a3, v3, ic2));
+                ic1 = fma(2.0, v1, -ic1);
+                ic2 = fma(2.0, v2, -ic2);
+                y[0] = fma(m0, v0, fma(m1, v1, m2 * v2));
+            }
+            if (sat > 0.0) tp_nonlinear<MONO, true, 1>(y, sat, oneMinusSat);
+            else           tp_nonlinear<MONO, false, 1>(y, sat, oneMinusSat);
+            buf[c * kTpStride + i] = y[0];
+            ic1 = sanitize(ic1);
+            ic2 = sanitize(ic2);
+        }
+    sState[0] = ic1;
+    sState[1] = ic2;
+}
+
+template <int LC>
+__device__ __forceinline__ void tp_span(const double* in, double* out, double* buf, double* wtot, double* sState,
+                                        int* sFlag, int tid, const double* __restrict__ cf,
+                                        const int* __restrict__ fl, const TpBandTables* __restrict__ tb, double sat,
+                                        double gain)
+{
+    constexpr int LCI = (LC == kTpLcMain) ? 0 : 1;
+    // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
+    bool bad = false;
+#pragma unroll 4
+    for (int it = 0; it < LC; ++it) {
+        const int j = it * kTpChunks + tid;
+        const double x = in[j];
+        bad |= !(fabs(x) < kTpInputBound);
+        buf[(j / LC) * kTpStride + (j % LC)] = x;
+    }
+    if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
+    if (tid == 0) *sFlag = 0;
+    __syncthreads();
+    if (__any(bad) && (tid & 63) == 0) atomicOr(sFlag, 1);
+    __syncthreads();
+    const bool unsafe = (*sFlag != 0);
+
+    for (int b = 0; b < kBands; ++b) {
+        const int flag = fl[b];                      // uniform
+        if (!(flag & 1)) continue;
+        const bool mono = (flag & 2) != 0;
+        const TpLcTables* t = &tb[b].t[LCI];
+        if (!unsafe) {
+            if (mono) {
+                if (sat > 0.0) tp_band<LC, true, true>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
+                else           tp_band<LC, true, false>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
+            } else {
+                if (sat > 0.0) tp_band<LC, false, true>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
+                else           tp_band<LC, false, false>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
+            }
+        } else {
+            if (tid == 0) {
+                if (mono) tp_band_guarded<true>(buf, LC, cf + b * 6, sat, sState + 2 * b);
+                else      tp_band_guarded<false>(buf, LC, cf + b * 6, sat, sState + 2 * b);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll 4
+    for (int it = 0; it < LC; ++it) {
+        const int j = it * kTpChunks + tid;
+        out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, double* out, int64_t chStride,
+                                                              int nSamples, const double* __restrict__ coef,
+                                                              const int* __restrict__ flags,
+                                                              const double* __restrict__ satGain,
+                                                              double* __restrict__ state,
+                                                              const TpBandTables* __restrict__ tables)
+{
+    __shared__ double buf[kTpChunks * kTpStride];
+    __shared__ double sState[kBands * 2];
+    __shared__ double wtot[2 * kTpWaves];
+    __shared__ int sFlag;
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    const double* cf = coef + (int64_t)c * kBands * 6;
+    const int* fl = flags + c * kBands;
+    const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;     // tables are per stream
+    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
+    if (tid < kBands * 2) sState[tid] = state[(int64_t)c * kBands * 2 + tid];
+    __syncthreads();
+
+    const double* src = in + (int64_t)c * chStride;
+    double* dst = out + (int64_t)c * chStride;
+    int done = 0;
+    while (nSamples - done >= kTpChunks * kTpLcMain) {
+        tp_span<kTpLcMain>(src + done, dst + done, buf, wtot, sState, &sFlag, tid, cf, fl, tb, sat, gain);
+        done += kTpChunks * kTpLcMain;
+    }
+    while (nSamples - done >= kTpChunks * kTpLcTail) {       // remaining whole 512-sample blocks
+        tp_span<kTpLcTail>(src + done, dst + done, buf, wtot, sState, &sFlag, tid, cf, fl, tb, sat, gain);
+        done += kTpChunks * kTpLcTail;
+    }
+    if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
+}
+
 }  // namespace
 
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
@@ -148,4 +446,15 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
                        satGain, state);
 }
 
+}  // namespace cpq
+
+namespace cpq {
+void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
+                           const double* coef, const int* flags, const double* satGain, double* state,
+                           const void* tables)
+{
+    static_assert(sizeof(TpBandTables) == kSvfTpTableDoubles * sizeof(double), "host/device table layout");
+    hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in, out, chStride, nSamples, coef, flags,
+                       satGain, state, reinterpret_cast<const TpBandTables*>(tables));
+}
 }  // namespace cpq

@@ -111,6 +111,9 @@ class BatchedEngine:
     def set_eq_params(self, stream, params):
         self._ck(self._lib.cpq_eq_set_params(self._h, stream, C.byref(params)))
 
+    def set_eq_mode(self, mode):
+        self._ck(self._lib.cpq_eq_set_mode(self._h, mode))
+
     def conv_reset(self):
         self._ck(self._lib.cpq_conv_reset(self._h))
 

@@ -196,6 +196,12 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* pa
  * (src/eqprocessor/EQProcessor.Processing.cpp:1019-1276), serial structure, steady total gain. */
 int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);
 int32_t cpq_eq_process_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+/* EQ kernel choice.  AUTO: time-parallel kernel (per band: zero-state chunk runs + state scan; equal to the
+ * sequential recurrence up to rounding, measured <= 3e-15) whenever the host can prove the reference's state
+ * guards cannot trip, else the sequential kernel.  SEQUENTIAL: lane-skewed kernel that reproduces the
+ * reference recurrence operation for operation (bit-identical to the SSE2+FMA path given equal coefficients). */
+typedef enum { CPQ_EQ_MODE_AUTO = 0, CPQ_EQ_MODE_SEQUENTIAL = 1 } cpq_eq_mode;
+int32_t cpq_eq_set_mode(cpq_engine* e, int32_t mode);
 /* zero filterState (EQProcessor::prepareToPlay, src/eqprocessor/EQProcessor.Core.cpp:769) */
 int32_t cpq_eq_reset(cpq_engine* e);
 
@@ -213,8 +219,9 @@ typedef enum {
     CPQ_K_FDL_MAC  = 1,   /* k_fdl_mac      */
     CPQ_K_DCNYQ    = 2,   /* k_fdl_mac_dcnyq */
     CPQ_K_RFFT_INV = 3,   /* k_rfft_inv_ols */
-    CPQ_K_SVF      = 4,   /* k_svf_cascade  */
-    CPQ_K_COUNT    = 5
+    CPQ_K_SVF      = 4,   /* k_svf_cascade (lane-skewed sequential recurrence) */
+    CPQ_K_SVF_TP   = 5,   /* k_svf_cascade_tp (time-parallel, default) */
+    CPQ_K_COUNT    = 6
 } cpq_kernel_id;
 int32_t     cpq_profile_enable(cpq_engine* e, int32_t on);
 int32_t     cpq_profile_reset(cpq_engine* e);
