@@ -1,0 +1,156 @@
+// convopeq_mi355x.hpp -- header-only C++20 adapter over the C ABI (convopeq_mi355x.h).
+//
+// Gives reference-style callers the member-function names of the reference's hot-path surface, batched over
+// S stereo streams:
+//   cpq::BatchedConvolver  ::SetImpulse / Add / Get / Reset / isReady / getLatency
+//        <- convo::MKLNonUniformConvolver (src/MKLNonUniformConvolver.h:197-242), one instance per mono channel
+//           in the reference, here one object for every channel of every stream
+//   cpq::BatchedProcessor  ::prepareToPlay / process / setEqParameters / loadImpulse
+//        <- ConvolverProcessor::{prepareToPlay,process} (src/ConvolverProcessor.h:226,259) and
+//           EQProcessor::{prepareToPlay,process(block, params, cache)} (src/eqprocessor/EQProcessor.h:189-205)
+// Same argument meaning and error behaviour as the reference: bool / sample-count returns, never throws on the
+// processing path, a failed call leaves the output zeroed (the reference's fail-closed FFT policy,
+// src/MKLNonUniformConvolver.cpp:75-82).
+#pragma once
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "convopeq_mi355x.h"
+
+namespace cpq {
+
+// planar block of all streams: channels()[c] points at numSamples doubles (juce::dsp::AudioBlock<double> is
+// `double* const* channels, numChannels, numSamples`; here numChannels = 2 * streams)
+struct AudioBlockBatch {
+    double* const* channels;
+    int numChannels;
+    int numSamples;
+};
+
+class Engine {
+public:
+    Engine(int streams, int blockSize, int maxIrLen, int maxBlocksPerCall, double sampleRate = 48000.0,
+           cpq_semantics semantics = CPQ_SEM_REFERENCE, int device = 0)
+    {
+        cpq_engine_desc d{};
+        d.struct_size = static_cast<int32_t>(sizeof(d));
+        d.device = device;
+        d.n_streams = streams;
+        d.block_size = blockSize;
+        d.max_ir_len = maxIrLen;
+        d.max_blocks_per_call = maxBlocksPerCall;
+        d.semantics = semantics;
+        d.mac_tile = 0;
+        d.sample_rate = sampleRate;
+        cpq_engine* raw = nullptr;
+        const int rc = cpq_engine_create(&d, &raw);
+        if (rc != CPQ_OK) throw std::runtime_error(std::string("cpq_engine_create: ") + cpq_last_error(nullptr));
+        h_.reset(raw);
+        streams_ = streams;
+        block_ = blockSize;
+        maxCall_ = blockSize * maxBlocksPerCall;
+    }
+    cpq_engine* get() const noexcept { return h_.get(); }
+    int streams() const noexcept { return streams_; }
+    int channels() const noexcept { return 2 * streams_; }
+    int blockSize() const noexcept { return block_; }
+    int maxSamplesPerCall() const noexcept { return maxCall_; }
+
+private:
+    struct Deleter { void operator()(cpq_engine* e) const noexcept { cpq_engine_destroy(e); } };
+    std::unique_ptr<cpq_engine, Deleter> h_;
+    int streams_ = 0, block_ = 0, maxCall_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+class BatchedConvolver {
+public:
+    explicit BatchedConvolver(Engine& e) : e_(e), pending_(static_cast<size_t>(e.channels()) * e.maxSamplesPerCall()),
+                                           result_(pending_.size()) {}
+
+    // one shared stereo IR for every stream (CPQ_ALL_STREAMS) or one stream's IR; arguments as
+    // MKLNonUniformConvolver::SetImpulse(impulse, irLen, blockSize, scale, enableDirectHead, filterSpec)
+    bool SetImpulse(int stream, const double* impulseL, const double* impulseR, int irLen, int blockSize,
+                    double scale = 1.0, bool enableDirectHead = false, const cpq_filter_spec* filterSpec = nullptr)
+    {
+        if (blockSize != e_.blockSize()) return false;
+        return cpq_conv_set_impulse(e_.get(), stream, impulseL, impulseR, irLen, scale, enableDirectHead ? 1 : 0,
+                                    filterSpec) == CPQ_OK;
+    }
+
+    // Add: input planar [channel][numSamples]; nullptr = silence (reference :205-208)
+    void Add(const double* input, int numSamples)
+    {
+        have_ = 0;
+        if (numSamples <= 0 || numSamples > e_.maxSamplesPerCall()) return;
+        const size_t n = static_cast<size_t>(e_.channels()) * numSamples;
+        if (input) std::memcpy(pending_.data(), input, n * sizeof(double));
+        else std::memset(pending_.data(), 0, n * sizeof(double));
+        if (cpq_conv_process(e_.get(), pending_.data(), result_.data(), numSamples) == CPQ_OK) have_ = numSamples;
+    }
+
+    // Get: returns samples written per channel; output zero-filled when nothing is available (reference :1560-1562)
+    int Get(double* output, int numSamples)
+    {
+        if (numSamples <= 0) return 0;
+        const size_t n = static_cast<size_t>(e_.channels()) * numSamples;
+        if (have_ != numSamples) {
+            if (output) std::memset(output, 0, n * sizeof(double));
+            return 0;
+        }
+        if (output) std::memcpy(output, result_.data(), n * sizeof(double));
+        have_ = 0;
+        return numSamples;
+    }
+
+    void Reset() { cpq_conv_reset(e_.get()); }
+    bool isReady() const noexcept { return cpq_conv_is_ready(e_.get()) != 0; }
+    int getLatency() const noexcept { return cpq_conv_latency(e_.get()); }
+
+private:
+    Engine& e_;
+    std::vector<double> pending_, result_;
+    int have_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+class BatchedProcessor {
+public:
+    explicit BatchedProcessor(Engine& e) : e_(e), scratch_(static_cast<size_t>(e.channels()) * e.maxSamplesPerCall()) {}
+
+    void prepareToPlay(double sampleRate, int samplesPerBlock) { cpq_engine_prepare(e_.get(), sampleRate, samplesPerBlock); }
+
+    bool loadImpulse(int stream, const double* irL, const double* irR, int irLen, double scale = 1.0)
+    {
+        return cpq_conv_set_impulse(e_.get(), stream, irL, irR, irLen, scale, 0, nullptr) == CPQ_OK;
+    }
+
+    bool setEqParameters(int stream, const cpq_eq_params& p) { return cpq_eq_set_params(e_.get(), stream, &p) == CPQ_OK; }
+    void setProcessingOrder(cpq_order o) { cpq_engine_set_order(e_.get(), o); }
+
+    // in-place on the planar block, like ConvolverProcessor::process / EQProcessor::process
+    void process(AudioBlockBatch& block)
+    {
+        const int n = block.numSamples;
+        if (n <= 0 || block.numChannels != e_.channels() || n > e_.maxSamplesPerCall()) { clear(block); return; }
+        for (int c = 0; c < block.numChannels; ++c)
+            std::memcpy(scratch_.data() + static_cast<size_t>(c) * n, block.channels[c], sizeof(double) * n);
+        if (cpq_engine_process_block(e_.get(), scratch_.data(), scratch_.data(), n) != CPQ_OK) { clear(block); return; }
+        for (int c = 0; c < block.numChannels; ++c)
+            std::memcpy(block.channels[c], scratch_.data() + static_cast<size_t>(c) * n, sizeof(double) * n);
+    }
+
+private:
+    static void clear(AudioBlockBatch& b)
+    {
+        for (int c = 0; c < b.numChannels; ++c) std::memset(b.channels[c], 0, sizeof(double) * b.numSamples);
+    }
+    Engine& e_;
+    std::vector<double> scratch_;
+};
+
+}  // namespace cpq

@@ -1,0 +1,147 @@
+"""CPU tests of the product's host logic through the C ABI (no GPU): the shared library loads, exports every
+symbol include/convopeq_mi355x.h declares, its host-only design functions agree with the oracle and with the
+fixtures, and device entry points fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import convopeq_amd
+    return convopeq_amd
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "convopeq_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cpq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(amd):
+    from convopeq_amd import _capi
+    lib = C.CDLL(_capi.LIB_PATH)
+    declared = header_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_capi.SYMBOLS) == declared, "python binding table out of sync with the header"
+    assert lib.cpq_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_object():
+    so = os.path.join(ROOT, "convopeq_amd", "libconvopeq_mi355x.so")
+    out = subprocess.run(["strings", "-a", so], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    for k in ("k_rfft_fwd_ols", "k_fdl_mac", "k_rfft_inv_ols", "k_svf_cascade"):
+        assert k in out
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not link, load or import anything under oracle/."""
+    so = os.path.join(ROOT, "convopeq_amd", "libconvopeq_mi355x.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "convopeq_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in src and "cpq_oracle" not in src and "libcpq_oracle" not in src, f
+
+
+def test_no_gpu_means_loud_failure(amd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(amd.CpqError) as ei:
+        amd.BatchedEngine(1)
+    assert ei.value.status == -2 and "no CPU fallback" in str(ei.value)
+
+
+@pytest.mark.parametrize("ir_len,block", [(4096, 512), (131072, 512), (131072, 128), (131072, 256), (524288, 512),
+                                           (131072, 1024), (131072, 2048), (100, 64), (5761, 512), (300000, 512)])
+def test_plan_matches_oracle(amd, oracle, ir_len, block):
+    a = amd.nuc_plan(ir_len, block)
+    o = oracle.plan(ir_len, block)
+    assert a.num_layers == o.numLayers and a.latency == o.latency and a.lti_valid == o.ltiValid
+    for i in range(a.num_layers):
+        assert (a.part_size[i], a.offset[i], a.len[i], a.num_parts_ir[i], a.num_parts[i], a.parts_per_callback[i],
+                a.output_delay[i], a.lag[i], a.done_callback[i]) == \
+               (o.partSize[i], o.offset[i], o.len[i], o.numPartsIR[i], o.numParts[i], o.partsPerCallback[i],
+                o.outputDelay[i], o.lag[i], o.doneCallback[i])
+        assert a.gain[i] == o.gain[i]
+
+
+def test_plan_with_filter_spec_variants(amd, oracle):
+    for kw in (dict(tail_mode=0, tail_strength=1.5), dict(tail_mode=2), dict(tail_enabled=0),
+               dict(tail_start_seconds=0.3, tail_l1l2_multiplier=4, tail_strength=0.2), dict(sample_rate=96000.0)):
+        sa = amd.FilterSpec.defaults(**kw)
+        so = oracle.FilterSpec.defaults(**{{"tail_mode": "tailMode", "tail_strength": "tailStrength",
+                                            "tail_enabled": "tailEnabled", "tail_start_seconds": "tailStartSeconds",
+                                            "tail_l1l2_multiplier": "tailL1L2Multiplier",
+                                            "sample_rate": "sampleRate"}[k]: v for k, v in kw.items()})
+        a = amd.nuc_plan(200000, 512, spec=sa)
+        o = oracle.plan(200000, 512, spec=so)
+        assert a.num_layers == o.numLayers
+        for i in range(a.num_layers):
+            assert (a.len[i], a.part_size[i], a.gain[i], a.lag[i]) == (o.len[i], o.partSize[i], o.gain[i], o.lag[i])
+
+
+def test_heff_matches_oracle_and_survey_form(amd, oracle):
+    h = oracle.gen_ir(131072)
+    a = amd.nuc_heff(h, 512)
+    assert np.array_equal(a, oracle.heff(h, 512))
+    # SURVEY finding 4: y = x*h[0:5760] + 1.4375 * delay_1408(x*h[5760:])
+    ref = np.zeros(131072 + 1408)
+    ref[:5760] = h[:5760]
+    ref[5760 + 1408:] += 1.4375000000000002 * h[5760:]
+    assert np.array_equal(a, ref)
+    assert np.array_equal(amd.nuc_heff(h[:4096], 512, scale=0.5), 0.5 * h[:4096])
+
+
+def test_svf_design_matches_oracle_and_survey(amd, oracle):
+    k = json.load(open(os.path.join(HERE, "golden", "survey_observations.json")))["svf_known_answer"]
+    c = amd.design_svf(k["type"], k["freq"], k["gain_db"], k["q"], k["sr"])
+    for n in ("a1", "a2", "a3", "m0", "m1", "m2"):
+        assert getattr(c, n) == float(k[n])
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        t = int(rng.integers(0, 5))
+        f, g, q = float(rng.uniform(5, 30000)), float(rng.uniform(-60, 60)), float(rng.uniform(0.001, 30))
+        sr = float(rng.choice([44100.0, 48000.0, 96000.0, 192000.0]))
+        a, o = amd.design_svf(t, f, g, q, sr), oracle.svf_design(t, f, g, q, sr)
+        for n in ("a1", "a2", "a3", "m0", "m1", "m2"):
+            assert getattr(a, n) == getattr(o, n), (t, f, g, q, sr, n)
+    c = amd.design_svf(1, 1000.0, 0.0, 1.0, -1.0)           # invalid rate -> bypass coefficients
+    assert (c.a1, c.a2, c.a3, c.m0, c.m1, c.m2) == (1.0, 0.0, 0.0, 1.0, 0.0, 0.0)
+
+
+def test_eq_params_default_matches_reference_fixture(amd):
+    g = json.load(open(os.path.join(HERE, "golden", "eq_params_default_ref.json")))
+    p = amd.eq_params_default()
+    for b, ref in zip(p.bands, g["bands"]):
+        assert [b.frequency, b.gain, b.q, b.enabled, b.type, b.channel_mode] == ref
+    assert p.nonlinear_saturation == np.float32(g["nonlinearSaturation"]) and p.total_gain_db == g["totalGainDb"]
+
+
+def test_invalid_arguments_are_rejected_without_gpu(amd):
+    from convopeq_amd import _capi
+    lib = _capi.load()
+    p = _capi.NucPlan()
+    assert lib.cpq_nuc_plan_compute(0, 512, 0, None, C.byref(p)) == _capi.CPQ_ERR_INVALID_ARG
+    assert lib.cpq_nuc_plan_compute(100, 0, 0, None, C.byref(p)) == _capi.CPQ_ERR_INVALID_ARG
+    assert lib.cpq_engine_create(None, None) == _capi.CPQ_ERR_INVALID_ARG
+    h = _capi._E()
+    d = _capi.EngineDesc(C.sizeof(_capi.EngineDesc), 0, 1, 500, 4096, 1, 0, 0, 48000.0)   # block not a power of two
+    assert lib.cpq_engine_create(C.byref(d), C.byref(h)) == _capi.CPQ_ERR_INVALID_ARG
+    assert b"power of two" in lib.cpq_last_error(None)
+    assert lib.cpq_status_string(-5) == b"not supported by this engine version"
+    assert lib.cpq_kernel_name(1) == b"k_fdl_mac"
