@@ -322,8 +322,8 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_UNSUPPORTED, "this version implements block_size == %d only", kP);
     if (d->semantics != CPQ_SEM_REFERENCE && d->semantics != CPQ_SEM_EXACT)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "bad semantics");
-    if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16)
-        return fail(nullptr, CPQ_ERR_INVALID_ARG, "mac_tile must be 0, 4, 8 or 16");
+    if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16 && d->mac_tile != 32)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "mac_tile must be 0, 4, 8, 16 or 32");
 
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
@@ -345,7 +345,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->sampleRate = d->sample_rate > 0.0 ? d->sample_rate : 48000.0;
     e->nCh = 2 * d->n_streams;
     e->tMax = d->max_blocks_per_call;
-    e->macTile = d->mac_tile ? d->mac_tile : 16;
+    e->macTile = d->mac_tile;     // 0 = automatic (workgroup-cooperative kernel for calls of >= 32 blocks)
 
     // partition capacity from the longest h_eff the plan can produce for max_ir_len
     cpq_nuc_plan pl;

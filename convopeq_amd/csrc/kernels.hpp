@@ -10,7 +10,7 @@ namespace cpq {
 // partition / block size handled by the wave-level FFT kernels in this version
 constexpr int kP = 512;            // samples per partition == complex bins per packed spectrum
 constexpr int kMacPrefetch = 4;    // FDL/IR rows kept in flight per lane in k_fdl_mac
-constexpr int kMacMaxTile = 16;    // largest outputs-per-lane tile; partition counts are padded to it
+constexpr int kMacMaxTile = 32;    // largest outputs-per-lane tile; partition counts are padded to it
 constexpr int kBands = 20;
 
 struct FftTables {

@@ -14,13 +14,14 @@
 // Accumulation order: ascending IR partition index k (the reference walks its reversed partition array
 // over the same pairs, :959-985,:1291-1308); FMA instead of the reference's mul/add.
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace cpq {
 
 namespace {
 
 template <int TT, int PF>
-__global__ __launch_bounds__(256) void k_fdl_mac(const double2* __restrict__ X, const double2* __restrict__ H,
+__global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) void k_fdl_mac(const double2* __restrict__ X, const double2* __restrict__ H,
                                                  const int* __restrict__ irSlot, double2* __restrict__ Y,
                                                  int nPairs, int kPad, int ringMask, int head, int T, int nTiles,
                                                  int64_t hSlotStride)
@@ -63,6 +64,9 @@ __global__ __launch_bounds__(256) void k_fdl_mac(const double2* __restrict__ X, 
             const double2 xnew = xn[r % PF];
             hn[r % PF] = Hc[(int64_t)(k + PF) * kP];                                   // IR row k+PF (zero rows past K)
             xn[r % PF] = Xc[(int64_t)((base - (k + PF) - 1) & ringMask) * kP];          // FDL row entering at step k+PF
+            // keep the two loads HERE: without the fence the scheduler sinks them next to their use PF steps
+            // later (to save registers) and the kernel runs with <= 3 loads in flight per wave
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TT; ++i) {
                 const double2 x = xw[(i - r + TT) % TT];
@@ -70,11 +74,100 @@ __global__ __launch_bounds__(256) void k_fdl_mac(const double2* __restrict__ X, 
                 acc[i].y = fma(x.x, h.y, fma(x.y, h.x, acc[i].y));
             }
             xw[TT - 1 - r] = xnew;    // X[t0 + TT-1 - k] retires, X[t0 - k - 1] takes its place
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i)
         if (t0 + i < T) Y[((int64_t)c * T + t0 + i) * kP + bin] = acc[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Workgroup-cooperative variant for calls of >= 32 blocks.
+//
+// fp64 FMA needs >= 4 waves per SIMD to approach its issue rate on gfx950 (measured: 1 wave 25-45, 2 waves
+// ~50, 4 waves ~60 TFLOP/s), i.e. <= 128 VGPRs per lane, which caps the register tile at 8 outputs per lane;
+// a tile that small re-reads every FDL and IR row 8x more often than a 64-output tile.  So eight waves of one
+// workgroup take the eight consecutive 8-block tiles of the SAME (channel, 64-bin column) and share the FDL rows
+// through LDS: wave w needs FDL row (t0 + 8w - k - 1) at partition step k, which wave w-1 needs eight steps
+// later, so each row is fetched from HBM once, parked in a 9-block LDS ring (72 KB, lane-linear rows: every
+// ds_read/ds_write_b128 is conflict-free) and read by the eight waves at eight different times.  One barrier per
+// 8 steps.  IR rows are read by all eight waves at the same step straight from global memory (one L2/HBM fetch,
+// seven L1 hits).  HBM traffic per launch = every needed FDL row, IR row and output row exactly once.
+constexpr int kWgWaves = 8;
+constexpr int kWgTile = 8;                       // outputs per lane
+constexpr int kWgRingBlocks = kWgWaves + 1;      // blocks of 8 rows
+
+template <int PFH>
+__global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* __restrict__ X,
+                                                                  const double2* __restrict__ H,
+                                                                  const int* __restrict__ irSlot,
+                                                                  double2* __restrict__ Y, int kPad, int ringMask,
+                                                                  int head, int T, int nGroups, int64_t hSlotStride)
+{
+    __shared__ double2 ring[kWgRingBlocks * kWgTile * 64];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int grp = blockIdx.x % nGroups;
+    const int cg = blockIdx.x / nGroups;
+    const int c = cg >> 3;
+    const int bin = (cg & 7) * 64 + lane;
+    const int base = head + grp * (kWgWaves * kWgTile);          // FDL slot of the group's first output block
+    const int t0w = grp * (kWgWaves * kWgTile) + w * kWgTile;    // this wave's first output block
+
+    const double2* __restrict__ Xc = X + (int64_t)c * (ringMask + 1) * kP + bin;
+    const double2* __restrict__ Hc = H + (int64_t)irSlot[c] * hSlotStride + bin;
+    auto slotOf = [](int b) { return ((b % kWgRingBlocks) + kWgRingBlocks) % kWgRingBlocks; };
+
+    double2 acc[kWgTile], xw[kWgTile], hn[PFH];
+#pragma unroll
+    for (int u = 0; u < kWgTile; ++u) {
+        acc[u] = make_double2(0.0, 0.0);
+        xw[u] = Xc[(int64_t)((base + kWgTile * w + u) & ringMask) * kP];
+    }
+    // ring prologue: block b (rows base+8b .. base+8b+7) for b = 0..6 is the register window of wave b;
+    // block -1 is fetched one row per wave
+    if (w < kWgWaves - 1) {
+#pragma unroll
+        for (int u = 0; u < kWgTile; ++u) ring[(slotOf(w) * kWgTile + u) * 64 + lane] = xw[u];
+    }
+    {
+        const double2 xs = Xc[(int64_t)((base - kWgTile + w) & ringMask) * kP];
+        ring[(slotOf(-1) * kWgTile + w) * 64 + lane] = xs;
+    }
+#pragma unroll
+    for (int r = 0; r < PFH; ++r) hn[r] = Hc[(int64_t)r * kP];
+    __syncthreads();
+
+    const int nChunks = kPad / kWgTile;
+    for (int j = 0; j < nChunks; ++j) {
+        // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
+        const double2 xs = Xc[(int64_t)((base + kWgTile * (-j - 2) + w) & ringMask) * kP];
+        const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < kWgTile; ++r) {
+            const int k = j * kWgTile + r;
+            const double2 h = hn[r % PFH];
+            hn[r % PFH] = Hc[(int64_t)(k + PFH) * kP];
+            const double2 xnew = blk[(kWgTile - 1 - r) * 64];        // X[t0w - k - 1]
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < kWgTile; ++i) {
+                const double2 x = xw[(i - r + kWgTile) % kWgTile];
+                acc[i].x = fma(x.x, h.x, fma(-x.y, h.y, acc[i].x));
+                acc[i].y = fma(x.x, h.y, fma(x.y, h.x, acc[i].y));
+            }
+            xw[kWgTile - 1 - r] = xnew;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // slot of block (-j-2) == slot of block (7-j), last read by wave 7 in chunk j-1: free since the barrier
+        // that ended that chunk
+        ring[(slotOf(-j - 2) * kWgTile + w) * 64 + lane] = xs;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < kWgTile; ++i)
+        if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * kP + bin] = acc[i];
 }
 
 // Packed bin 0 holds (DC, Nyquist): two independent real MACs per (channel, block).
@@ -99,11 +192,10 @@ __global__ __launch_bounds__(256) void k_fdl_mac_dcnyq(const double2* __restrict
     Y[(int64_t)idx * kP] = make_double2(dc, ny);
 }
 
-template <int TT>
+template <int TT, int PF>
 void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const int* irSlot, double2* Y, int nCh,
                   int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
 {
-    constexpr int PF = (TT < kMacPrefetch) ? TT : kMacPrefetch;
     const int nPairs = nCh * 2;
     const int nTiles = (T + TT - 1) / TT;
     const int groups = (nPairs + 7) / 8;
@@ -117,11 +209,23 @@ void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const 
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot, double2* Y,
                     int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
 {
-    switch (tile) {
-        case 4:  launch_mac_t<4>(stream, X, H, irSlot, Y, nCh, kPad, ringSlots, head, T, hSlotStride); break;
-        case 8:  launch_mac_t<8>(stream, X, H, irSlot, Y, nCh, kPad, ringSlots, head, T, hSlotStride); break;
-        default: launch_mac_t<16>(stream, X, H, irSlot, Y, nCh, kPad, ringSlots, head, T, hSlotStride); break;
+    if (tile == 0 && T >= 32) {      // default for long calls: workgroup-cooperative kernel
+        const int nGroups = (T + kWgWaves * kWgTile - 1) / (kWgWaves * kWgTile);
+        hipLaunchKernelGGL((k_fdl_mac_wg<4>), dim3(nCh * 8 * nGroups), dim3(64 * kWgWaves), 0, stream, X, H, irSlot, Y,
+                           kPad, ringSlots - 1, head, T, nGroups, hSlotStride);
+        return;
     }
+    // DIAG: CPQ_MAC_PF selects the prefetch depth for tuning experiments
+    const char* pfEnv = getenv("CPQ_MAC_PF");
+    const int pf = pfEnv ? atoi(pfEnv) : 4;
+#define CPQ_MAC_CASE(TT_, PF_) launch_mac_t<TT_, PF_>(stream, X, H, irSlot, Y, nCh, kPad, ringSlots, head, T, hSlotStride)
+    switch (tile) {
+        case 4:  CPQ_MAC_CASE(4, 4); break;
+        case 8:  if (pf >= 8) CPQ_MAC_CASE(8, 8); else CPQ_MAC_CASE(8, 4); break;
+        case 32: if (pf >= 16) CPQ_MAC_CASE(32, 16); else if (pf >= 8) CPQ_MAC_CASE(32, 8); else CPQ_MAC_CASE(32, 4); break;
+        default: if (pf >= 16) CPQ_MAC_CASE(16, 16); else if (pf >= 8) CPQ_MAC_CASE(16, 8); else CPQ_MAC_CASE(16, 4); break;
+    }
+#undef CPQ_MAC_CASE
 }
 
 void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2* HDN, const int* irSlot, double2* Y,

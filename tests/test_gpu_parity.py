@@ -55,14 +55,14 @@ def test_config1_single_stream_4096_taps(amd, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("blocks_per_call,tile", [(1, 16), (5, 4), (16, 8), (24, 16)])
+@pytest.mark.parametrize("blocks_per_call,tile", [(1, 16), (5, 4), (16, 8), (24, 16), (48, 32), (32, 0), (40, 0), (112, 0)])
 def test_long_ir_reference_semantics(amd, oracle, blocks_per_call, tile):
     """131072-tap IRs, private per channel: reference semantics (tail gain 1.4375, L1 lag +1408) via h_eff,
     time-batched T blocks per call, compared with the oracle's Add/Get schedule emulation."""
     O = oracle
     S = 2
     irs = [O.gen_ir(131072, stream=c // 2, channel=c % 2) for c in range(2 * S)]
-    n_blocks = 336 if blocks_per_call != 5 else 335
+    n_blocks = {5: 335, 32: 320, 40: 320, 112: 336}.get(blocks_per_call, 336)
     x = make_inputs(O, S, n_blocks * B)
     ref = oracle_conv(O, irs, x)
     eng = amd.BatchedEngine(S, max_ir_len=131072, max_blocks_per_call=blocks_per_call, mac_tile=tile)
