@@ -153,3 +153,150 @@ def test_conv_then_eq_whole_path(amd, oracle):
     print("conv+eq rms err", err)
     assert err <= 1e-13
     eng.close()
+
+
+def _copy_params(po, pa):
+    for i in range(20):
+        b, o = pa.bands[i], po.bands[i]
+        b.frequency, b.gain, b.q, b.enabled, b.type, b.channel_mode = o.frequency, o.gain, o.q, o.enabled, o.type, o.channelMode
+    pa.nonlinear_saturation = po.nonlinearSaturation
+    pa.total_gain_db = po.totalGainDb
+    return pa
+
+
+def test_config4_long_reverb_524288_taps(amd, oracle):
+    """BASELINE.json configs[3] shape (524288-tap IR, blk 512; 2 of the 64 streams so the oracle finishes in
+    seconds): three reference layers (512/4096/32768), L2 lag -232064, h_eff semantics."""
+    O = oracle
+    S, L, T = 2, 524288, 64
+    irs = [O.gen_ir(L, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    n_blocks = 1280
+    x = make_inputs(O, S, n_blocks * B)
+    ref = oracle_conv(O, irs, x)
+    eng = amd.BatchedEngine(S, max_ir_len=L, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    p = eng.plan()
+    assert p.num_layers == 3 and p.lag[2] == -232064 and p.lti_valid == 1
+    y = np.concatenate([eng.conv_process(x[:, o:o + T * B]) for o in range(0, n_blocks * B, T * B)], axis=1)
+    err = rms(y - ref)
+    print(f"config4 rms err {err:.3e} signal rms {rms(ref):.3f}")
+    assert err <= 1e-12
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+def test_eq_left_right_channel_modes_and_disabled_bands(amd, oracle, mode):
+    """Left/Right channel modes run the scalar processBand arithmetic (no FMA, hard-clipped fastTanh); disabled
+    bands are skipped; total gain applied at the end."""
+    O = oracle
+    S, n = 2, 8 * B
+    x = make_inputs(O, S, n)
+    po = O.eq_params_bench(0.2)
+    for i in (1, 5, 9):
+        po.bands[i].channelMode = 1
+    for i in (2, 6, 10):
+        po.bands[i].channelMode = 2
+    for i in (3, 7):
+        po.bands[i].enabled = 0
+    po.totalGainDb = -6.5
+    pa = _copy_params(po, amd.eq_params_default())
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=8)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, pa)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    y = eng.eq_process(x)
+    worst = 0.0
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po)
+        worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+    print("eq modes", mode, "max abs diff", worst)
+    assert worst <= (0.0 if mode == "sequential" else 1e-13)
+    eng.close()
+
+
+def test_eq_per_stream_params_and_hot_signal(amd, oracle):
+    """Different EQ parameters per stream; input scaled x40 so the saturation blend and the +-100 clamp act."""
+    O = oracle
+    S, n = 3, 16 * B
+    x = 40.0 * make_inputs(O, S, n)
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=16)
+    pos = []
+    for s in range(S):
+        po = O.eq_params_bench(0.1 * s)                # stream 0: linear (saturation 0) with large boosts
+        for i in range(20):
+            po.bands[i].gain = abs(po.bands[i].gain) * 4.0 if s == 0 else po.bands[i].gain * (1.0 + s)
+        po.bands[4].type = 3 if s == 1 else 1          # a low-pass band on stream 1
+        po.bands[12].type = 4 if s == 2 else 1         # a high-pass band on stream 2
+        pos.append(po)
+        eng.set_eq_params(s, _copy_params(po, amd.eq_params_default()))
+    y = eng.eq_process(x)
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], pos[s])
+        if s == 0:
+            assert np.abs(yl).max() == 100.0            # the +-100 clamp is exercised
+        assert max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max()) <= 1e-11
+    eng.close()
+
+
+def test_eq_nonfinite_input_takes_guarded_path(amd, oracle):
+    """NaN / Inf / huge samples: the time-parallel kernel must fall back to the guarded recurrence for that span
+    and reproduce the reference's sanitising behaviour exactly like the sequential kernel."""
+    O = oracle
+    S, n = 1, 16 * B
+    x = make_inputs(O, S, n)
+    x[0, 100] = np.nan
+    x[1, 5000] = np.inf
+    x[0, 6000] = 1e300
+    po = O.eq_params_bench(0.2)
+    pa = _copy_params(po, amd.eq_params_default())
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=16)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, pa)
+    y = eng.eq_process(x)
+    yl, yr, _ = O.eq_process_stereo(x[0], x[1], po)
+    assert np.all(np.isfinite(y))
+    assert max(np.abs(y[0] - yl).max(), np.abs(y[1] - yr).max()) <= 1e-12
+    eng.close()
+
+
+def test_eq_then_conv_order(amd, oracle):
+    O = oracle
+    S = 1
+    irs = [O.gen_ir(6000, stream=0, channel=ch) for ch in range(2)]
+    x = make_inputs(O, S, 24 * B)
+    po = O.eq_params_bench(0.2)
+    el, er, _ = O.eq_process_stereo(x[0], x[1], po)
+    ref = oracle_conv(O, irs, np.stack([el, er]))
+    eng = amd.BatchedEngine(S, max_ir_len=6000, max_blocks_per_call=8)
+    eng.set_impulse(0, irs[0], irs[1])
+    eng.set_eq_params(0, _copy_params(po, amd.eq_params_default()))
+    eng.set_order(amd.CPQ_ORDER_EQ_THEN_CONV)
+    y = np.concatenate([eng.process(x[:, o:o + 8 * B]) for o in range(0, 24 * B, 8 * B)], axis=1)
+    assert rms(y - ref) <= 1e-13
+    eng.close()
+
+
+def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
+    O = oracle
+    eng = amd.BatchedEngine(1, max_ir_len=4096, max_blocks_per_call=4)
+    ir = O.gen_ir(4096)
+    eng.set_impulse(0, ir, ir)
+    x = make_inputs(O, 1, 4 * B)
+    y1 = eng.conv_process(x)
+    eng.conv_process(x)
+    eng.prepare_to_play(48000.0, 4 * B)
+    assert np.array_equal(eng.conv_process(x), y1)
+    with pytest.raises(amd.CpqError) as e1:
+        eng.set_impulse(0, ir, ir, spec=amd.FilterSpec.defaults())
+    assert e1.value.status == -5
+    with pytest.raises(amd.CpqError) as e2:
+        eng.set_impulse(0, ir, ir, direct_head=True)
+    assert e2.value.status == -5
+    with pytest.raises(amd.CpqError):
+        eng.conv_process(x[:, :100])                    # not a multiple of the block size
+    p = amd.eq_params_default()
+    p.agc_enabled = 1
+    with pytest.raises(amd.CpqError):
+        eng.set_eq_params(0, p)
+    eng.close()
+    with pytest.raises(amd.CpqError):
+        amd.BatchedEngine(1, block_size=1024, max_ir_len=131072)   # non-LTI / unsupported block size
