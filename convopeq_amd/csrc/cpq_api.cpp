@@ -23,7 +23,6 @@
 #include "kernels.hpp"
 
 using cpq::kBands;
-using cpq::kP;
 
 namespace {
 
@@ -47,6 +46,7 @@ struct cpq_engine {
 
     // geometry
     int nCh = 0;          // 2 * streams
+    int P = 0;            // partition size == block size (samples) == complex bins per packed spectrum
     int kCap = 0;         // partition capacity per IR slot (multiple of kMacMaxTile)
     int hRows = 0;        // kCap + prefetch rows allocated per IR slot
     int ringSlots = 0;    // FDL ring slots per channel (power of two)
@@ -56,15 +56,15 @@ struct cpq_engine {
     // device arena
     char* arena = nullptr;
     int64_t arenaBytes = 0;
-    double2* X = nullptr;       // [nCh][ringSlots][kP]       FDL ring of packed spectra
+    double2* X = nullptr;       // [nCh][ringSlots][e->P]       FDL ring of packed spectra
     double2* XDN = nullptr;     // [nCh][ringSlots]           (DC, Nyquist) of every FDL slot
-    double2* H = nullptr;       // [nCh][hRows][kP]           IR partition spectra per IR slot
+    double2* H = nullptr;       // [nCh][hRows][e->P]           IR partition spectra per IR slot
     double2* HDN = nullptr;     // [nCh][hRows]
-    double2* Y = nullptr;       // [nCh][tMax][kP]            accumulated output spectra of the call
-    double* hist[2] = { nullptr, nullptr };   // [nCh][kP]    overlap history, ping-pong
-    double* stageIn = nullptr;  // [nCh][tMax*kP]             staging for the host-pointer entry points
+    double2* Y = nullptr;       // [nCh][tMax][e->P]            accumulated output spectra of the call
+    double* hist[2] = { nullptr, nullptr };   // [nCh][e->P]    overlap history, ping-pong
+    double* stageIn = nullptr;  // [nCh][tMax*e->P]             staging for the host-pointer entry points
     double* stageOut = nullptr;
-    double* mid = nullptr;      // [nCh][tMax*kP]             conv <-> EQ hand-off (not used when in place)
+    double* mid = nullptr;      // [nCh][tMax*e->P]             conv <-> EQ hand-off (not used when in place)
     double* heffDev = nullptr;  // staging for one h_eff upload
     int64_t heffCap = 0;
     double2* tw512 = nullptr;
@@ -161,25 +161,25 @@ int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int*
 int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!cpq_conv_is_ready(e)) return fail(e, CPQ_ERR_NOT_READY, "set_impulse has not covered every stream");
-    const int64_t stride = (int64_t)T * kP;
+    const int64_t stride = (int64_t)T * e->P;
     {
         ProfScope p(e, CPQ_K_RFFT_FWD);
         cpq::launch_rfft_fwd_ols(e->stream, dIn, stride, e->hist[e->histSel], e->hist[e->histSel ^ 1], e->X, e->XDN,
-                                 tables(e), e->nCh, T, e->head, e->ringSlots);
+                                 tables(e), e->P, e->nCh, T, e->head, e->ringSlots);
     }
     {
         ProfScope p(e, CPQ_K_FDL_MAC);
-        cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->nCh, e->kActive, e->ringSlots,
-                            e->head, T, (int64_t)e->hRows * kP);
+        cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh, e->kActive, e->ringSlots,
+                            e->head, T, (int64_t)e->hRows * e->P);
     }
     {
         ProfScope p(e, CPQ_K_DCNYQ);
-        cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN, e->irSlot, e->Y, e->nCh, e->kMaxReal, e->ringSlots,
+        cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN, e->irSlot, e->Y, e->P, e->nCh, e->kMaxReal, e->ringSlots,
                                   e->head, T, e->hRows);
     }
     {
         ProfScope p(e, CPQ_K_RFFT_INV);
-        cpq::launch_rfft_inv_ols(e->stream, e->Y, dOut, stride, tables(e), e->nCh, T);
+        cpq::launch_rfft_inv_ols(e->stream, e->Y, dOut, stride, tables(e), e->P, e->nCh, T);
     }
     CPQ_HIP(e, hipGetLastError());
     e->head = (e->head + T) & (e->ringSlots - 1);
@@ -192,13 +192,16 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
     bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO);
     for (char s : e->eqTpSafe) tp = tp && s;
-    if (tp) {
+    const int n = T * e->P;
+    const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
+    if (nTp > 0) {
         ProfScope p(e, CPQ_K_SVF_TP);
-        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, (int64_t)T * kP, e->nCh, T * kP, e->svfCoef, e->svfFlags,
+        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, (int64_t)n, e->nCh, nTp, e->svfCoef, e->svfFlags,
                                    e->svfSatGain, e->svfState, e->svfTp);
-    } else {
+    }
+    if (n > nTp) {
         ProfScope p(e, CPQ_K_SVF);
-        cpq::launch_svf_cascade(e->stream, dIn, dOut, (int64_t)T * kP, e->nCh, T * kP, e->svfCoef, e->svfFlags,
+        cpq::launch_svf_cascade(e->stream, dIn + nTp, dOut + nTp, (int64_t)n, e->nCh, n - nTp, e->svfCoef, e->svfFlags,
                                 e->svfSatGain, e->svfState);
     }
     CPQ_HIP(e, hipGetLastError());
@@ -225,10 +228,10 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
 {
     CPQ_HIP(e, hipSetDevice(e->device));
     if (conv) {
-        CPQ_HIP(e, hipMemsetAsync(e->X, 0, (size_t)e->nCh * e->ringSlots * kP * sizeof(double2), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->X, 0, (size_t)e->nCh * e->ringSlots * e->P * sizeof(double2), e->stream));
         CPQ_HIP(e, hipMemsetAsync(e->XDN, 0, (size_t)e->nCh * e->ringSlots * sizeof(double2), e->stream));
-        CPQ_HIP(e, hipMemsetAsync(e->hist[0], 0, (size_t)e->nCh * kP * sizeof(double), e->stream));
-        CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * kP * sizeof(double), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->hist[0], 0, (size_t)e->nCh * e->P * sizeof(double), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * e->P * sizeof(double), e->stream));
         e->head = 0;
         e->histSel = 0;
     }
@@ -318,8 +321,6 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "n_streams, max_ir_len and max_blocks_per_call must be positive");
     if (d->block_size < 64 || d->block_size > 2048 || (d->block_size & (d->block_size - 1)))
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 2048]");
-    if (d->block_size != kP)
-        return fail(nullptr, CPQ_ERR_UNSUPPORTED, "this version implements block_size == %d only", kP);
     if (d->semantics != CPQ_SEM_REFERENCE && d->semantics != CPQ_SEM_EXACT)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "bad semantics");
     if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16 && d->mac_tile != 32)
@@ -344,6 +345,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->device = d->device;
     e->sampleRate = d->sample_rate > 0.0 ? d->sample_rate : 48000.0;
     e->nCh = 2 * d->n_streams;
+    e->P = d->block_size;
     e->tMax = d->max_blocks_per_call;
     e->macTile = d->mac_tile;     // 0 = automatic (workgroup-cooperative kernel for calls of >= 32 blocks)
 
@@ -354,30 +356,30 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "cannot plan max_ir_len=%d", d->max_ir_len);
     }
     const int taps = (d->semantics == CPQ_SEM_REFERENCE) ? std::max(pl.heff_len, d->max_ir_len) : d->max_ir_len;
-    const int kReal = (taps + kP - 1) / kP;
+    const int kReal = (taps + e->P - 1) / e->P;
     e->kCap = (int)alignUp(kReal, cpq::kMacMaxTile);
     e->hRows = e->kCap + cpq::kMacMaxTile;   // zero rows read by the prefetch past the last partition
     e->ringSlots = nextPow2(e->kCap + cpq::kMacMaxTile + e->tMax);
-    e->heffCap = (int64_t)e->kCap * kP;
+    e->heffCap = (int64_t)e->kCap * e->P;
 
     // ---- arena layout
     struct Item { void** ptr; int64_t bytes; };
     const int64_t nCh = e->nCh;
-    const int64_t callSamples = (int64_t)e->tMax * kP;
+    const int64_t callSamples = (int64_t)e->tMax * e->P;
     Item items[] = {
-        { (void**)&e->X, nCh * e->ringSlots * kP * (int64_t)sizeof(double2) },
+        { (void**)&e->X, nCh * e->ringSlots * e->P * (int64_t)sizeof(double2) },
         { (void**)&e->XDN, nCh * e->ringSlots * (int64_t)sizeof(double2) },
-        { (void**)&e->H, nCh * e->hRows * kP * (int64_t)sizeof(double2) },
+        { (void**)&e->H, nCh * e->hRows * e->P * (int64_t)sizeof(double2) },
         { (void**)&e->HDN, nCh * e->hRows * (int64_t)sizeof(double2) },
-        { (void**)&e->Y, nCh * e->tMax * kP * (int64_t)sizeof(double2) },
-        { (void**)&e->hist[0], nCh * kP * (int64_t)sizeof(double) },
-        { (void**)&e->hist[1], nCh * kP * (int64_t)sizeof(double) },
+        { (void**)&e->Y, nCh * e->tMax * e->P * (int64_t)sizeof(double2) },
+        { (void**)&e->hist[0], nCh * e->P * (int64_t)sizeof(double) },
+        { (void**)&e->hist[1], nCh * e->P * (int64_t)sizeof(double) },
         { (void**)&e->stageIn, nCh * callSamples * (int64_t)sizeof(double) },
         { (void**)&e->stageOut, nCh * callSamples * (int64_t)sizeof(double) },
         { (void**)&e->mid, nCh * callSamples * (int64_t)sizeof(double) },
         { (void**)&e->heffDev, e->heffCap * (int64_t)sizeof(double) },
-        { (void**)&e->tw512, 512 * (int64_t)sizeof(double2) },
-        { (void**)&e->tw1024, 512 * (int64_t)sizeof(double2) },
+        { (void**)&e->tw512, e->P * (int64_t)sizeof(double2) },
+        { (void**)&e->tw1024, e->P * (int64_t)sizeof(double2) },
         { (void**)&e->irSlot, nCh * (int64_t)sizeof(int) },
         { (void**)&e->svfCoef, nCh * kBands * 6 * (int64_t)sizeof(double) },
         { (void**)&e->svfFlags, nCh * kBands * (int64_t)sizeof(int) },
@@ -402,15 +404,15 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_DEVICE, "hipMemset of the arena failed");
     }
     // twiddles in extended precision on the host, rounded once (SURVEY.md section 7 "hard parts")
-    std::vector<double2> w512(512), w1024(512);
+    std::vector<double2> w512(e->P), w1024(e->P);
     const long double twoPi = 6.283185307179586476925286766559005768L;
-    for (int m = 0; m < 512; ++m) {
-        const long double a = -twoPi * m / 512.0L, b = -twoPi * m / 1024.0L;
+    for (int m = 0; m < e->P; ++m) {
+        const long double a = -twoPi * m / (long double)e->P, b = -twoPi * m / (long double)(2 * e->P);
         w512[m] = make_double2((double)cosl(a), (double)sinl(a));
         w1024[m] = make_double2((double)cosl(b), (double)sinl(b));
     }
-    if (hipMemcpy(e->tw512, w512.data(), 512 * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(e->tw1024, w1024.data(), 512 * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMemcpy(e->tw512, w512.data(), e->P * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->tw1024, w1024.data(), e->P * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) {
         cpq_engine_destroy(e);
         return fail(nullptr, CPQ_ERR_DEVICE, "twiddle upload failed");
     }
@@ -506,18 +508,18 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             heff.assign(irs[ch], irs[ch] + irLen);
             if (std::abs(scale - 1.0) > 1e-12) for (double& v : heff) v *= scale;
         }
-        const int parts = ((int)heff.size() + kP - 1) / kP;
+        const int parts = ((int)heff.size() + e->P - 1) / e->P;
         if (parts > e->kCap) return fail(e, CPQ_ERR_INVALID_ARG, "h_eff needs %d partitions, capacity %d", parts, e->kCap);
         const int slot = slotBase + ch;
         CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        double2* Hs = e->H + (int64_t)slot * e->hRows * kP;
+        double2* Hs = e->H + (int64_t)slot * e->hRows * e->P;
         double2* HDNs = e->HDN + (int64_t)slot * e->hRows;
         // stale partitions of a longer previous IR in this slot become zero rows
         if (e->irParts[slot] > parts) {
-            CPQ_HIP(e, hipMemsetAsync(Hs + (int64_t)parts * kP, 0, (size_t)(e->irParts[slot] - parts) * kP * sizeof(double2), e->stream));
+            CPQ_HIP(e, hipMemsetAsync(Hs + (int64_t)parts * e->P, 0, (size_t)(e->irParts[slot] - parts) * e->P * sizeof(double2), e->stream));
             CPQ_HIP(e, hipMemsetAsync(HDNs + parts, 0, (size_t)(e->irParts[slot] - parts) * sizeof(double2), e->stream));
         }
-        cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Hs, HDNs, tables(e), parts);
+        cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Hs, HDNs, tables(e), e->P, parts);
         CPQ_HIP(e, hipGetLastError());
         CPQ_HIP(e, hipStreamSynchronize(e->stream));   // heffDev is reused for the next channel
         e->irParts[slot] = parts;

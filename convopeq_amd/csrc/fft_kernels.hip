@@ -204,26 +204,166 @@ __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__
         *reinterpret_cast<double2*>(o + 2 * (lane + 64 * (r - 4))) = make_double2(v[r].x * s, v[r].y * s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic partition sizes (P = 64 ... 2048 except 512): one workgroup per transform, radix-2 Stockham
+// autosort between two LDS buffers (2 x P complex), then the same real-FFT split.  Slower per byte than the
+// wave-level 512-point kernels above; covers the block-size sweep of BASELINE.json configs[2].
+// tw.tw512 holds exp(-2 pi i m / P) (m < P), tw.tw1024 holds exp(-2 pi i k / 2P) (k < P) for the engine's P.
+
+template <bool INV>
+__device__ __forceinline__ double2* stockham(double2* a, double2* b, int M, const double2* __restrict__ twM)
+{
+    const int half = M >> 1;
+    for (int ns = 1; ns < M; ns <<= 1) {
+        const int tstep = half / ns;                 // twiddle index scale: exp(-2 pi i k / (2 ns)) = twM[k * tstep]
+        for (int j = threadIdx.x; j < half; j += blockDim.x) {
+            const int k = j & (ns - 1);
+            const double2 w = twM[k * tstep];
+            const double2 u = a[j];
+            const double2 v = cmulw<INV>(a[j + half], w);
+            const int o = ((j - k) << 1) + k;
+            b[o] = cadd(u, v);
+            b[o + ns] = csub(u, v);
+        }
+        __syncthreads();
+        double2* t = a; a = b; b = t;
+    }
+    return a;      // buffer holding the result, natural order
+}
+
+__device__ __forceinline__ void split_store_generic(const double2* Z, int M, const double2* __restrict__ tw2M,
+                                                    double2* __restrict__ spec, double2* __restrict__ dcnyq)
+{
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        const double2 zk = Z[k];
+        const double2 zm = Z[(M - k) & (M - 1)];
+        const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+        const double2 o = make_double2(d.y, -d.x);
+        const double2 w = tw2M[k];
+        double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
+        if (k == 0) {
+            xk = make_double2(zk.x + zk.y, zk.x - zk.y);
+            *dcnyq = xk;
+        }
+        spec[k] = xk;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rfft_fwd_ols_generic(const double* __restrict__ in, int64_t chStride,
+                                                              const double* __restrict__ histOld,
+                                                              double* __restrict__ histNew, double2* __restrict__ X,
+                                                              double2* __restrict__ XDN, FftTables tw, int P, int T,
+                                                              int head, int ringMask)
+{
+    extern __shared__ double2 dyn[];
+    double2* a = dyn;
+    double2* b = dyn + P;
+    const int c = blockIdx.x / T;
+    const int t = blockIdx.x - c * T;
+    const double* cur = in + (int64_t)c * chStride + (int64_t)t * P;
+    const double* prev = (t > 0) ? (cur - P) : (histOld + (int64_t)c * P);
+    const int halfP = P >> 1;
+    for (int n = threadIdx.x; n < P; n += blockDim.x) {
+        const double* src = (n < halfP) ? (prev + 2 * n) : (cur + 2 * (n - halfP));
+        const double2 v = *reinterpret_cast<const double2*>(src);
+        a[n] = v;
+        if (t == T - 1 && n >= halfP) *reinterpret_cast<double2*>(histNew + (int64_t)c * P + 2 * (n - halfP)) = v;
+    }
+    __syncthreads();
+    const double2* Z = stockham<false>(a, b, P, tw.tw512);
+    const int slot = (head + t) & ringMask;
+    const int64_t row = (int64_t)c * (ringMask + 1) + slot;
+    split_store_generic(Z, P, tw.tw1024, X + row * P, XDN + row);
+}
+
+__global__ __launch_bounds__(256) void k_ir_spectra_generic(const double* __restrict__ heff, int heffLen,
+                                                            double2* __restrict__ H, double2* __restrict__ HDN,
+                                                            FftTables tw, int P)
+{
+    extern __shared__ double2 dyn[];
+    double2* a = dyn;
+    double2* b = dyn + P;
+    const int k = blockIdx.x;
+    const int halfP = P >> 1;
+    for (int n = threadIdx.x; n < P; n += blockDim.x) {
+        double2 v = make_double2(0.0, 0.0);
+        if (n < halfP) {
+            const int i = k * P + 2 * n;
+            v = make_double2(i < heffLen ? heff[i] : 0.0, (i + 1) < heffLen ? heff[i + 1] : 0.0);
+        }
+        a[n] = v;
+    }
+    __syncthreads();
+    const double2* Z = stockham<false>(a, b, P, tw.tw512);
+    split_store_generic(Z, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
+}
+
+__global__ __launch_bounds__(256) void k_rfft_inv_ols_generic(const double2* __restrict__ Y, double* __restrict__ out,
+                                                              int64_t chStride, FftTables tw, int P, int T)
+{
+    extern __shared__ double2 dyn[];
+    double2* a = dyn;
+    double2* b = dyn + P;
+    const int c = blockIdx.x / T;
+    const int t = blockIdx.x - c * T;
+    const double2* y = Y + (int64_t)blockIdx.x * P;
+    const double2 y0 = y[0];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        const double2 yk = y[k];
+        const double2 ym = y[(P - k) & (P - 1)];
+        const double2 e = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y - ym.y));
+        const double2 d = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y + ym.y));
+        const double2 w = tw.tw1024[k];
+        const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
+        double2 z = make_double2(e.x - o.y, e.y + o.x);
+        if (k == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
+        a[k] = z;
+    }
+    __syncthreads();
+    const double2* z = stockham<true>(a, b, P, tw.tw512);
+    double* o = out + (int64_t)c * chStride + (int64_t)t * P;
+    const double s = 1.0 / (double)P;
+    const int halfP = P >> 1;
+    for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)      // second half of the 2P-sample frame
+        *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(z[n].x * s, z[n].y * s);
+}
+
 }  // namespace
 
+static int genericThreads(int P) { return P / 2 < 64 ? 64 : (P / 2 > 256 ? 256 : P / 2); }
+
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
-                         double* histNew, double2* X, double2* XDN, FftTables tw, int nCh, int T, int head,
+                         double* histNew, double2* X, double2* XDN, FftTables tw, int P, int nCh, int T, int head,
                          int ringSlots)
 {
-    hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
-                       tw, T, head, ringSlots - 1);
+    if (P == kP)
+        hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
+                           tw, T, head, ringSlots - 1);
+    else
+        hipLaunchKernelGGL(k_rfft_fwd_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
+                           stream, in, chStride, histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
 }
 
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN, FftTables tw,
-                       int nParts)
+                       int P, int nParts)
 {
-    hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
+    if (P == kP)
+        hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
+    else
+        hipLaunchKernelGGL(k_ir_spectra_generic, dim3(nParts), dim3(genericThreads(P)), 2 * P * sizeof(double2), stream,
+                           heff, heffLen, H, HDN, tw, P);
 }
 
-void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int nCh,
-                         int T)
+void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P,
+                         int nCh, int T)
 {
-    hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
+    if (P == kP)
+        hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
+    else
+        hipLaunchKernelGGL(k_rfft_inv_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
+                           stream, Y, out, chStride, tw, P, T);
 }
 
 }  // namespace cpq

@@ -7,39 +7,39 @@
 
 namespace cpq {
 
-// partition / block size handled by the wave-level FFT kernels in this version
+// partition size with dedicated wave-level FFT kernels; other powers of two (64..2048) use generic kernels
 constexpr int kP = 512;            // samples per partition == complex bins per packed spectrum
 constexpr int kMacPrefetch = 4;    // FDL/IR rows kept in flight per lane in k_fdl_mac
 constexpr int kMacMaxTile = 32;    // largest outputs-per-lane tile; partition counts are padded to it
 constexpr int kBands = 20;
 
 struct FftTables {
-    const double2* tw512;    // exp(-2 pi i m / 512),  m < 512
-    const double2* tw1024;   // exp(-2 pi i k / 1024), k < 512
+    const double2* tw512;    // exp(-2 pi i m / P),  m < P   (P = partition size; 512 in the headline config)
+    const double2* tw1024;   // exp(-2 pi i k / 2P), k < P
 };
 
 // Overlap-save framing + 1024-point real FFT of T blocks per channel into the frequency-domain delay
 // line (FDL) ring; also saves the last block as the next call's overlap history.
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
-                         double* histNew, double2* X, double2* XDN, FftTables tw, int nCh, int T, int head,
-                         int ringSlots);
+                         double* histNew, double2* X, double2* XDN, FftTables tw, int P, int nCh, int T,
+                         int head, int ringSlots);
 
 // IR partition spectra: frames [h[k*P .. (k+1)*P) | 0] for k < nParts.
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN,
-                       FftTables tw, int nParts);
+                       FftTables tw, int P, int nParts);
 
 // Y[c][t][bin] = sum_k X[c][slot(head+t-k)][bin] * H[ir(c)][k][bin], bins 1..511 (bin 0 is written but
 // is overwritten by launch_fdl_mac_dcnyq).
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot,
-                    double2* Y, int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride);
+                    double2* Y, int P, int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride);
 
 // packed bin 0: DC and Nyquist are two independent real MACs.
 void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2* HDN, const int* irSlot,
-                          double2* Y, int nCh, int K, int ringSlots, int head, int T, int hdnStride);
+                          double2* Y, int P, int nCh, int K, int ringSlots, int head, int T, int hdnStride);
 
 // inverse 1024-point real FFT of Y, scaled 1/N, second half (P samples) to out.
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw,
-                         int nCh, int T);
+                         int P, int nCh, int T);
 
 // 20-band TPT-SVF cascade, lane = (channel, band), bands skewed in time across lanes.
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh,

@@ -14,7 +14,6 @@
 // Accumulation order: ascending IR partition index k (the reference walks its reversed partition array
 // over the same pairs, :959-985,:1291-1308); FMA instead of the reference's mul/add.
 #include "kernels.hpp"
-#include <cstdlib>
 
 namespace cpq {
 
@@ -24,7 +23,7 @@ template <int TT, int PF>
 __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) void k_fdl_mac(const double2* __restrict__ X, const double2* __restrict__ H,
                                                  const int* __restrict__ irSlot, double2* __restrict__ Y,
                                                  int nPairs, int kPad, int ringMask, int head, int T, int nTiles,
-                                                 int64_t hSlotStride)
+                                                 int64_t hSlotStride, int P, int segShift)
 {
     static_assert(TT % PF == 0, "prefetch depth must divide the tile");
     // XCD-aware decomposition: blocks b and b+8 share an XCD (and its L2) under round-robin dispatch, so the
@@ -36,11 +35,12 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
     const int tile = q % nTiles;
     const int pair = (q / nTiles) * 8 + xcd;
     if (pair >= nPairs) return;
-    const int c = pair >> 1;
-    const int bin = (pair & 1) * 256 + threadIdx.x;
+    // a block covers one segment of blockDim.x (<= 256) bins; P >> segShift... segments per spectrum = 1 << segShift
+    const int c = pair >> segShift;
+    const int bin = (pair & ((1 << segShift) - 1)) * blockDim.x + threadIdx.x;
     const int t0 = tile * TT;
 
-    const double2* __restrict__ Xc = X + (int64_t)c * (ringMask + 1) * kP + bin;
+    const double2* __restrict__ Xc = X + (int64_t)c * (ringMask + 1) * P + bin;
     const double2* __restrict__ Hc = H + (int64_t)irSlot[c] * hSlotStride + bin;
     const int base = head + t0;
 
@@ -48,12 +48,12 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
 #pragma unroll
     for (int u = 0; u < TT; ++u) {
         acc[u] = make_double2(0.0, 0.0);
-        xw[u] = Xc[(int64_t)((base + u) & ringMask) * kP];          // window: X[t0 + u - k] at (u - k) mod TT
+        xw[u] = Xc[(int64_t)((base + u) & ringMask) * P];          // window: X[t0 + u - k] at (u - k) mod TT
     }
 #pragma unroll
     for (int r = 0; r < PF; ++r) {
-        xn[r] = Xc[(int64_t)((base - r - 1) & ringMask) * kP];
-        hn[r] = Hc[(int64_t)r * kP];
+        xn[r] = Xc[(int64_t)((base - r - 1) & ringMask) * P];
+        hn[r] = Hc[(int64_t)r * P];
     }
 
     for (int k0 = 0; k0 < kPad; k0 += TT) {
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
             const int k = k0 + r;
             const double2 h = hn[r % PF];
             const double2 xnew = xn[r % PF];
-            hn[r % PF] = Hc[(int64_t)(k + PF) * kP];                                   // IR row k+PF (zero rows past K)
-            xn[r % PF] = Xc[(int64_t)((base - (k + PF) - 1) & ringMask) * kP];          // FDL row entering at step k+PF
+            hn[r % PF] = Hc[(int64_t)(k + PF) * P];                                   // IR row k+PF (zero rows past K)
+            xn[r % PF] = Xc[(int64_t)((base - (k + PF) - 1) & ringMask) * P];          // FDL row entering at step k+PF
             // keep the two loads HERE: without the fence the scheduler sinks them next to their use PF steps
             // later (to save registers) and the kernel runs with <= 3 loads in flight per wave
             __builtin_amdgcn_sched_barrier(0);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i)
-        if (t0 + i < T) Y[((int64_t)c * T + t0 + i) * kP + bin] = acc[i];
+        if (t0 + i < T) Y[((int64_t)c * T + t0 + i) * P + bin] = acc[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -103,19 +103,20 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
                                                                   const double2* __restrict__ H,
                                                                   const int* __restrict__ irSlot,
                                                                   double2* __restrict__ Y, int kPad, int ringMask,
-                                                                  int head, int T, int nGroups, int64_t hSlotStride)
+                                                                  int head, int T, int nGroups, int64_t hSlotStride,
+                                                                  int P, int nCols)
 {
     __shared__ double2 ring[kWgRingBlocks * kWgTile * 64];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int grp = blockIdx.x % nGroups;
     const int cg = blockIdx.x / nGroups;
-    const int c = cg >> 3;
-    const int bin = (cg & 7) * 64 + lane;
+    const int c = cg / nCols;
+    const int bin = (cg - c * nCols) * 64 + lane;
     const int base = head + grp * (kWgWaves * kWgTile);          // FDL slot of the group's first output block
     const int t0w = grp * (kWgWaves * kWgTile) + w * kWgTile;    // this wave's first output block
 
-    const double2* __restrict__ Xc = X + (int64_t)c * (ringMask + 1) * kP + bin;
+    const double2* __restrict__ Xc = X + (int64_t)c * (ringMask + 1) * P + bin;
     const double2* __restrict__ Hc = H + (int64_t)irSlot[c] * hSlotStride + bin;
     auto slotOf = [](int b) { return ((b % kWgRingBlocks) + kWgRingBlocks) % kWgRingBlocks; };
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
 #pragma unroll
     for (int u = 0; u < kWgTile; ++u) {
         acc[u] = make_double2(0.0, 0.0);
-        xw[u] = Xc[(int64_t)((base + kWgTile * w + u) & ringMask) * kP];
+        xw[u] = Xc[(int64_t)((base + kWgTile * w + u) & ringMask) * P];
     }
     // ring prologue: block b (rows base+8b .. base+8b+7) for b = 0..6 is the register window of wave b;
     // block -1 is fetched one row per wave
@@ -132,23 +133,23 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         for (int u = 0; u < kWgTile; ++u) ring[(slotOf(w) * kWgTile + u) * 64 + lane] = xw[u];
     }
     {
-        const double2 xs = Xc[(int64_t)((base - kWgTile + w) & ringMask) * kP];
+        const double2 xs = Xc[(int64_t)((base - kWgTile + w) & ringMask) * P];
         ring[(slotOf(-1) * kWgTile + w) * 64 + lane] = xs;
     }
 #pragma unroll
-    for (int r = 0; r < PFH; ++r) hn[r] = Hc[(int64_t)r * kP];
+    for (int r = 0; r < PFH; ++r) hn[r] = Hc[(int64_t)r * P];
     __syncthreads();
 
     const int nChunks = kPad / kWgTile;
     for (int j = 0; j < nChunks; ++j) {
         // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
-        const double2 xs = Xc[(int64_t)((base + kWgTile * (-j - 2) + w) & ringMask) * kP];
+        const double2 xs = Xc[(int64_t)((base + kWgTile * (-j - 2) + w) & ringMask) * P];
         const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
 #pragma unroll
         for (int r = 0; r < kWgTile; ++r) {
             const int k = j * kWgTile + r;
             const double2 h = hn[r % PFH];
-            hn[r % PFH] = Hc[(int64_t)(k + PFH) * kP];
+            hn[r % PFH] = Hc[(int64_t)(k + PFH) * P];
             const double2 xnew = blk[(kWgTile - 1 - r) * 64];        // X[t0w - k - 1]
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -167,14 +168,14 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     }
 #pragma unroll
     for (int i = 0; i < kWgTile; ++i)
-        if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * kP + bin] = acc[i];
+        if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * P + bin] = acc[i];
 }
 
 // Packed bin 0 holds (DC, Nyquist): two independent real MACs per (channel, block).
 __global__ __launch_bounds__(256) void k_fdl_mac_dcnyq(const double2* __restrict__ XDN,
                                                        const double2* __restrict__ HDN,
                                                        const int* __restrict__ irSlot, double2* __restrict__ Y,
-                                                       int nCh, int K, int ringMask, int head, int T, int hdnStride)
+                                                       int nCh, int K, int ringMask, int head, int T, int hdnStride, int P)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nCh * T) return;
@@ -189,36 +190,38 @@ __global__ __launch_bounds__(256) void k_fdl_mac_dcnyq(const double2* __restrict
         dc = fma(xv.x, hv.x, dc);
         ny = fma(xv.y, hv.y, ny);
     }
-    Y[(int64_t)idx * kP] = make_double2(dc, ny);
+    Y[(int64_t)idx * P] = make_double2(dc, ny);
 }
 
 template <int TT, int PF>
-void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const int* irSlot, double2* Y, int nCh,
-                  int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
+void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const int* irSlot, double2* Y, int P,
+                  int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
 {
-    const int nPairs = nCh * 2;
+    const int threads = P < 256 ? P : 256;
+    int segShift = 0;
+    while ((threads << segShift) < P) ++segShift;
+    const int nPairs = nCh << segShift;
     const int nTiles = (T + TT - 1) / TT;
     const int groups = (nPairs + 7) / 8;
     const int grid = groups * nTiles * 8;
-    hipLaunchKernelGGL((k_fdl_mac<TT, PF>), dim3(grid), dim3(256), 0, stream, X, H, irSlot, Y, nPairs, kPad,
-                       ringSlots - 1, head, T, nTiles, hSlotStride);
+    hipLaunchKernelGGL((k_fdl_mac<TT, PF>), dim3(grid), dim3(threads), 0, stream, X, H, irSlot, Y, nPairs, kPad,
+                       ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift);
 }
 
 }  // namespace
 
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot, double2* Y,
-                    int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
+                    int P, int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
 {
     if (tile == 0 && T >= 32) {      // default for long calls: workgroup-cooperative kernel
         const int nGroups = (T + kWgWaves * kWgTile - 1) / (kWgWaves * kWgTile);
-        hipLaunchKernelGGL((k_fdl_mac_wg<4>), dim3(nCh * 8 * nGroups), dim3(64 * kWgWaves), 0, stream, X, H, irSlot, Y,
-                           kPad, ringSlots - 1, head, T, nGroups, hSlotStride);
+        const int nCols = P / 64;
+        hipLaunchKernelGGL((k_fdl_mac_wg<4>), dim3(nCh * nCols * nGroups), dim3(64 * kWgWaves), 0, stream, X, H,
+                           irSlot, Y, kPad, ringSlots - 1, head, T, nGroups, hSlotStride, P, nCols);
         return;
     }
-    // DIAG: CPQ_MAC_PF selects the prefetch depth for tuning experiments
-    const char* pfEnv = getenv("CPQ_MAC_PF");
-    const int pf = pfEnv ? atoi(pfEnv) : 4;
-#define CPQ_MAC_CASE(TT_, PF_) launch_mac_t<TT_, PF_>(stream, X, H, irSlot, Y, nCh, kPad, ringSlots, head, T, hSlotStride)
+    const int pf = 4;     // prefetch depth in partition steps (deeper measured slower: register pressure)
+#define CPQ_MAC_CASE(TT_, PF_) launch_mac_t<TT_, PF_>(stream, X, H, irSlot, Y, P, nCh, kPad, ringSlots, head, T, hSlotStride)
     switch (tile) {
         case 4:  CPQ_MAC_CASE(4, 4); break;
         case 8:  if (pf >= 8) CPQ_MAC_CASE(8, 8); else CPQ_MAC_CASE(8, 4); break;
@@ -229,11 +232,11 @@ void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double
 }
 
 void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2* HDN, const int* irSlot, double2* Y,
-                          int nCh, int K, int ringSlots, int head, int T, int hdnStride)
+                          int P, int nCh, int K, int ringSlots, int head, int T, int hdnStride)
 {
     const int total = nCh * T;
     hipLaunchKernelGGL(k_fdl_mac_dcnyq, dim3((total + 255) / 256), dim3(256), 0, stream, XDN, HDN, irSlot, Y, nCh, K,
-                       ringSlots - 1, head, T, hdnStride);
+                       ringSlots - 1, head, T, hdnStride, P);
 }
 
 }  // namespace cpq

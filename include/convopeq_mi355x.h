@@ -114,7 +114,8 @@ typedef struct {
     int32_t device;                  /* HIP device ordinal */
     int32_t n_streams;               /* S stereo streams -> 2*S channels */
     int32_t block_size;              /* B: the caller's block / callQuantum; power of two, 64..2048;
-                                        partition size P == B (layer-0 partSize of the reference) */
+                                        partition size P == B (layer-0 partSize of the reference).  512 has
+                                        dedicated wave-level FFT kernels, other sizes use generic ones */
     int32_t max_ir_len;              /* longest IR (taps) any stream will be given */
     int32_t max_blocks_per_call;     /* T_max: a process call carries 1..T_max blocks of B samples
                                         (reference: up to 524288 samples per process(),

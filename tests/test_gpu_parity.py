@@ -298,5 +298,70 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     with pytest.raises(amd.CpqError):
         eng.set_eq_params(0, p)
     eng.close()
+    # blk 1024 + 131072 taps: the reference drops tail blocks (time-varying) -> refused in reference semantics
+    eng = amd.BatchedEngine(1, block_size=1024, max_ir_len=131072, max_blocks_per_call=2)
+    long_ir = O.gen_ir(131072)
+    with pytest.raises(amd.CpqError) as e3:
+        eng.set_impulse(0, long_ir, long_ir)
+    assert e3.value.status == -5
+    eng.close()
     with pytest.raises(amd.CpqError):
-        amd.BatchedEngine(1, block_size=1024, max_ir_len=131072)   # non-LTI / unsupported block size
+        amd.BatchedEngine(1, block_size=500, max_ir_len=4096)       # not a power of two
+
+
+@pytest.mark.parametrize("block,ir_len,blocks_per_call", [(64, 20000, 40), (128, 131072, 64), (256, 131072, 8),
+                                                           (256, 131072, 48), (1024, 5000, 4), (2048, 5760, 3)])
+def test_block_size_sweep_reference_semantics(amd, oracle, block, ir_len, blocks_per_call):
+    """BASELINE.json configs[2] block sizes (generic FFT kernels): reference semantics wherever the reference
+    itself is LTI (B <= 256 with long IRs: negative layer lags; B >= 1024 with IR inside layer 0)."""
+    O = oracle
+    S = 1
+    irs = [O.gen_ir(ir_len, stream=0, channel=ch) for ch in range(2)]
+    total_blocks = blocks_per_call * max(2, (ir_len // block + 200) // blocks_per_call + 1)
+    total_blocks = min(total_blocks, 6 * blocks_per_call if block >= 1024 else total_blocks)
+    x = make_inputs(O, S, total_blocks * block)
+    ref = oracle_conv(O, irs, x, block=block)
+    eng = amd.BatchedEngine(S, block_size=block, max_ir_len=ir_len, max_blocks_per_call=blocks_per_call)
+    eng.set_impulse(0, irs[0], irs[1])
+    assert eng.latency() == block
+    step = blocks_per_call * block
+    y = np.concatenate([eng.conv_process(x[:, o:o + step]) for o in range(0, x.shape[1], step)], axis=1)
+    err = rms(y - ref)
+    print(f"B={block} L={ir_len} T={blocks_per_call} rms err {err:.3e} signal rms {rms(ref):.3f}")
+    assert err <= 1e-13
+    eng.close()
+
+
+@pytest.mark.parametrize("block", [1024, 2048])
+def test_large_blocks_exact_semantics_long_ir(amd, oracle, block):
+    from scipy.signal import fftconvolve
+    O = oracle
+    ir = [O.gen_ir(131072, channel=ch) for ch in range(2)]
+    T = 4
+    x = make_inputs(O, 1, 40 * T * block // (block // 512))
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=131072, max_blocks_per_call=T, semantics=amd.CPQ_SEM_EXACT)
+    eng.set_impulse(0, ir[0], ir[1])
+    step = T * block
+    n = (x.shape[1] // step) * step
+    y = np.concatenate([eng.conv_process(x[:, o:o + step]) for o in range(0, n, step)], axis=1)
+    for c in range(2):
+        assert rms(y[c] - fftconvolve(x[c, :n], ir[c])[:n]) <= 1e-13
+    eng.close()
+
+
+def test_eq_small_blocks_use_both_kernels(amd, oracle):
+    """blk 128, 7 blocks per call = 896 samples: 512 through the time-parallel kernel, 384 through the sequential."""
+    O = oracle
+    S, blk, T = 2, 128, 7
+    x = make_inputs(O, S, 3 * T * blk)
+    po = O.eq_params_bench(0.2)
+    eng = amd.BatchedEngine(S, block_size=blk, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.profile_enable(True)
+    y = np.concatenate([eng.eq_process(x[:, o:o + T * blk]) for o in range(0, x.shape[1], T * blk)], axis=1)
+    prof = eng.profile_read()
+    assert prof["k_svf_cascade_tp"][0] == 3 and prof["k_svf_cascade"][0] == 3
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po, block=blk)
+        assert max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max()) <= 1e-13
+    eng.close()
