@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--shared-ir", action="store_true")
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -154,19 +155,23 @@ def main():
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # (== local_rank on a full node)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     S, T, L = args.streams, args.blocks_per_call, args.ir_len
     n = T * B
     use_eq = not args.no_eq
     eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T,
                             semantics=amd.CPQ_SEM_EXACT if args.exact else amd.CPQ_SEM_REFERENCE,
-                            device=local_rank, mac_tile=args.mac_tile)
+                            device=dev_index, mac_tile=args.mac_tile)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
 
@@ -219,8 +224,9 @@ def main():
 
     samples = float(S) * n * args.steps          # stereo samples this rank processed
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        ss = torch.tensor([samples], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        ss = torch.tensor([samples], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ss, op=dist.ReduceOp.SUM)
         elapsed, samples = tt.item(), ss.item()

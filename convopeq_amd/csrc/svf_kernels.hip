@@ -221,65 +221,64 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
     }
 }
 
-template <int LC, bool MONO, bool SAT>
-__device__ __forceinline__ void tp_band(double* buf, double* wtot, int tid, const double* __restrict__ cf,
-                                        const TpLcTables* __restrict__ tb, double sat, double* sState)
+// zero-state (or continuing) recurrence of one band over N samples held in registers: v[j] <- y_lin[j]
+template <bool MONO, int N>
+__device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic2, double a1, double a2, double a3,
+                                         double m0, double m1, double m2)
 {
-    constexpr int U = (LC < 8) ? LC : 8;
-    const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
-    const double oneMinusSat = 1.0 - sat;
-    const int lane = tid & 63, wave = tid >> 6;
-    double* row = buf + tid * kTpStride;
-
-    // ---- 1. zero-state run of this thread's chunk (reference operation order)
-    double ic1 = 0.0, ic2 = 0.0;
-#pragma unroll 1
-    for (int i0 = 0; i0 < LC; i0 += U) {
-        double v[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const double v0 = v[j];
-            const double v3 = v0 - ic2;
-            if (MONO) {
-                const double v1 = a1 * ic1 + a2 * v3;
-                const double v2 = ic2 + a2 * ic1 + a3 * v3;
-                ic1 = 2.0 * v1 - ic1;
-                ic2 = 2.0 * v2 - ic2;
-                v[j] = m0 * v0 + m1 * v1 + m2 * v2;
-            } else {
-                const double v1 = fma(a1, ic1, a2 * v3);
-                const double v2 = fma(a2, ic1, fma(a3, v3, ic2));
-                ic1 = fma(2.0, v1, -ic1);
-                ic2 = fma(2.0, v2, -ic2);
-                v[j] = fma(m0, v0, fma(m1, v1, m2 * v2));
-            }
+    for (int j = 0; j < N; ++j) {
+        const double v0 = v[j];
+        const double v3 = v0 - ic2;
+        if (MONO) {
+            const double v1 = a1 * ic1 + a2 * v3;
+            const double v2 = ic2 + a2 * ic1 + a3 * v3;
+            ic1 = 2.0 * v1 - ic1;
+            ic2 = 2.0 * v2 - ic2;
+            v[j] = m0 * v0 + m1 * v1 + m2 * v2;
+        } else {
+            const double v1 = fma(a1, ic1, a2 * v3);
+            const double v2 = fma(a2, ic1, fma(a3, v3, ic2));
+            ic1 = fma(2.0, v1, -ic1);
+            ic2 = fma(2.0, v2, -ic2);
+            v[j] = fma(m0, v0, fma(m1, v1, m2 * v2));
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
     }
+}
 
-    // ---- 2. chunk start states.  In-wave inclusive scan of S_c = M S_(c-1) + e_c (zero incoming state) ...
+// per-workgroup LDS copy of the channel's per-band constants (one chunk length at a time)
+struct TpLds {
+    double cf[kBands][6];        // a1 a2 a3 m0 m1 m2
+    double M[kBands][28];        // Mk[6][4], Mw[4]
+    double G[kBands][32];        // G[16][2]
+};
+
+// chunk start states of band b from the chunk end states (ic1, ic2) of the zero-state runs
+__device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const TpLds* L, int b,
+                                        const double* __restrict__ Pglob, double* wtot, double* sState, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    // this lane's power A^(LC (lane+1)): issued now, consumed after the in-wave scan
+    const double p0 = Pglob[lane * 4 + 0], p1 = Pglob[lane * 4 + 1], p2 = Pglob[lane * 4 + 2], p3 = Pglob[lane * 4 + 3];
     double sx = ic1, sy = ic2;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const double* Mk = tb->Mk[k];
+        const double k0 = L->M[b][k * 4 + 0], k1 = L->M[b][k * 4 + 1], k2 = L->M[b][k * 4 + 2], k3 = L->M[b][k * 4 + 3];
         const double px = __shfl_up(sx, 1 << k);
         const double py = __shfl_up(sy, 1 << k);
         if (lane >= (1 << k)) {
-            const double nx = fma(Mk[1], py, fma(Mk[0], px, sx));
-            const double ny = fma(Mk[3], py, fma(Mk[2], px, sy));
+            const double nx = fma(k1, py, fma(k0, px, sx));
+            const double ny = fma(k3, py, fma(k2, px, sy));
             sx = nx;
             sy = ny;
         }
     }
     if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
     __syncthreads();
-    // ... state at the start of this wave's segment: chain the totals of the preceding waves
-    double bx = sState[0], by = sState[1];
-    const double mw0 = tb->Mw[0], mw1 = tb->Mw[1], mw2 = tb->Mw[2], mw3 = tb->Mw[3];
-    double endx = bx, endy = by;             // becomes the state after the whole span
+    // state at the start of this wave's segment: chain the totals of the preceding waves
+    double bx = sState[2 * b], by = sState[2 * b + 1];
+    const double mw0 = L->M[b][24], mw1 = L->M[b][25], mw2 = L->M[b][26], mw3 = L->M[b][27];
+    double endx = bx, endy = by;
 #pragma unroll
     for (int w = 0; w < kTpWaves; ++w) {
         const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
@@ -288,58 +287,27 @@ __device__ __forceinline__ void tp_band(double* buf, double* wtot, int tid, cons
         endx = nx; endy = ny;
         if (w + 1 == wave) { bx = endx; by = endy; }
     }
-    // ... fold the wave's start state into every chunk end state, then shift to chunk START states
-    {
-        const double* Pc = tb->P[lane];
-        sx = fma(Pc[1], by, fma(Pc[0], bx, sx));
-        sy = fma(Pc[3], by, fma(Pc[2], bx, sy));
-    }
-    double s0x = __shfl_up(sx, 1), s0y = __shfl_up(sy, 1);
+    sx = fma(p1, by, fma(p0, bx, sx));
+    sy = fma(p3, by, fma(p2, bx, sy));
+    s0x = __shfl_up(sx, 1);
+    s0y = __shfl_up(sy, 1);
     if (lane == 0) { s0x = bx; s0y = by; }
-    __syncthreads();                          // all threads have read sState / wtot
-    if (tid == 0) { sState[0] = endx; sState[1] = endy; }
-
-    // ---- 3. add the state response, then the output nonlinearity of the reference
-#pragma unroll 1
-    for (int i0 = 0; i0 < LC; i0 += U) {
-        double v[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
-#pragma unroll
-        for (int j = 0; j < U; ++j) v[j] = fma(tb->G[i0 + j][1], s0y, fma(tb->G[i0 + j][0], s0x, v[j]));
-        tp_nonlinear<MONO, SAT, U>(v, sat, oneMinusSat);
-#pragma unroll
-        for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
-    }
-    __syncthreads();
+    __syncthreads();                          // every thread has read sState[b] and wtot
+    if (tid == 0) { sState[2 * b] = endx; sState[2 * b + 1] = endy; }
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
 // with every guard, used when the span input or the carried state is outside the proven-safe range.
 template <bool MONO>
-__device__ void tp_band_guarded(double* buf, int lc, const double* __restrict__ cf, double sat, double* sState)
+__device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sat, double* sState)
 {
     const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
     const double oneMinusSat = 1.0 - sat;
     double ic1 = sState[0], ic2 = sState[1];
     for (int c = 0; c < kTpChunks; ++c)
         for (int i = 0; i < lc; ++i) {
-            const double v0 = buf[c * kTpStride + i];
-            const double v3 = v0 - ic2;
-            double y[1];
-            if (MONO) {
-                const double v1 = a1 * ic1 + a2 * v3;
-                const double v2 = ic2 + a2 * ic1 + a3 * v3;
-                ic1 = 2.0 * v1 - ic1;
-                ic2 = 2.0 * v2 - ic2;
-                y[0] = m0 * v0 + m1 * v1 + m2 * v2;
-            } else {
-                const double v1 = fma(a1, ic1, a2 * v3);
-                const double v2 = fma(a2, ic1, fma(a3, v3, ic2));
-                ic1 = fma(2.0, v1, -ic1);
-                ic2 = fma(2.0, v2, -ic2);
-                y[0] = fma(m0, v0, fma(m1, v1, m2 * v2));
-            }
+            double y[1] = { buf[c * kTpStride + i] };
+            tp_recur<MONO, 1>(y, ic1, ic2, a1, a2, a3, m0, m1, m2);
             if (sat > 0.0) tp_nonlinear<MONO, true, 1>(y, sat, oneMinusSat);
             else           tp_nonlinear<MONO, false, 1>(y, sat, oneMinusSat);
             buf[c * kTpStride + i] = y[0];
@@ -350,13 +318,18 @@ __device__ void tp_band_guarded(double* buf, int lc, const double* __restrict__ 
     sState[1] = ic2;
 }
 
-template <int LC>
+// One span (kTpChunks chunks of LC samples) through all active bands.  Every thread owns one chunk = one LDS
+// row, so between bands no barrier is needed for the sample data; per band the only exchange is the 4 wave
+// totals of the state scan.  The output stage of band b and the zero-state run of the next active band are
+// fused over the same registers (the next band consumes what the output stage just produced).
+template <int LC, bool SAT>
 __device__ __forceinline__ void tp_span(const double* in, double* out, double* buf, double* wtot, double* sState,
-                                        int* sFlag, int tid, const double* __restrict__ cf,
-                                        const int* __restrict__ fl, const TpBandTables* __restrict__ tb, double sat,
-                                        double gain)
+                                        int* sFlag, const TpLds* L, int tid, const int* __restrict__ fl,
+                                        const TpBandTables* __restrict__ tb, double sat, double gain)
 {
     constexpr int LCI = (LC == kTpLcMain) ? 0 : 1;
+    constexpr int U = (LC < 8) ? LC : 8;
+    const double oneMinusSat = 1.0 - sat;
     // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
     bool bad = false;
 #pragma unroll 4
@@ -373,32 +346,91 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
     __syncthreads();
     const bool unsafe = (*sFlag != 0);
 
-    for (int b = 0; b < kBands; ++b) {
-        const int flag = fl[b];                      // uniform
-        if (!(flag & 1)) continue;
-        const bool mono = (flag & 2) != 0;
-        const TpLcTables* t = &tb[b].t[LCI];
-        if (!unsafe) {
-            if (mono) {
-                if (sat > 0.0) tp_band<LC, true, true>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
-                else           tp_band<LC, true, false>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
-            } else {
-                if (sat > 0.0) tp_band<LC, false, true>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
-                else           tp_band<LC, false, false>(buf, wtot, tid, cf + b * 6, t, sat, sState + 2 * b);
-            }
-        } else {
+    if (unsafe) {
+        for (int b = 0; b < kBands; ++b) {
+            const int flag = fl[b];
+            if (!(flag & 1)) continue;
             if (tid == 0) {
-                if (mono) tp_band_guarded<true>(buf, LC, cf + b * 6, sat, sState + 2 * b);
-                else      tp_band_guarded<false>(buf, LC, cf + b * 6, sat, sState + 2 * b);
+                if (flag & 2) tp_band_guarded<true>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                else          tp_band_guarded<false>(buf, LC, L->cf[b], sat, sState + 2 * b);
             }
             __syncthreads();
         }
+    } else {
+        double* row = buf + tid * kTpStride;
+        int b = 0;
+        while (b < kBands && !(fl[b] & 1)) ++b;              // first active band (uniform)
+        if (b < kBands) {
+            // zero-state run of the first active band on the raw input
+            double ic1 = 0.0, ic2 = 0.0;
+            {
+                const double a1 = L->cf[b][0], a2 = L->cf[b][1], a3 = L->cf[b][2];
+                const double m0 = L->cf[b][3], m1 = L->cf[b][4], m2 = L->cf[b][5];
+                const bool mono = (fl[b] & 2) != 0;
+#pragma unroll 1
+                for (int i0 = 0; i0 < LC; i0 += U) {
+                    double v[U];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
+                    if (mono) tp_recur<true, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                    else      tp_recur<false, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+#pragma unroll
+                    for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
+                }
+            }
+            while (b < kBands) {
+                int nb = b + 1;
+                while (nb < kBands && !(fl[nb] & 1)) ++nb;     // next active band (uniform)
+                double s0x, s0y;
+                tp_scan(ic1, ic2, s0x, s0y, L, b, &tb[b].t[LCI].P[0][0], wtot, sState, tid);
+                const bool monoB = (fl[b] & 2) != 0;
+                const bool hasNext = nb < kBands;
+                const bool monoN = hasNext && (fl[nb] & 2) != 0;
+                double a1 = 0, a2 = 0, a3 = 0, m0 = 1, m1 = 0, m2 = 0;
+                if (hasNext) {
+                    a1 = L->cf[nb][0]; a2 = L->cf[nb][1]; a3 = L->cf[nb][2];
+                    m0 = L->cf[nb][3]; m1 = L->cf[nb][4]; m2 = L->cf[nb][5];
+                }
+                ic1 = 0.0; ic2 = 0.0;
+#pragma unroll 1
+                for (int i0 = 0; i0 < LC; i0 += U) {
+                    double v[U];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
+#pragma unroll
+                    for (int j = 0; j < U; ++j)
+                        v[j] = fma(L->G[b][2 * (i0 + j) + 1], s0y, fma(L->G[b][2 * (i0 + j)], s0x, v[j]));
+                    if (monoB) tp_nonlinear<true, SAT, U>(v, sat, oneMinusSat);
+                    else       tp_nonlinear<false, SAT, U>(v, sat, oneMinusSat);
+                    if (hasNext) {
+                        if (monoN) tp_recur<true, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                        else       tp_recur<false, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
+                }
+                b = nb;
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll 4
     for (int it = 0; it < LC; ++it) {
         const int j = it * kTpChunks + tid;
         out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
     }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void tp_load_tables(TpLds* L, const double* __restrict__ cf,
+                                               const TpBandTables* __restrict__ tb, int lci, int tid)
+{
+    for (int i = tid; i < kBands * 6; i += kTpChunks) L->cf[i / 6][i % 6] = cf[i];
+    for (int i = tid; i < kBands * 28; i += kTpChunks) {
+        const int b = i / 28, q = i % 28;
+        L->M[b][q] = (q < 24) ? tb[b].t[lci].Mk[q / 4][q % 4] : tb[b].t[lci].Mw[q - 24];
+    }
+    for (int i = tid; i < kBands * 32; i += kTpChunks) L->G[i / 32][i % 32] = tb[i / 32].t[lci].G[(i % 32) / 2][i % 2];
     __syncthreads();
 }
 
@@ -410,6 +442,7 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
                                                               const TpBandTables* __restrict__ tables)
 {
     __shared__ double buf[kTpChunks * kTpStride];
+    __shared__ TpLds L;
     __shared__ double sState[kBands * 2];
     __shared__ double wtot[2 * kTpWaves];
     __shared__ int sFlag;
@@ -420,19 +453,28 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;     // tables are per stream
     const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
     if (tid < kBands * 2) sState[tid] = state[(int64_t)c * kBands * 2 + tid];
-    __syncthreads();
 
     const double* src = in + (int64_t)c * chStride;
     double* dst = out + (int64_t)c * chStride;
     int done = 0;
-    while (nSamples - done >= kTpChunks * kTpLcMain) {
-        tp_span<kTpLcMain>(src + done, dst + done, buf, wtot, sState, &sFlag, tid, cf, fl, tb, sat, gain);
-        done += kTpChunks * kTpLcMain;
+    if (nSamples >= kTpChunks * kTpLcMain) {
+        tp_load_tables(&L, cf, tb, 0, tid);
+        while (nSamples - done >= kTpChunks * kTpLcMain) {
+            if (sat > 0.0) tp_span<kTpLcMain, true>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
+            else           tp_span<kTpLcMain, false>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
+            done += kTpChunks * kTpLcMain;
+        }
     }
-    while (nSamples - done >= kTpChunks * kTpLcTail) {       // remaining whole 512-sample blocks
-        tp_span<kTpLcTail>(src + done, dst + done, buf, wtot, sState, &sFlag, tid, cf, fl, tb, sat, gain);
-        done += kTpChunks * kTpLcTail;
+    if (nSamples - done >= kTpChunks * kTpLcTail) {            // remaining whole 512-sample blocks
+        __syncthreads();
+        tp_load_tables(&L, cf, tb, 1, tid);
+        while (nSamples - done >= kTpChunks * kTpLcTail) {
+            if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
+            else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
+            done += kTpChunks * kTpLcTail;
+        }
     }
+    __syncthreads();
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
