@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=256, help="stereo streams per GPU")
     ap.add_argument("--ir-len", type=int, default=131072)
+    ap.add_argument("--block", type=int, default=512, help="diagnostic: block size")
+    ap.add_argument("--partition", type=int, default=0, help="internal FFT partition size (0 = block size)")
     ap.add_argument("--blocks-per-call", type=int, default=64)
     ap.add_argument("--mac-tile", type=int, default=0)
     ap.add_argument("--no-eq", action="store_true")
@@ -166,12 +168,14 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    global B
+    B = args.block
     S, T, L = args.streams, args.blocks_per_call, args.ir_len
     n = T * B
     use_eq = not args.no_eq
     eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T,
                             semantics=amd.CPQ_SEM_EXACT if args.exact else amd.CPQ_SEM_REFERENCE,
-                            device=dev_index, mac_tile=args.mac_tile)
+                            device=dev_index, mac_tile=args.mac_tile, partition_size=args.partition)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
 
@@ -192,7 +196,10 @@ def main():
     d_in = torch.from_numpy(host).cuda()
     d_out = torch.empty_like(d_in)
     plan = eng.plan()
-    k_parts = (plan.heff_len + B - 1) // B if not args.exact else (L + B - 1) // B
+    P = args.partition if args.partition else B          # internal FFT partition size
+    Tp = n // P                                          # partitions per call
+    taps = L if args.exact else plan.heff_len
+    k_parts = (taps + P - 1) // P
     setup_s = time.perf_counter() - t_setup
 
     def step():
@@ -233,15 +240,31 @@ def main():
 
     if rank == 0:
         n_ch = 2 * S
-        mac_n, mac_ms = prof["k_fdl_mac"]
-        mac_avg_s = (mac_ms / max(mac_n, 1)) * 1e-3
-        # algorithmic HBM bytes of one k_fdl_mac launch under the T-block time-batched uniform schedule
-        # (DESIGN.md section 4): every FDL row the call needs is read once, every IR row once, every output row written once
-        spec_bytes = B * 16
+        # algorithmic HBM bytes per launch: every row / sample a kernel needs is moved once
+        spec_bytes = P * 16
         ir_rows = (2 if args.shared_ir else n_ch) * k_parts
-        mac_bytes = (n_ch * (k_parts + T - 1) + ir_rows + n_ch * T) * spec_bytes
-        mac_flops = 8.0 * n_ch * T * k_parts * B
-        achieved = mac_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
+        alg_bytes = {
+            "k_rfft_fwd_ols": n_ch * Tp * (P * 8 + spec_bytes),
+            "k_fdl_mac": (n_ch * (k_parts + Tp - 1) + ir_rows + n_ch * Tp) * spec_bytes,
+            "k_fdl_mac_dcnyq": n_ch * (k_parts + Tp - 1 + Tp) * 16 + ir_rows * 16,
+            "k_rfft_inv_ols": n_ch * Tp * (spec_bytes + P * 8),
+            "k_svf_cascade_tp": n_ch * n * 16,
+            "k_svf_cascade": n_ch * n * 16,
+        }
+        # fp64 operations per launch (FMA = 2): MAC 8 per complex MAC; SVF ~35 fp64 instructions per band-sample
+        alg_flops = {"k_fdl_mac": 8.0 * n_ch * Tp * k_parts * P, "k_svf_cascade_tp": 2.0 * 35 * 20 * n_ch * n}
+        per_kernel = {}
+        for name, (cnt, ms) in prof.items():
+            if cnt == 0:
+                continue
+            avg_s = ms / cnt * 1e-3
+            per_kernel[name] = {"launches": cnt, "avg_launch_ms": round(avg_s * 1e3, 4),
+                                "algorithmic_bytes_per_launch": alg_bytes[name],
+                                "achieved_gbs": round(alg_bytes[name] / avg_s / 1e9, 1)}
+            if name in alg_flops:
+                per_kernel[name]["fp64_tflops"] = round(alg_flops[name] / avg_s / 1e12, 2)
+        dominant = max(per_kernel, key=lambda k: per_kernel[k]["avg_launch_ms"] * per_kernel[k]["launches"])
+        dk = per_kernel[dominant]
         out = {
             "metric": "Mega stereo-samples/s convolved (131072-tap IR, blk=512)",
             "value": round(samples / elapsed / 1e6, 3),
@@ -261,20 +284,25 @@ def main():
                             f"fp64 overlap-save conv{' + 20-band SVF EQ (sat %.1f)' % args.saturation if use_eq else ''}"
                             f" [BASELINE.json configs[1]{'' if (S == 256 and L == 131072) else ' (modified)'}]",
                 "streams_per_gpu": S, "ir_taps": L, "block": B, "blocks_per_call": T,
-                "schedule": f"uniform P=512, K={k_parts} partitions of "
-                            f"{'h' if args.exact else 'h_eff (reference NUC semantics)'}, {T}-block time batching",
+                "schedule": f"uniform overlap-save, FFT partition P={P}, K={k_parts} partitions of "
+                            f"{'h' if args.exact else 'h_eff (reference NUC semantics at blk 512)'}, "
+                            f"{T} blocks ({n} samples) per call = {Tp} partitions per FDL pass",
+                "partition": P,
                 "eq": use_eq, "parallelism": f"streams sharded, {world} rank(s)",
                 "gb_per_s_of_samples": round(samples / elapsed * 16 / 1e9, 3),
             },
             "roofline": {
-                "kernel": "k_fdl_mac", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": load_pmc_traffic(args.pmc_json, "k_fdl_mac"),
-                "algorithmic_bytes_per_launch": mac_bytes, "avg_launch_ms": round(mac_avg_s * 1e3, 4),
-                "launches": mac_n,
-                "fp64_vector": {"achieved_tflops": round(mac_flops / mac_avg_s / 1e12, 3) if mac_avg_s > 0 else 0.0,
-                                "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+                "kernel": dominant, "bound": "hbm", "achieved": dk["achieved_gbs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(dk["achieved_gbs"] / HBM_PEAK_GBS, 4),
+                "traffic": load_pmc_traffic(args.pmc_json, dominant),
+                "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_launch"],
+                "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
+                "note": ("k_svf_cascade_tp is fp64-VALU issue bound, not HBM bound: 20 sequential nonlinear bands per "
+                         "sample (~35 fp64 instructions per band-sample) against 16 B of HBM traffic per sample"
+                         if dominant.startswith("k_svf") else "HBM stream of FDL and IR spectra"),
+                "fp64_vector": {"achieved_tflops": dk.get("fp64_tflops"), "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
             },
+            "kernels": per_kernel,
             "kernels_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof.items()},
             "setup_s": round(setup_s, 2),
         }

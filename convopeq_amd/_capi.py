@@ -68,7 +68,8 @@ class EqParams(C.Structure):
 class EngineDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_streams", C.c_int32),
                 ("block_size", C.c_int32), ("max_ir_len", C.c_int32), ("max_blocks_per_call", C.c_int32),
-                ("semantics", C.c_int32), ("mac_tile", C.c_int32), ("sample_rate", C.c_double)]
+                ("semantics", C.c_int32), ("mac_tile", C.c_int32), ("sample_rate", C.c_double),
+                ("partition_size", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/convopeq_mi355x.h declares: (restype, argtypes)

@@ -46,7 +46,8 @@ struct cpq_engine {
 
     // geometry
     int nCh = 0;          // 2 * streams
-    int P = 0;            // partition size == block size (samples) == complex bins per packed spectrum
+    int B = 0;            // caller's block size (the reference's blockSize: layer plan, latency)
+    int P = 0;            // internal partition size (samples) == complex bins per packed spectrum; multiple of B
     int kCap = 0;         // partition capacity per IR slot (multiple of kMacMaxTile)
     int hRows = 0;        // kCap + prefetch rows allocated per IR slot
     int ringSlots = 0;    // FDL ring slots per channel (power of two)
@@ -145,12 +146,13 @@ int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int*
 {
     if (!e) return CPQ_ERR_INVALID_ARG;
     if (!in || !out) return fail(e, CPQ_ERR_INVALID_ARG, "null buffer");
-    if (nSamples <= 0 || nSamples % e->desc.block_size != 0)
-        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d is not a positive multiple of block_size=%d", nSamples,
-                    e->desc.block_size);
-    const int t = nSamples / e->desc.block_size;
+    if (nSamples <= 0 || nSamples % e->P != 0)
+        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d is not a positive multiple of the partition size %d", nSamples,
+                    e->P);
+    const int t = nSamples / e->P;
     if (t > e->tMax)
-        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d exceeds max_blocks_per_call=%d blocks", nSamples, e->tMax);
+        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d exceeds max_blocks_per_call=%d blocks of %d", nSamples,
+                    e->desc.max_blocks_per_call, e->B);
     if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
         return fail(e, CPQ_ERR_INVALID_ARG, "buffers must be 16-byte aligned");
     *T = t;
@@ -319,8 +321,8 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "struct_size %d != %zu", d->struct_size, sizeof(cpq_engine_desc));
     if (d->n_streams <= 0 || d->max_ir_len <= 0 || d->max_blocks_per_call <= 0)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "n_streams, max_ir_len and max_blocks_per_call must be positive");
-    if (d->block_size < 64 || d->block_size > 2048 || (d->block_size & (d->block_size - 1)))
-        return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 2048]");
+    if (d->block_size < 64 || d->block_size > 4096 || (d->block_size & (d->block_size - 1)))
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 4096]");
     if (d->semantics != CPQ_SEM_REFERENCE && d->semantics != CPQ_SEM_EXACT)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "bad semantics");
     if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16 && d->mac_tile != 32)
@@ -345,8 +347,15 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->device = d->device;
     e->sampleRate = d->sample_rate > 0.0 ? d->sample_rate : 48000.0;
     e->nCh = 2 * d->n_streams;
-    e->P = d->block_size;
-    e->tMax = d->max_blocks_per_call;
+    e->B = d->block_size;
+    e->P = d->partition_size ? d->partition_size : d->block_size;
+    if (e->P < e->B || e->P > 4096 || (e->P & (e->P - 1)) || ((int64_t)d->max_blocks_per_call * e->B) % e->P != 0) {
+        const int p = e->P;
+        delete e;
+        return fail(nullptr, CPQ_ERR_INVALID_ARG,
+                    "partition_size %d must be a power of two in [block_size, 4096] dividing block_size*max_blocks_per_call", p);
+    }
+    e->tMax = (int)(((int64_t)d->max_blocks_per_call * e->B) / e->P);     // partitions per call
     e->macTile = d->mac_tile;     // 0 = automatic (workgroup-cooperative kernel for calls of >= 32 blocks)
 
     // partition capacity from the longest h_eff the plan can produce for max_ir_len
@@ -463,7 +472,7 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
 {
     if (!e) return CPQ_ERR_INVALID_ARG;
     if (sampleRate <= 0.0) return fail(e, CPQ_ERR_INVALID_ARG, "sample rate must be positive");
-    if (maxBlock <= 0 || maxBlock > e->desc.block_size * e->tMax)
+    if (maxBlock <= 0 || maxBlock > e->P * e->tMax)
         return fail(e, CPQ_ERR_INVALID_ARG, "max_block %d exceeds block_size*max_blocks_per_call", maxBlock);
     e->sampleRate = sampleRate;
     return zeroRuntimeState(e, true, true);

@@ -332,6 +332,156 @@ __global__ __launch_bounds__(256) void k_rfft_inv_ols_generic(const double2* __r
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// Large partitions (P = 1024, 2048, 4096): one workgroup of P/8 threads per transform, 8 points per thread,
+// mixed-radix Stockham (radix-8 stages, then one radix-4 or radix-2 stage when P is not a power of 8) through
+// ONE P-complex LDS buffer: every thread reads its 8 inputs, barrier, butterflies in registers, writes its 8
+// outputs, barrier.  Stage with radix R and Ns = product of earlier radices, butterfly j in [0, P/R):
+//   k = j mod Ns,  in[j + q P/R] * exp(-2 pi i q k / (R Ns))  ->  out[(j - k) R + k + q Ns].
+template <bool INV>
+__device__ __forceinline__ void wg_stage8(double2* lds, int M, int ns, const double2* __restrict__ twM)
+{
+    const int j = threadIdx.x;
+    const int stride = M >> 3;
+    const int k = j & (ns - 1);
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = lds[j + q * stride];
+    if (ns > 1) {
+        const int tstep = M / (8 * ns);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], twM[q * k * tstep]);
+    }
+    dft8<INV>(v);
+    __syncthreads();
+    const int o = ((j - k) << 3) + k;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds[o + q * ns] = v[q];
+    __syncthreads();
+}
+
+// final radix-R stage (R = 2 or 4) over all P points with P/8 threads: each thread does 8/R butterflies
+template <bool INV, int R>
+__device__ __forceinline__ void wg_stage_small(double2* lds, int M, int ns, const double2* __restrict__ twM)
+{
+    constexpr int NB = 8 / R;
+    const int stride = M / R;
+    const int tstep = M / (R * ns);
+    double2 v[NB][R];
+    int outBase[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = threadIdx.x + b * blockDim.x;
+        const int k = j & (ns - 1);
+        outBase[b] = (j - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            v[b][q] = lds[j + q * stride];
+            if (q > 0) v[b][q] = cmulw<INV>(v[b][q], twM[q * k * tstep]);
+        }
+        if (R == 4) dft4<INV>(v[b][0], v[b][1], v[b][2], v[b][3]);
+        else { const double2 a = v[b][0], c = v[b][1]; v[b][0] = cadd(a, c); v[b][1] = csub(a, c); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[outBase[b] + q * ns] = v[b][q];
+    __syncthreads();
+}
+
+template <bool INV>
+__device__ __forceinline__ void wg_cfft(double2* lds, int M, const double2* __restrict__ twM)
+{
+    int ns = 1;
+    while (ns * 8 <= M) { wg_stage8<INV>(lds, M, ns, twM); ns *= 8; }
+    if (ns * 4 == M) wg_stage_small<INV, 4>(lds, M, ns, twM);
+    else if (ns * 2 == M) wg_stage_small<INV, 2>(lds, M, ns, twM);
+}
+
+__global__ __launch_bounds__(512) void k_rfft_fwd_ols_wg(const double* __restrict__ in, int64_t chStride,
+                                                         const double* __restrict__ histOld,
+                                                         double* __restrict__ histNew, double2* __restrict__ X,
+                                                         double2* __restrict__ XDN, FftTables tw, int P, int T,
+                                                         int head, int ringMask)
+{
+    extern __shared__ double2 dyn[];
+    const int c = blockIdx.x / T;
+    const int t = blockIdx.x - c * T;
+    const double* cur = in + (int64_t)c * chStride + (int64_t)t * P;
+    const double* prev = (t > 0) ? (cur - P) : (histOld + (int64_t)c * P);
+    const int halfP = P >> 1;
+    for (int n = threadIdx.x; n < P; n += blockDim.x) {
+        const double* src = (n < halfP) ? (prev + 2 * n) : (cur + 2 * (n - halfP));
+        const double2 v = *reinterpret_cast<const double2*>(src);
+        dyn[n] = v;
+        if (t == T - 1 && n >= halfP) *reinterpret_cast<double2*>(histNew + (int64_t)c * P + 2 * (n - halfP)) = v;
+    }
+    __syncthreads();
+    wg_cfft<false>(dyn, P, tw.tw512);
+    const int slot = (head + t) & ringMask;
+    const int64_t row = (int64_t)c * (ringMask + 1) + slot;
+    split_store_generic(dyn, P, tw.tw1024, X + row * P, XDN + row);
+}
+
+__global__ __launch_bounds__(512) void k_ir_spectra_wg(const double* __restrict__ heff, int heffLen,
+                                                       double2* __restrict__ H, double2* __restrict__ HDN,
+                                                       FftTables tw, int P)
+{
+    extern __shared__ double2 dyn[];
+    const int k = blockIdx.x;
+    const int halfP = P >> 1;
+    for (int n = threadIdx.x; n < P; n += blockDim.x) {
+        double2 v = make_double2(0.0, 0.0);
+        if (n < halfP) {
+            const int i = k * P + 2 * n;
+            v = make_double2(i < heffLen ? heff[i] : 0.0, (i + 1) < heffLen ? heff[i + 1] : 0.0);
+        }
+        dyn[n] = v;
+    }
+    __syncthreads();
+    wg_cfft<false>(dyn, P, tw.tw512);
+    split_store_generic(dyn, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
+}
+
+__global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restrict__ Y, double* __restrict__ out,
+                                                         int64_t chStride, FftTables tw, int P, int T)
+{
+    extern __shared__ double2 dyn[];
+    const int c = blockIdx.x / T;
+    const int t = blockIdx.x - c * T;
+    const double2* y = Y + (int64_t)blockIdx.x * P;
+    const double2 y0 = y[0];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        const double2 yk = y[k];
+        const double2 ym = y[(P - k) & (P - 1)];
+        const double2 e = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y - ym.y));
+        const double2 d = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y + ym.y));
+        const double2 w = tw.tw1024[k];
+        const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
+        double2 z = make_double2(e.x - o.y, e.y + o.x);
+        if (k == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
+        dyn[k] = z;
+    }
+    __syncthreads();
+    wg_cfft<true>(dyn, P, tw.tw512);
+    double* o = out + (int64_t)c * chStride + (int64_t)t * P;
+    const double s = 1.0 / (double)P;
+    const int halfP = P >> 1;
+    for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)
+        *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(dyn[n].x * s, dyn[n].y * s);
+}
+
+template <typename K>
+void allowLargeLds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
 static int genericThreads(int P) { return P / 2 < 64 ? 64 : (P / 2 > 256 ? 256 : P / 2); }
 
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
@@ -341,7 +491,11 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
                            tw, T, head, ringSlots - 1);
-    else
+    else if (P >= 1024) {
+        allowLargeLds(k_rfft_fwd_ols_wg, P * sizeof(double2));
+        hipLaunchKernelGGL(k_rfft_fwd_ols_wg, dim3(nCh * T), dim3(P / 8), P * sizeof(double2), stream, in, chStride,
+                           histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
+    } else
         hipLaunchKernelGGL(k_rfft_fwd_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
                            stream, in, chStride, histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
 }
@@ -351,7 +505,11 @@ void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, doub
 {
     if (P == kP)
         hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
-    else
+    else if (P >= 1024) {
+        allowLargeLds(k_ir_spectra_wg, P * sizeof(double2));
+        hipLaunchKernelGGL(k_ir_spectra_wg, dim3(nParts), dim3(P / 8), P * sizeof(double2), stream, heff, heffLen, H, HDN,
+                           tw, P);
+    } else
         hipLaunchKernelGGL(k_ir_spectra_generic, dim3(nParts), dim3(genericThreads(P)), 2 * P * sizeof(double2), stream,
                            heff, heffLen, H, HDN, tw, P);
 }
@@ -361,7 +519,11 @@ void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int6
 {
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
-    else
+    else if (P >= 1024) {
+        allowLargeLds(k_rfft_inv_ols_wg, P * sizeof(double2));
+        hipLaunchKernelGGL(k_rfft_inv_ols_wg, dim3(nCh * T), dim3(P / 8), P * sizeof(double2), stream, Y, out, chStride,
+                           tw, P, T);
+    } else
         hipLaunchKernelGGL(k_rfft_inv_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
                            stream, Y, out, chStride, tw, P, T);
 }

@@ -113,7 +113,7 @@ typedef struct {
     int32_t struct_size;             /* sizeof(cpq_engine_desc) */
     int32_t device;                  /* HIP device ordinal */
     int32_t n_streams;               /* S stereo streams -> 2*S channels */
-    int32_t block_size;              /* B: the caller's block / callQuantum; power of two, 64..2048;
+    int32_t block_size;              /* B: the caller's block / callQuantum; power of two, 64..4096;
                                         partition size P == B (layer-0 partSize of the reference).  512 has
                                         dedicated wave-level FFT kernels, other sizes use generic ones */
     int32_t max_ir_len;              /* longest IR (taps) any stream will be given */
@@ -121,8 +121,15 @@ typedef struct {
                                         (reference: up to 524288 samples per process(),
                                         src/convolver/ConvolverProcessor.Runtime.cpp:609,667-682) */
     int32_t semantics;               /* cpq_semantics */
-    int32_t mac_tile;                /* 0 = default; else outputs per lane in the FDL MAC kernel (4/8/16) */
+    int32_t mac_tile;                /* 0 = default; else outputs per lane in the FDL MAC kernel (4/8/16/32) */
     double  sample_rate;
+    int32_t partition_size;          /* internal FFT partition P: 0 = block_size; else a power of two with
+                                        block_size <= P <= 4096.  The result is the same convolution (with the
+                                        h_eff the reference derives for block_size); larger P trades call
+                                        granularity for fewer partitions: every call must then carry a multiple
+                                        of P samples (offline / batched use).  The reference itself runs its tail
+                                        layers at 8x and 64x the block size (src/MKLNonUniformConvolver.cpp:738-740). */
+    int32_t reserved;
 } cpq_engine_desc;
 
 typedef struct cpq_engine cpq_engine;

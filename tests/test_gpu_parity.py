@@ -310,7 +310,7 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
 
 
 @pytest.mark.parametrize("block,ir_len,blocks_per_call", [(64, 20000, 40), (128, 131072, 64), (256, 131072, 8),
-                                                           (256, 131072, 48), (1024, 5000, 4), (2048, 5760, 3)])
+                                                           (256, 131072, 48), (1024, 5000, 4), (2048, 5760, 3), (4096, 5760, 2)])
 def test_block_size_sweep_reference_semantics(amd, oracle, block, ir_len, blocks_per_call):
     """BASELINE.json configs[2] block sizes (generic FFT kernels): reference semantics wherever the reference
     itself is LTI (B <= 256 with long IRs: negative layer lags; B >= 1024 with IR inside layer 0)."""
@@ -332,7 +332,7 @@ def test_block_size_sweep_reference_semantics(amd, oracle, block, ir_len, blocks
     eng.close()
 
 
-@pytest.mark.parametrize("block", [1024, 2048])
+@pytest.mark.parametrize("block", [1024, 2048, 4096])
 def test_large_blocks_exact_semantics_long_ir(amd, oracle, block):
     from scipy.signal import fftconvolve
     O = oracle

@@ -140,7 +140,7 @@ def test_invalid_arguments_are_rejected_without_gpu(amd):
     assert lib.cpq_nuc_plan_compute(100, 0, 0, None, C.byref(p)) == _capi.CPQ_ERR_INVALID_ARG
     assert lib.cpq_engine_create(None, None) == _capi.CPQ_ERR_INVALID_ARG
     h = _capi._E()
-    d = _capi.EngineDesc(C.sizeof(_capi.EngineDesc), 0, 1, 500, 4096, 1, 0, 0, 48000.0)   # block not a power of two
+    d = _capi.EngineDesc(C.sizeof(_capi.EngineDesc), 0, 1, 500, 4096, 1, 0, 0, 48000.0, 0, 0)   # block not a power of two
     assert lib.cpq_engine_create(C.byref(d), C.byref(h)) == _capi.CPQ_ERR_INVALID_ARG
     assert b"power of two" in lib.cpq_last_error(None)
     assert lib.cpq_status_string(-5) == b"not supported by this engine version"
