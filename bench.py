@@ -120,7 +120,11 @@ def load_pmc_traffic(path, kernel):
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(kernel, {}).get("hbm_bytes_per_launch")
+        if kernel in d:
+            return d[kernel].get("hbm_bytes_per_launch")
+        # kernel ids group template / variant names (k_fdl_mac covers k_fdl_mac_wg): take the variant that ran
+        cands = [v for k, v in d.items() if k.startswith(kernel) and isinstance(v, dict)]
+        return max((v.get("hbm_bytes_per_launch") for v in cands), default=None)
     except Exception:
         return None
 
@@ -143,7 +147,7 @@ def main():
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
