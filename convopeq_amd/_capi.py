@@ -22,7 +22,9 @@ CPQ_SEM_EXACT = 1
 CPQ_ORDER_CONV_THEN_EQ = 0
 CPQ_ORDER_EQ_THEN_CONV = 1
 KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4,
-              "k_svf_cascade_tp": 5}
+              "k_svf_cascade_tp": 5, "k_convproc_mix": 6}
+CPQ_LEVEL_NUC = 0
+CPQ_LEVEL_PROCESSOR = 1
 CPQ_EQ_MODE_AUTO = 0
 CPQ_EQ_MODE_SEQUENTIAL = 1
 
@@ -65,6 +67,10 @@ class EqParams(C.Structure):
                 ("nonlinear_saturation", C.c_float), ("filter_structure", C.c_int32)]
 
 
+class ConvProcParams(C.Structure):
+    _fields_ = [("mix", C.c_float), ("bypassed", C.c_int32), ("ir_peak_latency", C.c_int32), ("reserved", C.c_int32)]
+
+
 class EngineDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_streams", C.c_int32),
                 ("block_size", C.c_int32), ("max_ir_len", C.c_int32), ("max_blocks_per_call", C.c_int32),
@@ -96,6 +102,11 @@ SYMBOLS = {
     "cpq_conv_is_ready": (C.c_int32, [_E]),
     "cpq_conv_latency": (C.c_int32, [_E]),
     "cpq_conv_get_plan": (C.c_int32, [_E, C.POINTER(NucPlan)]),
+    "cpq_convproc_set_params": (C.c_int32, [_E, C.c_int32, C.POINTER(ConvProcParams)]),
+    "cpq_convproc_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
+    "cpq_convproc_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_convproc_delay": (C.c_int32, [_E, C.c_int32]),
+    "cpq_engine_set_conv_level": (C.c_int32, [_E, C.c_int32]),
     "cpq_eq_set_params": (C.c_int32, [_E, C.c_int32, C.POINTER(EqParams)]),
     "cpq_eq_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_eq_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -93,6 +93,16 @@ struct cpq_engine {
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
 
+    // processor-level wrapper (N1)
+    int convLevel = CPQ_LEVEL_NUC;
+    std::vector<cpq_convproc_params> procParams;   // per stream
+    bool procBypassed = false, procDryOnly = false;
+    double* procGains = nullptr;    // [streams][2] device
+    int* procDelay = nullptr;       // [streams] device
+    double* dryHist[2] = { nullptr, nullptr };   // [nCh][dryHistCap] device, allocated on first use
+    int dryHistCap = 0, dryHistSel = 0;
+    double* dryCopy = nullptr;      // [nCh][tMax*P] copy of the input when processing in place
+
     // profiling
     bool profiling = false;
     ProfileSlot prof[CPQ_K_COUNT];
@@ -236,6 +246,8 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * e->P * sizeof(double), e->stream));
         e->head = 0;
         e->histSel = 0;
+        for (double* p : { e->dryHist[0], e->dryHist[1] })
+            if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, (size_t)e->nCh * e->dryHistCap * sizeof(double), e->stream));
     }
     if (eq) CPQ_HIP(e, hipMemsetAsync(e->svfState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
@@ -280,6 +292,7 @@ const char* cpq_kernel_name(int32_t id)
         case CPQ_K_RFFT_INV: return "k_rfft_inv_ols";
         case CPQ_K_SVF: return "k_svf_cascade";
         case CPQ_K_SVF_TP: return "k_svf_cascade_tp";
+        case CPQ_K_MIX: return "k_convproc_mix";
         default: return "?";
     }
 }
@@ -430,6 +443,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->irLoaded.assign(e->nCh, 0);
     e->irParts.assign(e->nCh, 0);
     e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
+    e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0 });
     if (hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice) != hipSuccess) {
         cpq_engine_destroy(e);
         return fail(nullptr, CPQ_ERR_DEVICE, "irSlot upload failed");
@@ -448,6 +462,9 @@ void cpq_engine_destroy(cpq_engine* e)
         for (auto& ev : s.freeList) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     }
     if (e->arena) (void)hipFree(e->arena);
+    for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy }) if (p) (void)hipFree(p);
+    if (e->procGains) (void)hipFree(e->procGains);
+    if (e->procDelay) (void)hipFree(e->procDelay);
     delete e;
 }
 
@@ -580,6 +597,150 @@ int32_t cpq_conv_process(cpq_engine* e, const double* in, double* out, int32_t n
     return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueConv(e, a, b, T); });
 }
 
+}  // extern "C"
+
+// ----------------------------------------------------------------- convolver, processor level (N1)
+namespace {
+
+// equalPowerSin, src/convolver/ConvolverProcessor.Runtime.cpp:26-31 (9th-order Taylor of sin(pi x / 2))
+double equalPowerSin(double x)
+{
+    const double t = x * (3.141592653589793238462643383279502884 * 0.5);
+    const double t2 = t * t;
+    return t * (1.0 + t2 * (-1.0 / 6.0 + t2 * (1.0 / 120.0 + t2 * (-1.0 / 5040.0 + t2 * (1.0 / 362880.0)))));
+}
+
+int procDelayOf(const cpq_engine* e, int s)
+{
+    // algorithmLatency = conv->latency (layer-0 partSize == block size; direct head unsupported),
+    // irPeakLatency clamped like :266-277 (MAX_BLOCK_SIZE 524288, MAX_IR_LATENCY 2^21)
+    const int alg = std::min(e->B, 524288);
+    const int peak = std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152);
+    return alg + peak;
+}
+
+int uploadProcParams(cpq_engine* e)
+{
+    const int S = e->desc.n_streams;
+    std::vector<double> g((size_t)S * 2);
+    std::vector<int> d(S);
+    int maxDelay = 0;
+    for (int s = 0; s < S; ++s) {
+        const double mix = (double)e->procParams[s].mix;                 // targetMixValue (float widened, :366)
+        g[2 * s] = equalPowerSin(mix) * 1.0;                             // * CONVOLUTION_HEADROOM_GAIN
+        g[2 * s + 1] = (mix < 0.999) ? equalPowerSin(1.0 - mix) : 0.0;   // needsDrySignal, :375, :676
+        d[s] = procDelayOf(e, s);
+        maxDelay = std::max(maxDelay, d[s]);
+    }
+    CPQ_HIP(e, hipSetDevice(e->device));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    if (!e->procGains) {
+        CPQ_HIP(e, hipMalloc((void**)&e->procGains, sizeof(double) * 2 * S));
+        CPQ_HIP(e, hipMalloc((void**)&e->procDelay, sizeof(int) * S));
+    }
+    if (maxDelay > e->dryHistCap) {        // (re)allocate the dry delay line, preserving nothing: state restarts
+        for (int i = 0; i < 2; ++i) { if (e->dryHist[i]) (void)hipFree(e->dryHist[i]); e->dryHist[i] = nullptr; }
+        const int cap = (int)alignUp(maxDelay, 512);
+        for (int i = 0; i < 2; ++i) {
+            if (hipMalloc((void**)&e->dryHist[i], sizeof(double) * (size_t)e->nCh * cap) != hipSuccess)
+                return fail(e, CPQ_ERR_OOM, "dry delay line of %d samples per channel could not be allocated", cap);
+            CPQ_HIP(e, hipMemset(e->dryHist[i], 0, sizeof(double) * (size_t)e->nCh * cap));
+        }
+        e->dryHistCap = cap;
+        e->dryHistSel = 0;
+    }
+    CPQ_HIP(e, hipMemcpy(e->procGains, g.data(), sizeof(double) * g.size(), hipMemcpyHostToDevice));
+    CPQ_HIP(e, hipMemcpy(e->procDelay, d.data(), sizeof(int) * d.size(), hipMemcpyHostToDevice));
+    return CPQ_OK;
+}
+
+int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
+{
+    if (!e->procGains) { const int rc = uploadProcParams(e); if (rc != CPQ_OK) return rc; }
+    const int n = T * e->P;
+    const bool skipConv = e->procBypassed || e->procDryOnly;
+    const double* dry = dIn;
+    if (dIn == dOut && !skipConv) {
+        // in place: the convolver overwrites the block, keep a copy for the dry path
+        if (!e->dryCopy)
+            CPQ_HIP(e, hipMalloc((void**)&e->dryCopy, sizeof(double) * (size_t)e->nCh * e->tMax * e->P));
+        CPQ_HIP(e, hipMemcpyAsync(e->dryCopy, dIn, sizeof(double) * (size_t)e->nCh * n, hipMemcpyDeviceToDevice, e->stream));
+        dry = e->dryCopy;
+    }
+    const double* wet = dOut;
+    if (!skipConv) {
+        const int rc = enqueueConv(e, dIn, dOut, T);
+        if (rc != CPQ_OK) return rc;
+    } else if (dIn == dOut) {
+        // delayed copy in place needs the un-overwritten input as well
+        if (!e->dryCopy)
+            CPQ_HIP(e, hipMalloc((void**)&e->dryCopy, sizeof(double) * (size_t)e->nCh * e->tMax * e->P));
+        CPQ_HIP(e, hipMemcpyAsync(e->dryCopy, dIn, sizeof(double) * (size_t)e->nCh * n, hipMemcpyDeviceToDevice, e->stream));
+        dry = e->dryCopy;
+    }
+    {
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_convproc_mix(e->stream, wet, dry, dOut, (int64_t)n, e->nCh, n, e->procGains, e->procDelay,
+                                 e->dryHist[e->dryHistSel], e->dryHist[e->dryHistSel ^ 1], e->dryHistCap,
+                                 skipConv ? 0 : 1);
+    }
+    CPQ_HIP(e, hipGetLastError());
+    e->dryHistSel ^= 1;
+    return CPQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t cpq_convproc_set_params(cpq_engine* e, int32_t stream, const cpq_convproc_params* p)
+{
+    if (!e || !p) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (!(p->mix >= 0.0f && p->mix <= 1.0f)) return fail(e, CPQ_ERR_INVALID_ARG, "mix must be in [0, 1]");
+    if (p->ir_peak_latency < 0) return fail(e, CPQ_ERR_INVALID_ARG, "ir_peak_latency must be >= 0");
+    const bool dryOnly = !((double)p->mix > 0.001);        // needsConvolution, :374
+    if (stream != CPQ_ALL_STREAMS && (p->bypassed || dryOnly || e->procBypassed || e->procDryOnly))
+        return fail(e, CPQ_ERR_UNSUPPORTED, "bypass / dry-only freeze the convolver state and must be set for CPQ_ALL_STREAMS");
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    for (int s = s0; s < s1; ++s) e->procParams[s] = *p;
+    if (stream == CPQ_ALL_STREAMS) { e->procBypassed = p->bypassed != 0; e->procDryOnly = dryOnly; }
+    return uploadProcParams(e);
+}
+
+int32_t cpq_convproc_delay(const cpq_engine* e, int32_t stream)
+{
+    if (!e || stream < 0 || stream >= e->desc.n_streams) return CPQ_ERR_INVALID_ARG;
+    return procDelayOf(e, stream);
+}
+
+int32_t cpq_engine_set_conv_level(cpq_engine* e, int32_t level)
+{
+    if (!e || (level != CPQ_LEVEL_NUC && level != CPQ_LEVEL_PROCESSOR)) return CPQ_ERR_INVALID_ARG;
+    e->convLevel = level;
+    return CPQ_OK;
+}
+
+int32_t cpq_convproc_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
+{
+    int T = 0;
+    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    if (rc != CPQ_OK) return rc;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    return enqueueConvProc(e, dIn, dOut, T);
+}
+
+int32_t cpq_convproc_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
+{
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueConvProc(e, a, b, T); });
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // ---------------------------------------------------------------------------------- EQ
 int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
 {
@@ -669,12 +830,15 @@ int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t nSa
 static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
 {
     int rc;
+    auto conv = [e](const double* x, double* y, int t) {
+        return e->convLevel == CPQ_LEVEL_PROCESSOR ? enqueueConvProc(e, x, y, t) : enqueueConv(e, x, y, t);
+    };
     if (e->order == CPQ_ORDER_CONV_THEN_EQ) {
-        rc = enqueueConv(e, a, b, T);
+        rc = conv(a, b, T);
         if (rc == CPQ_OK) rc = enqueueEq(e, b, b, T);
     } else {
         rc = enqueueEq(e, a, e->mid, T);
-        if (rc == CPQ_OK) rc = enqueueConv(e, e->mid, b, T);
+        if (rc == CPQ_OK) rc = conv(e->mid, b, T);
     }
     return rc;
 }

@@ -58,4 +58,11 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
                            int nSamples, const double* coef, const int* flags, const double* satGain,
                            double* state, const void* tables);
 
+// Processor-level dry/wet stage (ConvolverProcessor::process steady state): out = sanitize(wet) * wetG + dryDelayed * dryG,
+// dry read `delay[stream]` samples back in (history ++ input); then the history is advanced.
+// gains: [streams][2] = {wetG, dryG}; histOld/histNew: [nCh][histCap] ping-pong.
+void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dryIn, double* out, int64_t chStride,
+                         int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
+                         double* histNew, int histCap, int wetValid);
+
 }  // namespace cpq

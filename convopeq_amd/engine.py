@@ -111,6 +111,19 @@ class BatchedEngine:
     def set_eq_params(self, stream, params):
         self._ck(self._lib.cpq_eq_set_params(self._h, stream, C.byref(params)))
 
+    def set_convproc_params(self, stream, mix=1.0, bypassed=False, ir_peak_latency=0):
+        p = K.ConvProcParams(mix, int(bypassed), ir_peak_latency, 0)
+        self._ck(self._lib.cpq_convproc_set_params(self._h, stream, C.byref(p)))
+
+    def convproc_delay(self, stream):
+        return self._lib.cpq_convproc_delay(self._h, stream)
+
+    def set_conv_level(self, level):
+        self._ck(self._lib.cpq_engine_set_conv_level(self._h, level))
+
+    def convproc_process(self, x):
+        return self._host(self._lib.cpq_convproc_process, x)
+
     def set_eq_mode(self, mode):
         self._ck(self._lib.cpq_eq_set_mode(self._h, mode))
 

@@ -196,6 +196,34 @@ int32_t cpq_conv_is_ready(const cpq_engine* e);
 int32_t cpq_conv_latency(const cpq_engine* e);
 int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan);
 
+/* ------------------------------------------- convolver, processor level (N1) */
+/* Steady-state restatement of ConvolverProcessor::process(AudioBlock<double>&)
+ * (src/convolver/ConvolverProcessor.Runtime.cpp:209-810) around the kernel-level convolver:
+ *   dry signal through a delay line of (algorithmLatency + irPeakLatency) samples (:266-288, :549-567),
+ *   wet = convolver output with NaN / Inf / |x| >= 1e300 replaced by 0 (:50-60, :722),
+ *   out = wet * wetG + dry * dryG, wetG = equalPowerSin(mix) * CONVOLUTION_HEADROOM_GAIN (= 1.0),
+ *   dryG = mix < 0.999 ? equalPowerSin(1 - mix) : 0, equalPowerSin = the 9th-order Taylor form (:26-31),
+ *   so mix = 1 scales the wet signal by 1.0000035... (:373-375, :675-676, :611-657);
+ *   mix <= 0.001: dry only, the convolver is not run (:573-585); bypassed: pure delay, convolver not run (:123-186).
+ * Parameter changes apply immediately: the reference's mix smoothing ramp (:591-607) and latency crossfade
+ * (:393-547) are transition effects of a live stream and are not reproduced.
+ * mix / ir_peak_latency may differ per stream; bypassed and mix <= 0.001 must be set for CPQ_ALL_STREAMS. */
+typedef struct {
+    float   mix;                 /* 0..1, default 1 (src/ConvolverProcessor.h:950) */
+    int32_t bypassed;
+    int32_t ir_peak_latency;     /* StereoConvolver::irLatency (peak delay of the loaded IR), samples */
+    int32_t reserved;
+} cpq_convproc_params;
+int32_t cpq_convproc_set_params(cpq_engine* e, int32_t stream, const cpq_convproc_params* p);
+int32_t cpq_convproc_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);
+int32_t cpq_convproc_process_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+/* total dry-path delay in samples of one stream (algorithmLatency + irPeakLatency) */
+int32_t cpq_convproc_delay(const cpq_engine* e, int32_t stream);
+/* CPQ_LEVEL_NUC (default): cpq_engine_process_block uses the kernel-level convolver (primary parity surface);
+ * CPQ_LEVEL_PROCESSOR: it uses cpq_convproc_process, as DSPCore does with ConvolverProcessor::process. */
+typedef enum { CPQ_LEVEL_NUC = 0, CPQ_LEVEL_PROCESSOR = 1 } cpq_conv_level;
+int32_t cpq_engine_set_conv_level(cpq_engine* e, int32_t level);
+
 /* ----------------------------------------------------------------------- EQ */
 /* replaces EQProcessor::createCoeffCache(params, sr, maxBlock, gen) (src/eqprocessor/
  * EQProcessor.ProcessingCache.cpp:56-93) + the (EQParameters, EQCoeffCache*) arguments of process(). */
@@ -229,7 +257,8 @@ typedef enum {
     CPQ_K_RFFT_INV = 3,   /* k_rfft_inv_ols */
     CPQ_K_SVF      = 4,   /* k_svf_cascade (lane-skewed sequential recurrence) */
     CPQ_K_SVF_TP   = 5,   /* k_svf_cascade_tp (time-parallel, default) */
-    CPQ_K_COUNT    = 6
+    CPQ_K_MIX      = 6,   /* k_convproc_mix (processor-level dry/wet stage) */
+    CPQ_K_COUNT    = 7
 } cpq_kernel_id;
 int32_t     cpq_profile_enable(cpq_engine* e, int32_t on);
 int32_t     cpq_profile_reset(cpq_engine* e);

@@ -257,3 +257,29 @@ def eq_process_stereo(xl, xr, params, sr=48000.0, block=512, state=None):
         state = np.zeros(2 * 20 * 2, dtype=np.float64)
     lib().orc_eq_process_stereo(dp(yl), dp(yr), len(yl), block, C.byref(params), sr, dp(state))
     return yl, yr, state
+
+
+def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0):
+    """Steady-state restatement of ConvolverProcessor::process for ONE channel over the whole signal x
+    (src/convolver/ConvolverProcessor.Runtime.cpp:209-810): dry delay line of algorithmLatency + irPeakLatency,
+    wet sanitise (NaN / Inf / |x| >= 1e300 -> 0, :50-60), out = wet*wetG + dry*dryG with the Taylor
+    equalPowerSin (:26-31, :675-676); mix <= 0.001 -> delayed dry only, bypass -> delayed dry only (convolver not run)."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(x)
+    mixd = float(np.float32(mix))
+    delay = min(block, 524288) + min(max(0, ir_peak_latency), 2097152)
+    dry = np.zeros(n)
+    if delay < n:
+        dry[delay:] = x[:n - delay]
+    if bypassed or not (mixd > 0.001):
+        return dry
+    nuc = Nuc()
+    assert nuc.set_impulse(ir, block)
+    wet = nuc.run(x, block)
+    nuc.close()
+    bad = ~(np.abs(wet) < 1.0e300)
+    wet = np.where(bad, 0.0, wet)
+    wet_g = L.orc_equal_power_sin(mixd) * 1.0
+    dry_g = L.orc_equal_power_sin(1.0 - mixd) if mixd < 0.999 else 0.0
+    return (wet * wet_g) + (dry * dry_g)

@@ -365,3 +365,55 @@ def test_eq_small_blocks_use_both_kernels(amd, oracle):
         yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po, block=blk)
         assert max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max()) <= 1e-13
     eng.close()
+
+
+@pytest.mark.parametrize("mix,peak", [(1.0, 0), (0.35, 777), (0.9995, 100), (0.0, 64)])
+def test_processor_level_wrapper_steady_state(amd, oracle, mix, peak):
+    """SURVEY N1 / A9: ConvolverProcessor::process steady state around the kernel-level convolver."""
+    O = oracle
+    S, T = 2, 8
+    irs = [O.gen_ir(9000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, S, 5 * T * B)
+    eng = amd.BatchedEngine(S, max_ir_len=9000, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=mix, ir_peak_latency=peak)
+    assert eng.convproc_delay(0) == 512 + peak
+    y = np.concatenate([eng.convproc_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    for c in range(2 * S):
+        ref = O.convproc_steady(irs[c], x[c], B, mix=mix, ir_peak_latency=peak)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(y[c]), ok)
+        assert rms(y[c][ok] - ref[ok]) <= 1e-13
+    if mix == 1.0:
+        # finding 5: wetG = equalPowerSin(1) = 1.0000035... != 1
+        eng.conv_reset()
+        plain = np.concatenate([eng.conv_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+        ok = np.isfinite(plain[0])
+        ratio = y[0][ok][np.abs(plain[0][ok]) > 1e-3] / plain[0][ok][np.abs(plain[0][ok]) > 1e-3]
+        assert abs(ratio.mean() - 1.0000035) < 1e-7
+    eng.close()
+
+
+def test_processor_level_bypass_and_whole_path(amd, oracle):
+    O = oracle
+    S, T = 1, 4
+    irs = [O.gen_ir(3000, stream=0, channel=ch) for ch in range(2)]
+    x = make_inputs(O, S, 6 * T * B)
+    eng = amd.BatchedEngine(S, max_ir_len=3000, max_blocks_per_call=T)
+    eng.set_impulse(0, irs[0], irs[1])
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=1.0, bypassed=True, ir_peak_latency=40)
+    y = np.concatenate([eng.convproc_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    for c in range(2):
+        assert np.array_equal(y[c], O.convproc_steady(irs[c], x[c], B, bypassed=True, ir_peak_latency=40))
+    # whole path at processor level: conv wrapper (mix 0.8) then EQ, in place
+    eng.prepare_to_play(48000.0, T * B)
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=0.8, ir_peak_latency=40)
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    po = O.eq_params_bench(0.2)
+    eng.set_eq_params(0, _copy_params(po, amd.eq_params_default()))
+    y = np.concatenate([eng.process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    w = [O.convproc_steady(irs[c], x[c], B, mix=0.8, ir_peak_latency=40) for c in range(2)]
+    rl, rr, _ = O.eq_process_stereo(w[0], w[1], po)
+    assert rms(y[0] - rl) <= 1e-13 and rms(y[1] - rr) <= 1e-13
+    eng.close()
