@@ -22,7 +22,7 @@ CPQ_SEM_EXACT = 1
 CPQ_ORDER_CONV_THEN_EQ = 0
 CPQ_ORDER_EQ_THEN_CONV = 1
 KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4,
-              "k_svf_cascade_tp": 5, "k_convproc_mix": 6}
+              "k_svf_cascade_tp": 5, "k_convproc_mix": 6, "k_outfilter_cascade": 7}
 CPQ_LEVEL_NUC = 0
 CPQ_LEVEL_PROCESSOR = 1
 CPQ_EQ_MODE_AUTO = 0
@@ -65,6 +65,10 @@ class EqBand(C.Structure):
 class EqParams(C.Structure):
     _fields_ = [("bands", EqBand * 20), ("total_gain_db", C.c_float), ("agc_enabled", C.c_int32),
                 ("nonlinear_saturation", C.c_float), ("filter_structure", C.c_int32)]
+
+
+class BiquadCoeffs(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("b0", "b1", "b2", "a1", "a2")]
 
 
 class ConvProcParams(C.Structure):
@@ -112,6 +116,12 @@ SYMBOLS = {
     "cpq_eq_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
     "cpq_eq_set_mode": (C.c_int32, [_E, C.c_int32]),
     "cpq_eq_reset": (C.c_int32, [_E]),
+    "cpq_outfilter_design": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(BiquadCoeffs)]),
+    "cpq_outfilter_set_params": (C.c_int32, [_E, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "cpq_outfilter_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
+    "cpq_outfilter_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_outfilter_reset": (C.c_int32, [_E]),
+    "cpq_engine_enable_output_filter": (C.c_int32, [_E, C.c_int32]),
     "cpq_engine_process_block": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_engine_process_block_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
     "cpq_profile_enable": (C.c_int32, [_E, C.c_int32]),

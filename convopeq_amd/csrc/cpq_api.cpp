@@ -76,6 +76,13 @@ struct cpq_engine {
     double* svfSatGain = nullptr;   // [nCh][2]
     double* svfState = nullptr; // [nCh][20][2]
     double* svfTp = nullptr;    // [streams][20][kSvfTpTableDoubles]  time-parallel kernel tables
+    // output filter (N2): the same cascade kernels running DF-II-T sections in band slots 0..2
+    double* ofCoef = nullptr;   // [nCh][20][6]  b0 b1 b2 a1 a2 -
+    int* ofFlags = nullptr;     // [nCh][20]
+    double* ofSatGain = nullptr;
+    double* ofState = nullptr;  // [nCh][20][2]  w1 w2
+    double* ofTp = nullptr;     // [streams][20][kSvfTpTableDoubles]
+    bool ofSet = false, ofTpSafe = true, ofInPath = false;
 
     // run-time state
     int head = 0;               // ring slot of the next block
@@ -199,25 +206,39 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     return CPQ_OK;
 }
 
+int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int T, bool tp, int idTp, int idSeq,
+                   const double* coef, const int* flags, const double* satGain, double* state, const double* tables)
+{
+    const int n = T * e->P;
+    const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
+    if (nTp > 0) {
+        ProfScope p(e, idTp);
+        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, (int64_t)n, e->nCh, nTp, coef, flags, satGain, state, tables);
+    }
+    if (n > nTp) {
+        ProfScope p(e, idSeq);
+        cpq::launch_svf_cascade(e->stream, dIn + nTp, dOut + nTp, (int64_t)n, e->nCh, n - nTp, coef, flags, satGain,
+                                state);
+    }
+    CPQ_HIP(e, hipGetLastError());
+    return CPQ_OK;
+}
+
 int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
     bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO);
     for (char s : e->eqTpSafe) tp = tp && s;
-    const int n = T * e->P;
-    const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
-    if (nTp > 0) {
-        ProfScope p(e, CPQ_K_SVF_TP);
-        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, (int64_t)n, e->nCh, nTp, e->svfCoef, e->svfFlags,
-                                   e->svfSatGain, e->svfState, e->svfTp);
-    }
-    if (n > nTp) {
-        ProfScope p(e, CPQ_K_SVF);
-        cpq::launch_svf_cascade(e->stream, dIn + nTp, dOut + nTp, (int64_t)n, e->nCh, n - nTp, e->svfCoef, e->svfFlags,
-                                e->svfSatGain, e->svfState);
-    }
-    CPQ_HIP(e, hipGetLastError());
-    return CPQ_OK;
+    return enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
+                          e->svfState, e->svfTp);
+}
+
+int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T)
+{
+    if (!e->ofSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_outfilter_set_params has not been called");
+    const bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO) && e->ofTpSafe;
+    return enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_OUTFILT, CPQ_K_OUTFILT, e->ofCoef, e->ofFlags, e->ofSatGain,
+                          e->ofState, e->ofTp);
 }
 
 template <typename F>
@@ -249,7 +270,10 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         for (double* p : { e->dryHist[0], e->dryHist[1] })
             if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, (size_t)e->nCh * e->dryHistCap * sizeof(double), e->stream));
     }
-    if (eq) CPQ_HIP(e, hipMemsetAsync(e->svfState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
+    if (eq) {
+        CPQ_HIP(e, hipMemsetAsync(e->svfState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(e->ofState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
+    }
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     return CPQ_OK;
 }
@@ -293,6 +317,7 @@ const char* cpq_kernel_name(int32_t id)
         case CPQ_K_SVF: return "k_svf_cascade";
         case CPQ_K_SVF_TP: return "k_svf_cascade_tp";
         case CPQ_K_MIX: return "k_convproc_mix";
+        case CPQ_K_OUTFILT: return "k_outfilter_cascade";
         default: return "?";
     }
 }
@@ -408,6 +433,11 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->svfSatGain, nCh * 2 * (int64_t)sizeof(double) },
         { (void**)&e->svfState, nCh * kBands * 2 * (int64_t)sizeof(double) },
         { (void**)&e->svfTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
+        { (void**)&e->ofCoef, nCh * kBands * 6 * (int64_t)sizeof(double) },
+        { (void**)&e->ofFlags, nCh * kBands * (int64_t)sizeof(int) },
+        { (void**)&e->ofSatGain, nCh * 2 * (int64_t)sizeof(double) },
+        { (void**)&e->ofState, nCh * kBands * 2 * (int64_t)sizeof(double) },
+        { (void**)&e->ofTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
     };
     int64_t total = 0;
     for (const Item& it : items) total += alignUp(it.bytes, 256);
@@ -826,6 +856,82 @@ int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t nSa
     return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueEq(e, a, b, T); });
 }
 
+// ------------------------------------------------------------------- output filter (N2)
+int32_t cpq_outfilter_design(int32_t convIsLast, int32_t hcMode, int32_t lcMode, int32_t lpMode, double sampleRate,
+                             cpq_biquad_coeffs out[3])
+{
+    if (!out || hcMode < 0 || hcMode > 2 || lcMode < 0 || lcMode > 1 || lpMode < 0 || lpMode > 2) return CPQ_ERR_INVALID_ARG;
+    cpq::designOutputFilter(convIsLast, hcMode, lcMode, lpMode, sampleRate, out);
+    return CPQ_OK;
+}
+
+int32_t cpq_outfilter_set_params(cpq_engine* e, int32_t stream, int32_t convIsLast, int32_t hcMode, int32_t lcMode,
+                                 int32_t lpMode)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    cpq_biquad_coeffs q[3];
+    const int rc = cpq_outfilter_design(convIsLast, hcMode, lcMode, lpMode, e->sampleRate, q);
+    if (rc != CPQ_OK) return fail(e, rc, "bad output filter mode");
+    std::vector<double> coef((size_t)kBands * 6, 0.0), tp((size_t)kBands * cpq::kSvfTpTableDoubles, 0.0);
+    std::vector<int> flags(kBands, 0);
+    bool safe = true;
+    for (int b = 0; b < 3; ++b) {
+        const double v[6] = { q[b].b0, q[b].b1, q[b].b2, q[b].a1, q[b].a2, 0.0 };
+        std::memcpy(&coef[(size_t)b * 6], v, sizeof(v));
+        flags[b] = 1 | 4;       // active, DF-II-T section (an identity section is run like the reference runs it)
+        safe = cpq::buildBiquadTpTables(q[b], &tp[(size_t)b * cpq::kSvfTpTableDoubles]) && safe;
+    }
+    CPQ_HIP(e, hipSetDevice(e->device));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    const double sg[2] = { 0.0, 1.0 };
+    for (int s = s0; s < s1; ++s) {
+        for (int ch = 0; ch < 2; ++ch) {
+            const size_t c = (size_t)2 * s + ch;
+            CPQ_HIP(e, hipMemcpy(e->ofCoef + c * kBands * 6, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice));
+            CPQ_HIP(e, hipMemcpy(e->ofFlags + c * kBands, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice));
+            CPQ_HIP(e, hipMemcpy(e->ofSatGain + c * 2, sg, sizeof(sg), hipMemcpyHostToDevice));
+        }
+        CPQ_HIP(e, hipMemcpy(e->ofTp + (size_t)s * tp.size(), tp.data(), tp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    e->ofTpSafe = e->ofTpSafe && safe;
+    e->ofSet = true;
+    return CPQ_OK;
+}
+
+int32_t cpq_engine_enable_output_filter(cpq_engine* e, int32_t on)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    e->ofInPath = on != 0;
+    return CPQ_OK;
+}
+
+int32_t cpq_outfilter_reset(cpq_engine* e)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    CPQ_HIP(e, hipMemsetAsync(e->ofState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    return CPQ_OK;
+}
+
+int32_t cpq_outfilter_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
+{
+    int T = 0;
+    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    if (rc != CPQ_OK) return rc;
+    CPQ_HIP(e, hipSetDevice(e->device));
+    return enqueueOutFilter(e, dIn, dOut, T);
+}
+
+int32_t cpq_outfilter_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
+{
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueOutFilter(e, a, b, T); });
+}
+
 // ------------------------------------------------------------------------ whole path
 static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
 {
@@ -840,6 +946,7 @@ static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
         rc = enqueueEq(e, a, e->mid, T);
         if (rc == CPQ_OK) rc = conv(e->mid, b, T);
     }
+    if (rc == CPQ_OK && e->ofInPath) rc = enqueueOutFilter(e, b, b, T);
     return rc;
 }
 

@@ -197,12 +197,33 @@ double totalGainLinear(float db)
 // State-space form of one TPT-SVF band (src/eqprocessor/EQProcessor.Processing.cpp:228-241):
 //   ic' = A ic + Bv v0,   y_lin = C ic + D v0
 //   A = [[2 a1 - 1, -2 a2], [2 a2, 1 - 2 a3]],  Bv = [2 a2, 2 a3],  C = [m1 a1 + m2 a2, -m1 a2 + m2 (1 - a3)]
+namespace {
+typedef long double ld;
+bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double* out);
+}  // namespace
+
 bool buildSvfTpTables(const cpq_svf_coeffs& c, double* out)
 {
-    typedef long double ld;
     const ld a1 = c.a1, a2 = c.a2, a3 = c.a3, m1 = c.m1, m2 = c.m2;
     const ld A[4] = { 2 * a1 - 1, -2 * a2, 2 * a2, 1 - 2 * a3 };
     const ld C[2] = { m1 * a1 + m2 * a2, -m1 * a2 + m2 * (1 - a3) };
+    const ld Bv[2] = { 2 * a2, 2 * a3 };
+    return buildTpTablesFromStateSpace(A, C, Bv, out);
+}
+
+// DF-II-T biquad (src/OutputFilter.h:33-68): y = b0 x + w1; w1' = b1 x - a1 y + w2; w2' = b2 x - a2 y
+//   => state (w1, w2): A = [[-a1, 1], [-a2, 0]], Bv = [b1 - a1 b0, b2 - a2 b0], C = [1, 0], D = b0
+bool buildBiquadTpTables(const cpq_biquad_coeffs& q, double* out)
+{
+    const ld A[4] = { -(ld)q.a1, 1, -(ld)q.a2, 0 };
+    const ld C[2] = { 1, 0 };
+    const ld Bv[2] = { (ld)q.b1 - (ld)q.a1 * q.b0, (ld)q.b2 - (ld)q.a2 * q.b0 };
+    return buildTpTablesFromStateSpace(A, C, Bv, out);
+}
+
+namespace {
+bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double* out)
+{
     auto mul = [](const ld* x, const ld* y, ld* z) {
         const ld r[4] = { x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3],
                           x[2] * y[0] + x[3] * y[2], x[2] * y[1] + x[3] * y[3] };
@@ -246,7 +267,7 @@ bool buildSvfTpTables(const cpq_svf_coeffs& c, double* out)
     // guard-freedom proof: sup_n |A^n|_inf (carried state) and the l1 gain input -> state must keep every
     // state below 1e15 for |input|, |carried state| < 1e9 (one decade of margin)
     ld Q[4] = { 1, 0, 0, 1 };
-    ld s[2] = { 2 * a2, 2 * a3 };
+    ld s[2] = { Bv[0], Bv[1] };
     ld kappa = 1, l1 = 0;
     const long maxIter = 1L << 23;
     long n = 0;
@@ -262,6 +283,66 @@ bool buildSvfTpTables(const cpq_svf_coeffs& c, double* out)
     }
     if (n >= maxIter) return false;
     return (kappa + l1) < 1.0e5L;
+}
+}  // namespace
+
+// OutputFilter::makeLPF / makeHPF / makeIdentity (src/OutputFilter.cpp:23-72), RBJ cookbook forms
+static cpq_biquad_coeffs biquadIdentity() { return cpq_biquad_coeffs{ 1.0, 0.0, 0.0, 0.0, 0.0 }; }
+
+static cpq_biquad_coeffs makeLpf(double fc, double Q, double fs)
+{
+    const double nyq = fs * 0.4999;
+    if (fc >= nyq || Q <= 0.0 || fs <= 0.0) return biquadIdentity();
+    const double w0 = 2.0 * 3.141592653589793238462643383279502884 * fc / fs;
+    const double sn = std::sin(w0), cs = std::cos(w0);
+    const double alpha = sn / (2.0 * Q);
+    const double a0inv = 1.0 / (1.0 + alpha);
+    cpq_biquad_coeffs c;
+    c.b0 = (1.0 - cs) * 0.5 * a0inv;
+    c.b1 = (1.0 - cs) * a0inv;
+    c.b2 = (1.0 - cs) * 0.5 * a0inv;
+    c.a1 = (-2.0 * cs) * a0inv;
+    c.a2 = (1.0 - alpha) * a0inv;
+    return c;
+}
+
+static cpq_biquad_coeffs makeHpf(double fc, double Q, double fs)
+{
+    const double nyq = fs * 0.4999;
+    if (fc <= 0.0 || fc >= nyq || Q <= 0.0 || fs <= 0.0) return biquadIdentity();
+    const double w0 = 2.0 * 3.141592653589793238462643383279502884 * fc / fs;
+    const double sn = std::sin(w0), cs = std::cos(w0);
+    const double alpha = sn / (2.0 * Q);
+    const double a0inv = 1.0 / (1.0 + alpha);
+    cpq_biquad_coeffs c;
+    c.b0 = (1.0 + cs) * 0.5 * a0inv;
+    c.b1 = -(1.0 + cs) * a0inv;
+    c.b2 = (1.0 + cs) * 0.5 * a0inv;
+    c.a1 = (-2.0 * cs) * a0inv;
+    c.a2 = (1.0 - alpha) * a0inv;
+    return c;
+}
+
+// the three sections OutputFilter::process runs, in order (src/OutputFilter.cpp:78-121, 214-222, 318-324):
+//   convIsLast:  LC (HPF 18/15 Hz) -> HC stage 0 -> HC stage 1        (fc 19 kHz, or 22 kHz above 48 kHz)
+//   EQ is last:  HPF 20 Hz         -> LP stage 0 -> LP stage 1        (fc 19 kHz, or 24 kHz above 48 kHz)
+void designOutputFilter(int convIsLast, int hcMode, int lcMode, int lpMode, double fs, cpq_biquad_coeffs out[3])
+{
+    const double fcHc = (fs <= 48000.0) ? 19000.0 : 22000.0;
+    const double fcLp = (fs <= 48000.0) ? 19000.0 : 24000.0;
+    if (convIsLast) {
+        out[0] = (lcMode == 1) ? makeHpf(15.0, 0.5, fs) : makeHpf(18.0, 0.70711, fs);
+        switch (hcMode) {
+            case 0: out[1] = makeLpf(fcHc, 0.54120, fs); out[2] = makeLpf(fcHc, 1.30656, fs); break;
+            case 2: out[1] = makeLpf(fcHc, 0.5, fs); out[2] = biquadIdentity(); break;
+            default: out[1] = makeLpf(fcHc, 0.70711, fs); out[2] = makeLpf(fcHc, 0.70711, fs); break;
+        }
+    } else {
+        out[0] = makeHpf(20.0, 0.70711, fs);
+        const double q = (lpMode == 0) ? 1.0 : (lpMode == 2 ? 0.5 : 0.70711);
+        out[1] = makeLpf(fcLp, q, fs);
+        out[2] = makeLpf(fcLp, q, fs);
+    }
 }
 
 }  // namespace cpq

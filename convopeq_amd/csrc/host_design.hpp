@@ -18,5 +18,7 @@ double totalGainLinear(float db);
 // svf_kernels.hip: 2x2 powers of the state matrix and the state-to-output response).  Returns false when the state guards of the reference could
 // trip for inputs / carried states below 1e9 (or the filter does not decay), i.e. the kernel must not be used.
 bool   buildSvfTpTables(const cpq_svf_coeffs& c, double* out);
+bool   buildBiquadTpTables(const cpq_biquad_coeffs& q, double* out);
+void   designOutputFilter(int convIsLast, int hcMode, int lcMode, int lpMode, double fs, cpq_biquad_coeffs out[3]);
 
 }  // namespace cpq

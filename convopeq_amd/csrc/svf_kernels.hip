@@ -58,6 +58,7 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
     }
     const bool active = (flag & 1) != 0;
     const bool mono = (flag & 2) != 0;      // Left/Right channel mode -> scalar processBand arithmetic
+    const bool df2t = (flag & 4) != 0;      // OutputFilter section: Direct-Form-II-transposed biquad (coef = b0 b1 b2 a1 a2)
     const double oneMinusSat = 1.0 - sat;
 
     double ylast = 0.0;
@@ -78,7 +79,16 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
             const double v0 = (band == 0) ? xin[chl < kChPerWave ? chl : 0][i & 63] : fromPrev;
             if (live && n >= 0 && n < nSamples) {
                 double y = v0;
-                if (active) {
+                if (active && df2t) {
+                    // biquadStep128_FMA (src/OutputFilter.cpp:143-165): state (w1, w2) in (ic1, ic2);
+                    // explicit flush of |w| < 1e-20 like the reference
+                    const double yy = fma(a1, v0, ic1);                       // b0 x + w1
+                    double n1 = fma(a2, v0, fma(-m0, yy, ic2));               // b1 x - a1 y + w2
+                    double n2 = fma(-m1, yy, a3 * v0);                        // b2 x - a2 y
+                    ic1 = (fabs(n1) < 1.0e-20) ? 0.0 : n1;
+                    ic2 = (fabs(n2) < 1.0e-20) ? 0.0 : n2;
+                    y = yy;
+                } else if (active) {
                     if (!mono) {
                         const double v3 = v0 - ic2;
                         const double v1 = fma(a1, ic1, a2 * v3);
@@ -222,15 +232,25 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 }
 
 // zero-state (or continuing) recurrence of one band over N samples held in registers: v[j] <- y_lin[j]
-template <bool MONO, int N>
+// KIND: 0 = SVF, packed stereo arithmetic (FMA), 1 = SVF scalar arithmetic (Left/Right modes), 2 = DF-II-T biquad
+// of the OutputFilter (coefficients b0 b1 b2 a1 a2 in a1 a2 a3 m0 m1; state w1 w2 in ic1 ic2)
+template <int KIND, int N>
 __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic2, double a1, double a2, double a3,
                                          double m0, double m1, double m2)
 {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const double v0 = v[j];
+        if (KIND == 2) {
+            const double yy = fma(a1, v0, ic1);
+            const double n1 = fma(a2, v0, fma(-m0, yy, ic2));
+            ic2 = fma(-m1, yy, a3 * v0);
+            ic1 = n1;
+            v[j] = yy;
+            continue;
+        }
         const double v3 = v0 - ic2;
-        if (MONO) {
+        if (KIND == 1) {
             const double v1 = a1 * ic1 + a2 * v3;
             const double v2 = ic2 + a2 * ic1 + a3 * v3;
             ic1 = 2.0 * v1 - ic1;
@@ -298,7 +318,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
 // with every guard, used when the span input or the carried state is outside the proven-safe range.
-template <bool MONO>
+template <int KIND>
 __device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sat, double* sState)
 {
     const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
@@ -307,12 +327,17 @@ __device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sa
     for (int c = 0; c < kTpChunks; ++c)
         for (int i = 0; i < lc; ++i) {
             double y[1] = { buf[c * kTpStride + i] };
-            tp_recur<MONO, 1>(y, ic1, ic2, a1, a2, a3, m0, m1, m2);
-            if (sat > 0.0) tp_nonlinear<MONO, true, 1>(y, sat, oneMinusSat);
-            else           tp_nonlinear<MONO, false, 1>(y, sat, oneMinusSat);
+            tp_recur<KIND, 1>(y, ic1, ic2, a1, a2, a3, m0, m1, m2);
+            if (KIND == 2) {          // OutputFilter: no output stage, denormal flush of the state (OutputFilter.cpp:154-162)
+                ic1 = (fabs(ic1) < 1.0e-20) ? 0.0 : ic1;
+                ic2 = (fabs(ic2) < 1.0e-20) ? 0.0 : ic2;
+            } else {
+                if (sat > 0.0) tp_nonlinear<KIND == 1, true, 1>(y, sat, oneMinusSat);
+                else           tp_nonlinear<KIND == 1, false, 1>(y, sat, oneMinusSat);
+                ic1 = sanitize(ic1);
+                ic2 = sanitize(ic2);
+            }
             buf[c * kTpStride + i] = y[0];
-            ic1 = sanitize(ic1);
-            ic2 = sanitize(ic2);
         }
     sState[0] = ic1;
     sState[1] = ic2;
@@ -351,8 +376,9 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
             const int flag = fl[b];
             if (!(flag & 1)) continue;
             if (tid == 0) {
-                if (flag & 2) tp_band_guarded<true>(buf, LC, L->cf[b], sat, sState + 2 * b);
-                else          tp_band_guarded<false>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b);
             }
             __syncthreads();
         }
@@ -366,14 +392,15 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
             {
                 const double a1 = L->cf[b][0], a2 = L->cf[b][1], a3 = L->cf[b][2];
                 const double m0 = L->cf[b][3], m1 = L->cf[b][4], m2 = L->cf[b][5];
-                const bool mono = (fl[b] & 2) != 0;
+                const int kind = (fl[b] >> 1) & 3;      // 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
 #pragma unroll 1
                 for (int i0 = 0; i0 < LC; i0 += U) {
                     double v[U];
 #pragma unroll
                     for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
-                    if (mono) tp_recur<true, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                    else      tp_recur<false, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                    if (kind == 2)      tp_recur<2, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                    else if (kind == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                    else                tp_recur<0, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
 #pragma unroll
                     for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
                 }
@@ -383,9 +410,9 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
                 while (nb < kBands && !(fl[nb] & 1)) ++nb;     // next active band (uniform)
                 double s0x, s0y;
                 tp_scan(ic1, ic2, s0x, s0y, L, b, &tb[b].t[LCI].P[0][0], wtot, sState, tid);
-                const bool monoB = (fl[b] & 2) != 0;
+                const int kindB = (fl[b] >> 1) & 3;
                 const bool hasNext = nb < kBands;
-                const bool monoN = hasNext && (fl[nb] & 2) != 0;
+                const int kindN = hasNext ? ((fl[nb] >> 1) & 3) : 0;
                 double a1 = 0, a2 = 0, a3 = 0, m0 = 1, m1 = 0, m2 = 0;
                 if (hasNext) {
                     a1 = L->cf[nb][0]; a2 = L->cf[nb][1]; a3 = L->cf[nb][2];
@@ -400,11 +427,13 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 #pragma unroll
                     for (int j = 0; j < U; ++j)
                         v[j] = fma(L->G[b][2 * (i0 + j) + 1], s0y, fma(L->G[b][2 * (i0 + j)], s0x, v[j]));
-                    if (monoB) tp_nonlinear<true, SAT, U>(v, sat, oneMinusSat);
-                    else       tp_nonlinear<false, SAT, U>(v, sat, oneMinusSat);
+                    if (kindB == 1)      tp_nonlinear<true, SAT, U>(v, sat, oneMinusSat);
+                    else if (kindB == 0) tp_nonlinear<false, SAT, U>(v, sat, oneMinusSat);
+                    // kindB == 2 (OutputFilter biquad): linear section, no output stage
                     if (hasNext) {
-                        if (monoN) tp_recur<true, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                        else       tp_recur<false, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                        if (kindN == 2)      tp_recur<2, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                        else if (kindN == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
+                        else                 tp_recur<0, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
                     }
 #pragma unroll
                     for (int j = 0; j < U; ++j) row[i0 + j] = v[j];

@@ -53,6 +53,14 @@ def design_svf(btype, freq, gain_db, q, sr):
     return c
 
 
+def outfilter_design(conv_is_last, hc_mode, lc_mode, lp_mode, sr):
+    out = (K.BiquadCoeffs * 3)()
+    rc = K.load().cpq_outfilter_design(int(conv_is_last), hc_mode, lc_mode, lp_mode, sr, out)
+    if rc != 0:
+        raise CpqError(rc, "cpq_outfilter_design")
+    return list(out)
+
+
 def eq_params_default():
     p = K.EqParams()
     K.load().cpq_eq_params_default(C.byref(p))
@@ -123,6 +131,18 @@ class BatchedEngine:
 
     def convproc_process(self, x):
         return self._host(self._lib.cpq_convproc_process, x)
+
+    def set_outfilter_params(self, stream, conv_is_last, hc_mode=1, lc_mode=0, lp_mode=1):
+        self._ck(self._lib.cpq_outfilter_set_params(self._h, stream, int(conv_is_last), hc_mode, lc_mode, lp_mode))
+
+    def outfilter_process(self, x):
+        return self._host(self._lib.cpq_outfilter_process, x)
+
+    def enable_output_filter(self, on=True):
+        self._ck(self._lib.cpq_engine_enable_output_filter(self._h, int(on)))
+
+    def outfilter_reset(self):
+        self._ck(self._lib.cpq_outfilter_reset(self._h))
 
     def set_eq_mode(self, mode):
         self._ck(self._lib.cpq_eq_set_mode(self._h, mode))

@@ -241,6 +241,26 @@ int32_t cpq_eq_set_mode(cpq_engine* e, int32_t mode);
 /* zero filterState (EQProcessor::prepareToPlay, src/eqprocessor/EQProcessor.Core.cpp:769) */
 int32_t cpq_eq_reset(cpq_engine* e);
 
+/* ------------------------------------------------- output filter (N2, adjacent) */
+/* POD mirror of convo::BiquadCoeff (src/OutputFilter.h:40-44), a0-normalised Direct Form II Transposed */
+typedef struct { double b0, b1, b2, a1, a2; } cpq_biquad_coeffs;
+/* OutputFilter::prepare coefficient design (src/OutputFilter.cpp:23-121) for the three sections process() runs:
+ * conv_is_last: low cut, high cut stage 0, stage 1; else: 20 Hz high-pass, low-pass stage 0, stage 1.  Host only. */
+int32_t cpq_outfilter_design(int32_t conv_is_last, int32_t hc_mode, int32_t lc_mode, int32_t lp_mode,
+                             double sample_rate, cpq_biquad_coeffs out[3]);
+/* replaces OutputFilter::prepare + the mode arguments of process() (src/OutputFilter.h:106-131) */
+int32_t cpq_outfilter_set_params(cpq_engine* e, int32_t stream, int32_t conv_is_last, int32_t hc_mode,
+                                 int32_t lc_mode, int32_t lp_mode);
+/* replaces OutputFilter::process(block, convIsLast, hcMode, lcMode, lpMode) stereo path: three DF-II-T biquads per
+ * sample (biquadStep128_FMA, src/OutputFilter.cpp:143-165, :214-392) */
+int32_t cpq_outfilter_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);
+int32_t cpq_outfilter_process_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+/* OutputFilter::reset (src/OutputFilter.cpp:126-137) */
+int32_t cpq_outfilter_reset(cpq_engine* e);
+/* on != 0: cpq_engine_process_block also runs the output filter after the conv/EQ pair, as DSPCore does
+ * (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:453 ff.); default off */
+int32_t cpq_engine_enable_output_filter(cpq_engine* e, int32_t on);
+
 /* ------------------------------------------------------- whole path per call */
 /* replaces the DSPCore routing of convolverRt().process(block) and eqRt().process(block, params, cache)
  * (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:386-451) in the configured order. */
@@ -258,7 +278,8 @@ typedef enum {
     CPQ_K_SVF      = 4,   /* k_svf_cascade (lane-skewed sequential recurrence) */
     CPQ_K_SVF_TP   = 5,   /* k_svf_cascade_tp (time-parallel, default) */
     CPQ_K_MIX      = 6,   /* k_convproc_mix (processor-level dry/wet stage) */
-    CPQ_K_COUNT    = 7
+    CPQ_K_OUTFILT  = 7,   /* output-filter biquad cascade (k_svf_cascade_tp / k_svf_cascade running DF-II-T sections) */
+    CPQ_K_COUNT    = 8
 } cpq_kernel_id;
 int32_t     cpq_profile_enable(cpq_engine* e, int32_t on);
 int32_t     cpq_profile_reset(cpq_engine* e);

@@ -994,6 +994,93 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
     }
 }
 
+/* ====================================================== OutputFilter ===== */
+
+static orc_biquad bq_identity(void) { orc_biquad c = { 1.0, 0.0, 0.0, 0.0, 0.0 }; return c; }
+
+static orc_biquad bq_lpf(double fc, double Q, double fs)
+{
+    const double nyq = fs * 0.4999;
+    if (fc >= nyq || Q <= 0.0 || fs <= 0.0) return bq_identity();
+    const double w0 = 2.0 * M_PI * fc / fs;
+    const double sn = sin(w0), cs = cos(w0);
+    const double alpha = sn / (2.0 * Q);
+    const double a0inv = 1.0 / (1.0 + alpha);
+    orc_biquad c;
+    c.b0 = (1.0 - cs) * 0.5 * a0inv;
+    c.b1 = (1.0 - cs) * a0inv;
+    c.b2 = (1.0 - cs) * 0.5 * a0inv;
+    c.a1 = (-2.0 * cs) * a0inv;
+    c.a2 = (1.0 - alpha) * a0inv;
+    return c;
+}
+
+static orc_biquad bq_hpf(double fc, double Q, double fs)
+{
+    const double nyq = fs * 0.4999;
+    if (fc <= 0.0 || fc >= nyq || Q <= 0.0 || fs <= 0.0) return bq_identity();
+    const double w0 = 2.0 * M_PI * fc / fs;
+    const double sn = sin(w0), cs = cos(w0);
+    const double alpha = sn / (2.0 * Q);
+    const double a0inv = 1.0 / (1.0 + alpha);
+    orc_biquad c;
+    c.b0 = (1.0 + cs) * 0.5 * a0inv;
+    c.b1 = -(1.0 + cs) * a0inv;
+    c.b2 = (1.0 + cs) * 0.5 * a0inv;
+    c.a1 = (-2.0 * cs) * a0inv;
+    c.a2 = (1.0 - alpha) * a0inv;
+    return c;
+}
+
+void orc_outfilter_design(int convIsLast, int hcMode, int lcMode, int lpMode, double fs, orc_biquad out[3])
+{
+    const double fc_hc = (fs <= 48000.0) ? 19000.0 : 22000.0;
+    const double fc_lp = (fs <= 48000.0) ? 19000.0 : 24000.0;
+    if (convIsLast) {
+        out[0] = (lcMode == 1) ? bq_hpf(15.0, 0.5, fs) : bq_hpf(18.0, 0.70711, fs);
+        if (hcMode == 0)      { out[1] = bq_lpf(fc_hc, 0.54120, fs); out[2] = bq_lpf(fc_hc, 1.30656, fs); }
+        else if (hcMode == 2) { out[1] = bq_lpf(fc_hc, 0.5, fs);     out[2] = bq_identity(); }
+        else                  { out[1] = bq_lpf(fc_hc, 0.70711, fs); out[2] = bq_lpf(fc_hc, 0.70711, fs); }
+    } else {
+        out[0] = bq_hpf(20.0, 0.70711, fs);
+        const double q = (lpMode == 0) ? 1.0 : (lpMode == 2 ? 0.5 : 0.70711);
+        out[1] = bq_lpf(fc_lp, q, fs);
+        out[2] = bq_lpf(fc_lp, q, fs);
+    }
+}
+
+static double bq_step(double x, const orc_biquad* c, double* w1, double* w2)
+{
+    const double y = fma(c->b0, x, *w1);
+    const double n1 = fma(c->b1, x, fma(-c->a1, y, *w2));
+    const double n2 = fma(-c->a2, y, c->b2 * x);
+    *w1 = (fabs(n1) < 1.0e-20) ? 0.0 : n1;      /* _mm_andnot_pd(_mm_cmplt_pd(|w|, 1e-20), w) */
+    *w2 = (fabs(n2) < 1.0e-20) ? 0.0 : n2;
+    return y;
+}
+
+void orc_biquad_df2t_lane(double* data, int64_t n, const orc_biquad* c, double* state)
+{
+    double w1 = state[0], w2 = state[1];
+    for (int64_t i = 0; i < n; ++i) data[i] = bq_step(data[i], c, &w1, &w2);
+    state[0] = w1; state[1] = w2;
+}
+
+void orc_outfilter_process_stereo(double* dataL, double* dataR, int64_t n, const orc_biquad c[3], double* state)
+{
+    double* ch[2] = { dataL, dataR };
+    for (int k = 0; k < 2; ++k) {
+        double* st = state + k * 6;
+        for (int64_t i = 0; i < n; ++i) {
+            double x = ch[k][i];
+            x = bq_step(x, &c[0], &st[0], &st[1]);
+            x = bq_step(x, &c[1], &st[2], &st[3]);
+            x = bq_step(x, &c[2], &st[4], &st[5]);
+            ch[k][i] = x;
+        }
+    }
+}
+
 double orc_equal_power_sin(double x)
 {
     const double t = x * (M_PI * 0.5);

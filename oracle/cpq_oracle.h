@@ -147,6 +147,17 @@ void   orc_svf_band_mono(double* data, int64_t n, const orc_svf_coeffs* c,
 void   orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSize,
                              const orc_eq_params* p, double sr, double* state /*[2][20][2]*/);
 
+/* ------------------------------------------------------- OutputFilter (N2) ---- */
+/* mirrors convo::BiquadCoeff, src/OutputFilter.h:40-44 */
+typedef struct { double b0, b1, b2, a1, a2; } orc_biquad;
+/* makeLPF / makeHPF / makeIdentity + prepare(), src/OutputFilter.cpp:23-121: the three sections process() runs */
+void   orc_outfilter_design(int convIsLast, int hcMode, int lcMode, int lpMode, double fs, orc_biquad out[3]);
+/* biquadStep128_FMA applied to one lane, src/OutputFilter.cpp:143-165; state = {w1, w2} */
+void   orc_biquad_df2t_lane(double* data, int64_t n, const orc_biquad* c, double* state);
+/* OutputFilter::process stereo path, src/OutputFilter.cpp:214-392: per sample LC/HPF -> stage 0 -> stage 1;
+ * state[2][3][2] = [channel][section][w1,w2] */
+void   orc_outfilter_process_stereo(double* dataL, double* dataR, int64_t n, const orc_biquad c[3], double* state);
+
 /* equalPowerSin, src/convolver/ConvolverProcessor.Runtime.cpp:26-31 */
 double orc_equal_power_sin(double x);
 

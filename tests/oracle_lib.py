@@ -42,6 +42,10 @@ class SvfCoeffs(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("g", "k", "a1", "a2", "a3", "m0", "m1", "m2")]
 
 
+class Biquad(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("b0", "b1", "b2", "a1", "a2")]
+
+
 class EqBand(C.Structure):
     _fields_ = [("frequency", C.c_float), ("gain", C.c_float), ("q", C.c_float),
                 ("enabled", C.c_int), ("type", C.c_int), ("channelMode", C.c_int)]
@@ -100,6 +104,9 @@ def lib():
     L.orc_svf_band_mono.argtypes = [c_double_p, C.c_int64, C.POINTER(SvfCoeffs), c_double_p, C.c_double]
     L.orc_eq_process_stereo.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, C.POINTER(EqParams),
                                         C.c_double, c_double_p]
+    L.orc_outfilter_design.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Biquad)]
+    L.orc_biquad_df2t_lane.argtypes = [c_double_p, C.c_int64, C.POINTER(Biquad), c_double_p]
+    L.orc_outfilter_process_stereo.argtypes = [c_double_p, c_double_p, C.c_int64, C.POINTER(Biquad), c_double_p]
     L.orc_equal_power_sin.restype = C.c_double
     L.orc_equal_power_sin.argtypes = [C.c_double]
     _LIB = L
@@ -283,3 +290,18 @@ def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0):
     wet_g = L.orc_equal_power_sin(mixd) * 1.0
     dry_g = L.orc_equal_power_sin(1.0 - mixd) if mixd < 0.999 else 0.0
     return (wet * wet_g) + (dry * dry_g)
+
+
+def outfilter_design(conv_is_last, hc_mode=1, lc_mode=0, lp_mode=1, sr=48000.0):
+    out = (Biquad * 3)()
+    lib().orc_outfilter_design(int(conv_is_last), hc_mode, lc_mode, lp_mode, sr, out)
+    return out
+
+
+def outfilter_process_stereo(xl, xr, coeffs, state=None):
+    yl = np.array(xl, dtype=np.float64, copy=True)
+    yr = np.array(xr, dtype=np.float64, copy=True)
+    if state is None:
+        state = np.zeros(12, dtype=np.float64)
+    lib().orc_outfilter_process_stereo(dp(yl), dp(yr), len(yl), coeffs, dp(state))
+    return yl, yr, state

@@ -417,3 +417,57 @@ def test_processor_level_bypass_and_whole_path(amd, oracle):
     rl, rr, _ = O.eq_process_stereo(w[0], w[1], po)
     assert rms(y[0] - rl) <= 1e-13 and rms(y[1] - rr) <= 1e-13
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+@pytest.mark.parametrize("conv_is_last,hc,lc,lp", [(1, 1, 0, 1), (1, 0, 1, 1), (1, 2, 0, 1), (0, 1, 0, 0), (0, 1, 0, 2)])
+def test_output_filter_df2t_cascade(amd, oracle, mode, conv_is_last, hc, lc, lp):
+    """OutputFilter three-section DF-II-T cascade (stereo FMA path)."""
+    O = oracle
+    S, T = 3, 12
+    x = make_inputs(O, S, 3 * T * B)
+    q = O.outfilter_design(conv_is_last, hc, lc, lp, 48000.0)
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, conv_is_last, hc, lc, lp)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    y = np.concatenate([eng.outfilter_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    worst, err2 = 0.0, 0.0
+    for s in range(S):
+        yl, yr, _ = O.outfilter_process_stereo(x[2 * s], x[2 * s + 1], q)
+        worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+        err2 += np.sum((y[2 * s] - yl) ** 2) + np.sum((y[2 * s + 1] - yr) ** 2)
+    r = float(np.sqrt(err2 / y.size))
+    print("outfilter", mode, (conv_is_last, hc, lc, lp), "max abs diff", worst, "rms", r)
+    # sequential kernel: reference op order -> bit equality.  Time-parallel kernel: the 18/20 Hz high-pass has poles
+    # at |z| = 0.998, where ANY fp64 evaluation order is ~2e-13 (max) from the exact result (see the CPU test
+    # against a long-double evaluation); bar = 1e-12 RMS of BASELINE.json.
+    assert worst <= (0.0 if mode == "sequential" else 5e-12) and r <= (0.0 if mode == "sequential" else 1e-12)
+    eng.outfilter_reset()
+    y2 = eng.outfilter_process(x[:, :T * B])
+    assert np.abs(y2 - y[:, :T * B]).max() <= (0.0 if mode == "sequential" else 5e-12)
+    eng.close()
+
+
+def test_whole_chain_conv_eq_output_filter(amd, oracle):
+    """DSPCore order Conv -> EQ -> OutputFilter (EQ last: 20 Hz HPF + 2 x LPF), processor-level convolver."""
+    O = oracle
+    S, T = 2, 8
+    irs = [O.gen_ir(7000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, S, 4 * T * B)
+    po = O.eq_params_bench(0.2)
+    q = O.outfilter_design(0, 1, 0, 1, 48000.0)
+    eng = amd.BatchedEngine(S, max_ir_len=7000, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=1.0)
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    eng.enable_output_filter(True)
+    y = np.concatenate([eng.process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    for s in range(S):
+        w = [O.convproc_steady(irs[2 * s + ch], x[2 * s + ch], B) for ch in range(2)]
+        el, er, _ = O.eq_process_stereo(w[0], w[1], po)
+        fl, fr, _ = O.outfilter_process_stereo(el, er, q)
+        assert rms(y[2 * s] - fl) <= 1e-12 and rms(y[2 * s + 1] - fr) <= 1e-12
+    eng.close()

@@ -145,3 +145,36 @@ def test_invalid_arguments_are_rejected_without_gpu(amd):
     assert b"power of two" in lib.cpq_last_error(None)
     assert lib.cpq_status_string(-5) == b"not supported by this engine version"
     assert lib.cpq_kernel_name(1) == b"k_fdl_mac"
+
+
+def test_outfilter_design_matches_oracle_and_rbj(amd, oracle):
+    """N2: OutputFilter::prepare coefficient design through the C ABI == oracle restatement; sanity vs scipy."""
+    from scipy.signal import freqz
+    for sr in (44100.0, 48000.0, 96000.0):
+        for cil in (0, 1):
+            for hc in range(3):
+                for lc in range(2):
+                    for lp in range(3):
+                        a = amd.outfilter_design(cil, hc, lc, lp, sr)
+                        o = oracle.outfilter_design(cil, hc, lc, lp, sr)
+                        for x, y in zip(a, o):
+                            assert (x.b0, x.b1, x.b2, x.a1, x.a2) == (y.b0, y.b1, y.b2, y.a1, y.a2)
+    q = amd.outfilter_design(0, 1, 0, 1, 48000.0)        # EQ last: 20 Hz HPF, 2 x 19 kHz LPF (Q 0.7071)
+    w, hh = freqz([q[1].b0, q[1].b1, q[1].b2], [1.0, q[1].a1, q[1].a2], worN=[19000.0], fs=48000.0)
+    assert abs(20 * np.log10(abs(hh[0])) + 3.01) < 0.02
+    w, hh = freqz([q[0].b0, q[0].b1, q[0].b2], [1.0, q[0].a1, q[0].a2], worN=[20.0], fs=48000.0)
+    assert abs(20 * np.log10(abs(hh[0])) + 3.01) < 0.02
+    s = amd.outfilter_design(1, 2, 0, 1, 48000.0)        # Soft high cut: second stage is the identity
+    assert (s[2].b0, s[2].b1, s[2].b2, s[2].a1, s[2].a2) == (1.0, 0.0, 0.0, 0.0, 0.0)
+
+
+def test_oracle_df2t_matches_scipy_lfilter(oracle):
+    from scipy.signal import lfilter
+    q = oracle.outfilter_design(1, 0, 0, 1, 48000.0)
+    x = oracle.gen_pcm(4096)
+    yl, yr, _ = oracle.outfilter_process_stereo(x, x, q)
+    ref = x
+    for s in q:
+        ref = lfilter([s.b0, s.b1, s.b2], [1.0, s.a1, s.a2], ref)
+    # the 18 Hz high-pass has poles at |z| = 0.998: any fp64 evaluation order sits ~2e-13 from the exact result
+    assert np.abs(yl - ref).max() < 2e-12 and np.array_equal(yl, yr)
