@@ -116,15 +116,18 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     const int base = head + grp * (kWgWaves * kWgTile);          // FDL slot of the group's first output block
     const int t0w = grp * (kWgWaves * kWgTile) + w * kWgTile;    // this wave's first output block
 
-    const double2* __restrict__ Xc = X + (int64_t)c * (ringMask + 1) * P + bin;
-    const double2* __restrict__ Hc = H + (int64_t)irSlot[c] * hSlotStride + bin;
+    // uniform row bases (SGPR) + per-lane bin offset: the loads use the scalar-base addressing form
+    const double2* __restrict__ Xu = X + (int64_t)c * (ringMask + 1) * P;
+    const double2* __restrict__ Hu = H + (int64_t)irSlot[c] * hSlotStride;
     auto slotOf = [](int b) { return ((b % kWgRingBlocks) + kWgRingBlocks) % kWgRingBlocks; };
+    auto xrow = [&](int slot) { return Xu + (int64_t)(slot & ringMask) * P; };
+    auto hrow = [&](int k) { return Hu + (int64_t)k * P; };
 
     double2 acc[kWgTile], xw[kWgTile], hn[PFH];
 #pragma unroll
     for (int u = 0; u < kWgTile; ++u) {
         acc[u] = make_double2(0.0, 0.0);
-        xw[u] = Xc[(int64_t)((base + kWgTile * w + u) & ringMask) * P];
+        xw[u] = xrow(base + kWgTile * w + u)[bin];
     }
     // ring prologue: block b (rows base+8b .. base+8b+7) for b = 0..6 is the register window of wave b;
     // block -1 is fetched one row per wave
@@ -133,32 +136,38 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         for (int u = 0; u < kWgTile; ++u) ring[(slotOf(w) * kWgTile + u) * 64 + lane] = xw[u];
     }
     {
-        const double2 xs = Xc[(int64_t)((base - kWgTile + w) & ringMask) * P];
+        const double2 xs = xrow(base - kWgTile + w)[bin];
         ring[(slotOf(-1) * kWgTile + w) * 64 + lane] = xs;
     }
 #pragma unroll
-    for (int r = 0; r < PFH; ++r) hn[r] = Hc[(int64_t)r * P];
+    for (int r = 0; r < PFH; ++r) hn[r] = hrow(r)[bin];
     __syncthreads();
 
     const int nChunks = kPad / kWgTile;
     for (int j = 0; j < nChunks; ++j) {
         // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
-        const double2 xs = Xc[(int64_t)((base + kWgTile * (-j - 2) + w) & ringMask) * P];
+        const double2 xs = xrow(base + kWgTile * (-j - 2) + w)[bin];
         const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
 #pragma unroll
         for (int r = 0; r < kWgTile; ++r) {
             const int k = j * kWgTile + r;
             const double2 h = hn[r % PFH];
-            hn[r % PFH] = Hc[(int64_t)(k + PFH) * P];
-            const double2 xnew = blk[(kWgTile - 1 - r) * 64];        // X[t0w - k - 1]
+            // output 7 is the last user of window slot 7-r: retire it first, then refill the slot straight from
+            // the LDS ring (X[t0w - k - 1]); the read's latency hides behind the other seven MACs
+            {
+                const double2 x = xw[kWgTile - 1 - r];
+                acc[kWgTile - 1].x = fma(x.x, h.x, fma(-x.y, h.y, acc[kWgTile - 1].x));
+                acc[kWgTile - 1].y = fma(x.x, h.y, fma(x.y, h.x, acc[kWgTile - 1].y));
+            }
+            xw[kWgTile - 1 - r] = blk[(kWgTile - 1 - r) * 64];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < kWgTile; ++i) {
+            for (int i = 0; i < kWgTile - 1; ++i) {
                 const double2 x = xw[(i - r + kWgTile) % kWgTile];
                 acc[i].x = fma(x.x, h.x, fma(-x.y, h.y, acc[i].x));
                 acc[i].y = fma(x.x, h.y, fma(x.y, h.x, acc[i].y));
             }
-            xw[kWgTile - 1 - r] = xnew;
+            hn[r % PFH] = hrow(k + PFH)[bin];        // IR row k+PFH (zero rows past K), into the slot just consumed
             __builtin_amdgcn_sched_barrier(0);
         }
         // slot of block (-j-2) == slot of block (7-j), last read by wave 7 in chunk j-1: free since the barrier
