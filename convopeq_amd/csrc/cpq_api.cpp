@@ -67,6 +67,8 @@ struct cpq_engine {
     double* stageOut = nullptr;
     double* mid = nullptr;      // [nCh][tMax*e->P]             conv <-> EQ hand-off (not used when in place)
     double* heffDev = nullptr;  // staging for one h_eff upload
+    double* gainDev = nullptr;  // [P+1] spectral gains of a FilterSpec
+    bool directHead = false;    // last set_impulse enabled the direct head (affects the processor-level dry delay)
     int64_t heffCap = 0;
     double2* tw512 = nullptr;
     double2* tw1024 = nullptr;
@@ -425,6 +427,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->stageOut, nCh * callSamples * (int64_t)sizeof(double) },
         { (void**)&e->mid, nCh * callSamples * (int64_t)sizeof(double) },
         { (void**)&e->heffDev, e->heffCap * (int64_t)sizeof(double) },
+        { (void**)&e->gainDev, (e->P + 1) * (int64_t)sizeof(double) },
         { (void**)&e->tw512, e->P * (int64_t)sizeof(double2) },
         { (void**)&e->tw1024, e->P * (int64_t)sizeof(double2) },
         { (void**)&e->irSlot, nCh * (int64_t)sizeof(int) },
@@ -541,8 +544,25 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
         return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
     if (irLen > e->desc.max_ir_len) return fail(e, CPQ_ERR_INVALID_ARG, "ir_len %d > max_ir_len %d", irLen, e->desc.max_ir_len);
-    if (spec) return fail(e, CPQ_ERR_UNSUPPORTED, "non-NULL FilterSpec (per-partition HC/LC spectral gains) is not implemented");
-    if (direct) return fail(e, CPQ_ERR_UNSUPPORTED, "direct head is not implemented");
+    // Direct head (<= 32 taps computed in the time domain, src/MKLNonUniformConvolver.cpp:689-731,1169-1232): the taps
+    // are only MOVED from the FFT path to a direct FIR, so h_eff is unchanged and the engine convolves them in the
+    // FFT path (difference: rounding, and the reference's flush of |direct output| < 1e-20).
+    // FilterSpec: the HC/LC gains multiply every partition spectrum of every layer at that layer's FFT size
+    // (:336-443), which this engine reproduces exactly only for a single-layer plan at P == block size.
+    std::vector<double> gains;
+    if (spec) {
+        cpq_nuc_plan sp;
+        if (cpq::computeNucPlan(irLen, e->desc.block_size, direct != 0, spec, &sp) != CPQ_OK)
+            return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
+        if (sp.num_layers != 1)
+            return fail(e, CPQ_ERR_UNSUPPORTED,
+                        "FilterSpec with tail layers: per-layer HC/LC spectral gains need the reference's layer partition sizes");
+        if (e->P != sp.part_size[0])
+            return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec needs partition_size == the reference layer-0 partition (%d)", sp.part_size[0]);
+        if (direct) return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec together with the direct head is not implemented");
+        if (e->desc.semantics != CPQ_SEM_REFERENCE) return fail(e, CPQ_ERR_INVALID_ARG, "FilterSpec requires reference semantics");
+        cpq::spectrumFilterGains(*spec, 2 * e->P, gains);
+    }
 
     CPQ_HIP(e, hipSetDevice(e->device));
     const double* irs[2] = { irL, irR };
@@ -553,7 +573,7 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         cpq_nuc_plan pl;
         int rc;
         if (e->desc.semantics == CPQ_SEM_REFERENCE) {
-            rc = cpq::buildHeff(irs[ch], irLen, e->desc.block_size, scale, nullptr, heff, &pl);
+            rc = cpq::buildHeff(irs[ch], irLen, e->desc.block_size, scale, spec, heff, &pl);
             if (rc != CPQ_OK) return fail(e, rc, "layer plan failed");
             if (!pl.lti_valid)
                 return fail(e, CPQ_ERR_UNSUPPORTED,
@@ -576,11 +596,17 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             CPQ_HIP(e, hipMemsetAsync(HDNs + parts, 0, (size_t)(e->irParts[slot] - parts) * sizeof(double2), e->stream));
         }
         cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Hs, HDNs, tables(e), e->P, parts);
+        if (!gains.empty()) {
+            CPQ_HIP(e, hipMemcpyAsync(e->gainDev, gains.data(), gains.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+            cpq::launch_spectrum_gain(e->stream, Hs, HDNs, e->gainDev, e->P, parts);
+        }
         CPQ_HIP(e, hipGetLastError());
         CPQ_HIP(e, hipStreamSynchronize(e->stream));   // heffDev is reused for the next channel
         e->irParts[slot] = parts;
         e->plan = pl;
+        e->plan.direct_taps = direct ? std::min(irLen, std::min(pl.part_size[0], 32)) : 0;
         e->planValid = true;
+        e->directHead = direct != 0;
     }
     if (stream == CPQ_ALL_STREAMS) {
         for (int c = 0; c < e->nCh; ++c) { e->irSlotHost[c] = c & 1; e->irLoaded[c] = 1; }
@@ -644,7 +670,7 @@ int procDelayOf(const cpq_engine* e, int s)
 {
     // algorithmLatency = conv->latency (layer-0 partSize == block size; direct head unsupported),
     // irPeakLatency clamped like :266-277 (MAX_BLOCK_SIZE 524288, MAX_IR_LATENCY 2^21)
-    const int alg = std::min(e->B, 524288);
+    const int alg = e->directHead ? 0 : std::min(e->B, 524288);     // storedDirectHeadEnabled ? 0 : latency (:266)
     const int peak = std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152);
     return alg + peak;
 }

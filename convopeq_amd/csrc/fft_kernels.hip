@@ -474,6 +474,25 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
         *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(dyn[n].x * s, dyn[n].y * s);
 }
 
+// H[k][bin] *= gain[bin] for the IR partition spectra of one IR slot (the HC/LC spectral shaping of a non-NULL
+// FilterSpec, src/MKLNonUniformConvolver.cpp:433-441); packed bin 0 = (DC * gain[0], Nyquist * gain[P])
+__global__ __launch_bounds__(256) void k_spectrum_gain(double2* __restrict__ H, double2* __restrict__ HDN,
+                                                       const double* __restrict__ gain, int P)
+{
+    const int k = blockIdx.x;
+    double2* row = H + (int64_t)k * P;
+    for (int b = threadIdx.x; b < P; b += blockDim.x) {
+        double2 v = row[b];
+        if (b == 0) {
+            v = make_double2(v.x * gain[0], v.y * gain[P]);
+            HDN[k] = v;
+        } else {
+            v = make_double2(v.x * gain[b], v.y * gain[b]);
+        }
+        row[b] = v;
+    }
+}
+
 template <typename K>
 void allowLargeLds(K kernel, size_t bytes)
 {
@@ -512,6 +531,11 @@ void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, doub
     } else
         hipLaunchKernelGGL(k_ir_spectra_generic, dim3(nParts), dim3(genericThreads(P)), 2 * P * sizeof(double2), stream,
                            heff, heffLen, H, HDN, tw, P);
+}
+
+void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const double* gain, int P, int nParts)
+{
+    hipLaunchKernelGGL(k_spectrum_gain, dim3(nParts), dim3(256), 0, stream, H, HDN, gain, P);
 }
 
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P,

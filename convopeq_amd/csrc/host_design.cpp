@@ -134,6 +134,46 @@ int buildHeff(const double* ir, int irLen, int blockSize, double scale, const cp
     return CPQ_OK;
 }
 
+// MKLNonUniformConvolver::applySpectrumFilter (src/MKLNonUniformConvolver.cpp:336-443): real per-bin gains of the
+// HC (high cut) and LC (low cut) output filters for an N-point frame; gains[0..N/2].
+void spectrumFilterGains(const cpq_filter_spec& spec, int N, std::vector<double>& gains)
+{
+    const double pi = 3.141592653589793238462643383279502884;
+    const double fs = spec.sample_rate;
+    const double nyquist = fs * 0.5;
+    const int halfN = N / 2, cSize = halfN + 1;
+    const double hcStart = (fs <= 48000.0) ? 18000.0 : 22000.0;
+    const double hcEnd = nyquist;
+    const double lcEnd = (spec.lc_mode == 1) ? 6.0 : 8.0;
+    const double lcStart = (spec.lc_mode == 1) ? 15.0 : 18.0;
+    gains.assign((size_t)cSize, 1.0);
+    {
+        const int kS = (int)std::round(hcStart * N / fs);
+        const int kE = std::min(halfN, (int)std::round(hcEnd * N / fs));
+        for (int k = 0; k < cSize; ++k) {
+            if (k <= kS || k > kE) continue;
+            const double x = (double)(k - kS) / (double)(kE - kS);
+            switch (spec.hc_mode) {
+                case 0: gains[k] = 1.0 / std::sqrt(1.0 + std::pow(x, 8.0)); break;
+                case 1: gains[k] = 0.5 * (1.0 + std::cos(pi * x)); break;
+                case 2: gains[k] = std::exp(-4.60517 * x * x); break;
+                default: break;
+            }
+        }
+    }
+    {
+        const int kE = (int)std::round(lcEnd * N / fs);
+        const int kS = (int)std::round(lcStart * N / fs);
+        for (int k = 0; k < cSize; ++k) {
+            if (k <= kE) gains[k] = 0.0;
+            else if (k < kS) {
+                const double x = (double)(k - kE) / (double)std::max(1, kS - kE);
+                gains[k] *= 0.5 * (1.0 - std::cos(pi * x));
+            }
+        }
+    }
+}
+
 // src/eqprocessor/EQProcessor.Coefficients.cpp:84-96 (clamps, float), :101-130, :431-618
 void designSvf(int type, float freq, float gainDb, float q, double sr, cpq_svf_coeffs* c)
 {

@@ -28,6 +28,9 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN,
                        FftTables tw, int P, int nParts);
 
+// H[k][bin] *= gain[bin] (gain has P+1 entries: bins 0..P) for nParts partition spectra
+void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const double* gain, int P, int nParts);
+
 // Y[c][t][bin] = sum_k X[c][slot(head+t-k)][bin] * H[ir(c)][k][bin], bins 1..511 (bin 0 is written but
 // is overwritten by launch_fdl_mac_dcnyq).
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot,

@@ -177,9 +177,12 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
 /* replaces StereoConvolver::init (src/ConvolverProcessor.h:741-814) -> 2 x
  * MKLNonUniformConvolver::SetImpulse(impulse, irLen, blockSize, scale, enableDirectHead, filterSpec)
  * (src/MKLNonUniformConvolver.h:197-200).  stream = index or CPQ_ALL_STREAMS (one shared stereo IR).
- * The caller keeps ownership of ir_l/ir_r (copied).  spec must be NULL in this version: a non-NULL
- * FilterSpec makes the reference apply per-partition HC/LC spectral gains (:336-443) that depend on its
- * own partition sizes -> CPQ_ERR_UNSUPPORTED.  enable_direct_head must be 0 (-> CPQ_ERR_UNSUPPORTED). */
+ * The caller keeps ownership of ir_l/ir_r (copied).
+ * spec: NULL (the primary parity surface), or a FilterSpec whose plan has ONE layer (IR inside layer 0, or tail
+ * disabled / tail mode 2, which truncates the IR to 32 partitions): its HC/LC spectral gains (:336-443) are then
+ * applied to the partition spectra exactly as the reference does.  With tail layers the gains depend on the
+ * reference's per-layer partition sizes -> CPQ_ERR_UNSUPPORTED.
+ * enable_direct_head: accepted; the <= 32 head taps stay in the FFT path (same h_eff, rounding-level difference). */
 int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* ir_l, const double* ir_r,
                              int32_t ir_len, double scale, int32_t enable_direct_head,
                              const cpq_filter_spec* spec);

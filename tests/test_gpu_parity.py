@@ -285,11 +285,8 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     eng.conv_process(x)
     eng.prepare_to_play(48000.0, 4 * B)
     assert np.array_equal(eng.conv_process(x), y1)
-    with pytest.raises(amd.CpqError) as e1:
-        eng.set_impulse(0, ir, ir, spec=amd.FilterSpec.defaults())
-    assert e1.value.status == -5
     with pytest.raises(amd.CpqError) as e2:
-        eng.set_impulse(0, ir, ir, direct_head=True)
+        eng.set_impulse(0, ir, ir, direct_head=True, spec=amd.FilterSpec.defaults())
     assert e2.value.status == -5
     with pytest.raises(amd.CpqError):
         eng.conv_process(x[:, :100])                    # not a multiple of the block size
@@ -304,6 +301,12 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     with pytest.raises(amd.CpqError) as e3:
         eng.set_impulse(0, long_ir, long_ir)
     assert e3.value.status == -5
+    eng.close()
+    # FilterSpec with tail layers: per-layer spectral gains need the reference's layer partition sizes
+    eng = amd.BatchedEngine(1, max_ir_len=131072, max_blocks_per_call=2)
+    with pytest.raises(amd.CpqError) as e4:
+        eng.set_impulse(0, long_ir, long_ir, spec=amd.FilterSpec.defaults())
+    assert e4.value.status == -5
     eng.close()
     with pytest.raises(amd.CpqError):
         amd.BatchedEngine(1, block_size=500, max_ir_len=4096)       # not a power of two
@@ -470,4 +473,53 @@ def test_whole_chain_conv_eq_output_filter(amd, oracle):
         el, er, _ = O.eq_process_stereo(w[0], w[1], po)
         fl, fr, _ = O.outfilter_process_stereo(el, er, q)
         assert rms(y[2 * s] - fl) <= 1e-12 and rms(y[2 * s + 1] - fr) <= 1e-12
+    eng.close()
+
+
+def test_direct_head_is_accepted(amd, oracle):
+    """enableDirectHead only moves <= 32 taps to a time-domain FIR in the reference: same h_eff."""
+    O = oracle
+    irs = [O.gen_ir(3000, channel=ch) for ch in range(2)]
+    x = make_inputs(O, 1, 16 * B)
+    ref = np.empty_like(x)
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], B, scale=0.7, direct=True)
+        ref[c] = nuc.run(x[c], B)
+    eng = amd.BatchedEngine(1, max_ir_len=3000, max_blocks_per_call=4)
+    eng.set_impulse(0, irs[0], irs[1], scale=0.7, direct_head=True)
+    assert eng.plan().direct_taps == 32
+    y = np.concatenate([eng.conv_process(x[:, o:o + 4 * B]) for o in range(0, 16 * B, 4 * B)], axis=1)
+    assert rms(y - ref) <= 1e-13
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=1.0, ir_peak_latency=5)
+    assert eng.convproc_delay(0) == 5          # algorithmLatency = 0 with the direct head (Runtime.cpp:266)
+    eng.close()
+
+
+@pytest.mark.parametrize("kw,ir_len", [(dict(), 4096), (dict(hc_mode=0, lc_mode=1), 5000), (dict(hc_mode=2), 3000),
+                                       (dict(tail_enabled=0), 40000), (dict(tail_mode=2, hc_mode=0), 131072),
+                                       (dict(sample_rate=96000.0, tail_start_seconds=0.2), 9000)])
+def test_filter_spec_single_layer(amd, oracle, kw, ir_len):
+    """non-NULL FilterSpec whose plan has one layer -- HC/LC spectral gains on every partition
+    spectrum (a circular operation inside each 2P frame, finding 5), tail disabled = IR truncated to 32 partitions."""
+    O = oracle
+    names = {"hc_mode": "hcMode", "lc_mode": "lcMode", "tail_enabled": "tailEnabled", "tail_mode": "tailMode",
+             "sample_rate": "sampleRate", "tail_start_seconds": "tailStartSeconds"}
+    sa = amd.FilterSpec.defaults(**kw)
+    so = O.FilterSpec.defaults(applySpectrumFilter=1, **{names[k]: v for k, v in kw.items()})
+    irs = [O.gen_ir(ir_len, channel=ch) for ch in range(2)]
+    T = 8
+    x = make_inputs(O, 1, 6 * T * B)
+    ref = np.empty_like(x)
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], B, spec=so)
+        assert nuc.plan().numLayers == 1
+        ref[c] = nuc.run(x[c], B)
+    eng = amd.BatchedEngine(1, max_ir_len=ir_len, max_blocks_per_call=T)
+    eng.set_impulse(0, irs[0], irs[1], spec=sa)
+    y = np.concatenate([eng.conv_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    err = rms(y - ref)
+    print("filterspec", kw, ir_len, "rms err", err, "signal", rms(ref))
+    assert err <= 1e-13 and rms(ref) > 1e-3
     eng.close()
