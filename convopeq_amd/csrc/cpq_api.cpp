@@ -804,7 +804,7 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
         return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
     if (p->agc_enabled) return fail(e, CPQ_ERR_UNSUPPORTED, "AGC is not implemented");
-    if (p->filter_structure != 0) return fail(e, CPQ_ERR_UNSUPPORTED, "parallel filter structure is not implemented");
+    if (p->filter_structure != 0 && p->filter_structure != 1) return fail(e, CPQ_ERR_INVALID_ARG, "filter_structure must be 0 (serial) or 1 (parallel)");
     for (int b = 0; b < kBands; ++b)
         if (p->bands[b].enabled && (p->bands[b].channel_mode < 0 || p->bands[b].channel_mode > 2))
             return fail(e, CPQ_ERR_UNSUPPORTED, "band %d: Mid/Side channel modes are not implemented", b);
@@ -828,7 +828,7 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             std::memcpy(coef[ch][b], v, sizeof(v));
             // Stereo -> both channels through the packed SSE2+FMA kernel; Left/Right -> one channel, scalar kernel
             const bool on = active && (bp.channel_mode == 0 || bp.channel_mode == 1 + ch);
-            flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0);
+            flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0) | (p->filter_structure == 1 ? 8 : 0);
         }
     }
     const double satGain[2] = { (double)p->nonlinear_saturation, cpq::totalGainLinear(p->total_gain_db) };
@@ -848,6 +848,7 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             hs[ci * 2 + 1] = satGain[1];
         }
     for (int s = s0; s < s1; ++s) std::memcpy(&ht[(size_t)(s - s0) * tp.size()], tp.data(), tp.size() * sizeof(double));
+    if (p->filter_structure == 1) tpSafe = false;     // parallel structure runs on the lane-skewed kernel
     for (int s = s0; s < s1; ++s) e->eqTpSafe[s] = tpSafe ? 1 : 0;
     const size_t c0 = (size_t)s0 * 2;
     CPQ_HIP(e, hipStreamSynchronize(e->stream));

@@ -59,9 +59,12 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
     const bool active = (flag & 1) != 0;
     const bool mono = (flag & 2) != 0;      // Left/Right channel mode -> scalar processBand arithmetic
     const bool df2t = (flag & 4) != 0;      // OutputFilter section: Direct-Form-II-transposed biquad (coef = b0 b1 b2 a1 a2)
+    // FilterStructure::Parallel (Processing.cpp:1164-1226): every band filters the block INPUT; out = src + accum with
+    // accum = (((0 + y_0) - src) + y_1) - src ... in band order.  Bit 3 is set on all 20 band slots of the channel.
+    const bool parallel = (flag & 8) != 0;
     const double oneMinusSat = 1.0 - sat;
 
-    double ylast = 0.0;
+    double ylast = 0.0, xlast = 0.0;
     const int nChunks = nSamples / 64;      // nSamples is a multiple of the 64-sample minimum block
 
     for (int chunk = 0; chunk <= nChunks; ++chunk) {
@@ -76,7 +79,12 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
         for (int i = 0; i < steps; ++i) {
             const int n = chunk * 64 + i - band;                  // sample this lane handles at this step
             const double fromPrev = __shfl_up(ylast, 1);
-            const double v0 = (band == 0) ? xin[chl < kChPerWave ? chl : 0][i & 63] : fromPrev;
+            const double xPrev = __shfl_up(xlast, 1);
+            const double xRaw = xin[chl < kChPerWave ? chl : 0][i & 63];
+            // serial: v0 = previous band's output.  parallel: v0 = the raw input sample, ylast carries the accumulator
+            const double xv = (band == 0) ? xRaw : xPrev;
+            const double accIn = (band == 0) ? 0.0 : fromPrev;
+            const double v0 = parallel ? xv : ((band == 0) ? xRaw : fromPrev);
             if (live && n >= 0 && n < nSamples) {
                 double y = v0;
                 if (active && df2t) {
@@ -128,8 +136,16 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
                         ic2 = sanitize(ic2);
                     }
                 }
-                ylast = y;
-                if (band == kBands - 1) yout[chl][n & 127] = y * gain;
+                if (parallel) {
+                    // accum += work; accum -= src  (juce::FloatVectorOperations::add / subtract, :1195-1198)
+                    const double acc = active ? ((accIn + y) - xv) : accIn;
+                    ylast = acc;
+                    xlast = xv;
+                    if (band == kBands - 1) yout[chl][n & 127] = (xv + acc) * gain;     // block = src + accum (:1220-1221)
+                } else {
+                    ylast = y;
+                    if (band == kBands - 1) yout[chl][n & 127] = y * gain;
+                }
             }
         }
         __syncthreads();

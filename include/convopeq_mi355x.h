@@ -106,7 +106,7 @@ typedef struct {
     float   total_gain_db;
     int32_t agc_enabled;             /* must be 0 (AGC: CPQ_ERR_UNSUPPORTED) */
     float   nonlinear_saturation;    /* default 0.2 */
-    int32_t filter_structure;        /* 0 Serial (1 Parallel: CPQ_ERR_UNSUPPORTED) */
+    int32_t filter_structure;        /* 0 Serial, 1 Parallel (parallel runs on the lane-skewed kernel) */
 } cpq_eq_params;
 
 typedef struct {

@@ -977,6 +977,34 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
     const double gain = gdb > -100.0 ? pow(10.0, gdb * 0.05) : 0.0;
     for (int64_t off = 0; off < n; off += blockSize) {
         const int64_t len = (n - off < blockSize) ? (n - off) : blockSize;
+        if (p->filterStructure == 1) {
+            /* FilterStructure::Parallel, Processing.cpp:1164-1226: out = src + sum over bands of (band(src) - src),
+             * accumulated in band order as accum += work; accum -= src */
+            double* srcL = alloc_d((size_t)len); double* srcR = alloc_d((size_t)len);
+            double* accL = alloc_d((size_t)len); double* accR = alloc_d((size_t)len);
+            double* wrk = alloc_d((size_t)len);
+            memcpy(srcL, dataL + off, sizeof(double) * (size_t)len);
+            memcpy(srcR, dataR + off, sizeof(double) * (size_t)len);
+            for (int b = 0; b < 20; ++b) {
+                if (!active[b]) continue;
+                const int mode = p->bands[b].channelMode;
+                for (int ch = 0; ch < 2; ++ch) {
+                    if (!(mode == 0 || mode == 1 + ch)) continue;
+                    const double* src = ch ? srcR : srcL;
+                    double* acc = ch ? accR : accL;
+                    memcpy(wrk, src, sizeof(double) * (size_t)len);
+                    if (mode == 0) orc_svf_band_stereo_lane(wrk, len, &co[b], state + (ch * 20 + b) * 2, sat);
+                    else           orc_svf_band_mono(wrk, len, &co[b], state + (ch * 20 + b) * 2, sat);
+                    for (int64_t i = 0; i < len; ++i) { acc[i] = acc[i] + wrk[i]; acc[i] = acc[i] - src[i]; }
+                }
+            }
+            for (int64_t i = 0; i < len; ++i) {
+                dataL[off + i] = (srcL[i] + accL[i]) * gain;
+                dataR[off + i] = (srcR[i] + accR[i]) * gain;
+            }
+            free(srcL); free(srcR); free(accL); free(accR); free(wrk);
+            continue;
+        }
         for (int b = 0; b < 20; ++b) {
             if (!active[b]) continue;
             const int mode = p->bands[b].channelMode;

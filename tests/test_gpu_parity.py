@@ -161,6 +161,7 @@ def _copy_params(po, pa):
         b.frequency, b.gain, b.q, b.enabled, b.type, b.channel_mode = o.frequency, o.gain, o.q, o.enabled, o.type, o.channelMode
     pa.nonlinear_saturation = po.nonlinearSaturation
     pa.total_gain_db = po.totalGainDb
+    pa.filter_structure = po.filterStructure
     return pa
 
 
@@ -522,4 +523,27 @@ def test_filter_spec_single_layer(amd, oracle, kw, ir_len):
     err = rms(y - ref)
     print("filterspec", kw, ir_len, "rms err", err, "signal", rms(ref))
     assert err <= 1e-13 and rms(ref) > 1e-3
+    eng.close()
+
+
+@pytest.mark.parametrize("sat", [0.0, 0.2])
+def test_eq_parallel_structure(amd, oracle, sat):
+    """SURVEY N4 (part) / A13: FilterStructure::Parallel -- out = src + sum_b (band_b(src) - src), in band order."""
+    O = oracle
+    S, T = 2, 6
+    x = make_inputs(O, S, 3 * T * B)
+    po = O.eq_params_bench(sat)
+    po.filterStructure = 1
+    po.bands[4].channelMode = 1
+    po.bands[9].channelMode = 2
+    po.bands[13].enabled = 0
+    po.totalGainDb = 1.5
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.profile_enable(True)
+    y = np.concatenate([eng.eq_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    assert eng.profile_read()["k_svf_cascade"][0] == 3
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po)
+        assert np.array_equal(y[2 * s], yl) and np.array_equal(y[2 * s + 1], yr)
     eng.close()
