@@ -322,7 +322,11 @@ bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double*
         if (nq < 1e-22L && std::max(std::fabs(s[0]), std::fabs(s[1])) < 1e-22L) break;
     }
     if (n >= maxIter) return false;
-    return (kappa + l1) < 1.0e5L;
+    // states: |s| <= (kappa + l1) * 1e9 must stay far below the 1e15 guard;
+    // band output: |y_lin| <= (|C|_1 (kappa + l1) + |D|) * 1e9 must stay below it as well (the kernel omits the
+    // output guard on its fast path); |D| <= |C|_1-scale coefficients, bounded here by 1e3 (A^2 at +48 dB = 251)
+    const ld c1 = std::fabs(C[0]) + std::fabs(C[1]);
+    return (kappa + l1) < 1.0e5L && (c1 * (kappa + l1) + 1.0e3L) < 1.0e5L;
 }
 }  // namespace
 

@@ -180,26 +180,33 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * P + bin] = acc[i];
 }
 
-// Packed bin 0 holds (DC, Nyquist): two independent real MACs per (channel, block).
+// Packed bin 0 holds (DC, Nyquist): two independent real MACs per (channel, block).  One wave per (channel,
+// block): lanes stride over the partitions (coalesced reads of the compact XDN / HDN rows), then a wave reduction.
 __global__ __launch_bounds__(256) void k_fdl_mac_dcnyq(const double2* __restrict__ XDN,
                                                        const double2* __restrict__ HDN,
                                                        const int* __restrict__ irSlot, double2* __restrict__ Y,
                                                        int nCh, int K, int ringMask, int head, int T, int hdnStride, int P)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (channel, block) of this wave
     if (idx >= nCh * T) return;
     const int c = idx / T;
     const int t = idx - c * T;
     const double2* __restrict__ x = XDN + (int64_t)c * (ringMask + 1);
     const double2* __restrict__ h = HDN + (int64_t)irSlot[c] * hdnStride;
     double dc = 0.0, ny = 0.0;
-    for (int k = 0; k < K; ++k) {
+    for (int k = lane; k < K; k += 64) {
         const double2 xv = x[(head + t - k) & ringMask];
         const double2 hv = h[k];
         dc = fma(xv.x, hv.x, dc);
         ny = fma(xv.y, hv.y, ny);
     }
-    Y[(int64_t)idx * P] = make_double2(dc, ny);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dc += __shfl_down(dc, off);
+        ny += __shfl_down(ny, off);
+    }
+    if (lane == 0) Y[(int64_t)idx * P] = make_double2(dc, ny);
 }
 
 template <int TT, int PF>
@@ -243,8 +250,8 @@ void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double
 void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2* HDN, const int* irSlot, double2* Y,
                           int P, int nCh, int K, int ringSlots, int head, int T, int hdnStride)
 {
-    const int total = nCh * T;
-    hipLaunchKernelGGL(k_fdl_mac_dcnyq, dim3((total + 255) / 256), dim3(256), 0, stream, XDN, HDN, irSlot, Y, nCh, K,
+    const int total = nCh * T;          // one wave each, 4 waves per block
+    hipLaunchKernelGGL(k_fdl_mac_dcnyq, dim3((total + 3) / 4), dim3(256), 0, stream, XDN, HDN, irSlot, Y, nCh, K,
                        ringSlots - 1, head, T, hdnStride, P);
 }
 
