@@ -102,6 +102,17 @@ struct cpq_engine {
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
 
+    // layered (time-varying) reference semantics: per-layer convolutions + replay of the tail delay-line reader
+    bool layered = false;
+    cpq_nuc_plan layerPlan{};
+    int layerRow[3] = { 0, 0, 0 };      // first IR row of each layer inside a channel's slot
+    int layerK[3] = { 0, 0, 0 };        // partitions per layer
+    double* layerOut = nullptr;         // [nTail][nCh][tMax*P]
+    double* tailRing = nullptr;         // [nTail][nCh][tailRingSlots]
+    int tailRingSlots = 0;
+    void* tailState = nullptr;          // device: callback counter + read cursors
+    long long* tailSched = nullptr;     // device: [nTail][tMax]
+
     // processor-level wrapper (N1)
     int convLevel = CPQ_LEVEL_NUC;
     std::vector<cpq_convproc_params> procParams;   // per stream
@@ -183,6 +194,48 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!cpq_conv_is_ready(e)) return fail(e, CPQ_ERR_NOT_READY, "set_impulse has not covered every stream");
     const int64_t stride = (int64_t)T * e->P;
+    if (e->layered) {
+        const cpq_nuc_plan& pl = e->layerPlan;
+        const int nTail = pl.num_layers - 1;
+        {
+            ProfScope p(e, CPQ_K_RFFT_FWD);
+            cpq::launch_rfft_fwd_ols(e->stream, dIn, stride, e->hist[e->histSel], e->hist[e->histSel ^ 1], e->X, e->XDN,
+                                     tables(e), e->P, e->nCh, T, e->head, e->ringSlots);
+        }
+        for (int l = 0; l < pl.num_layers; ++l) {
+            const int kTile = (e->macTile == 0 && T >= 32) ? 8 : (e->macTile ? e->macTile : 16);
+            const int kPad = (int)alignUp(e->layerK[l], kTile);
+            double* dst = (l == 0) ? dOut : e->layerOut + (int64_t)(l - 1) * e->nCh * stride;
+            {
+                ProfScope p(e, CPQ_K_FDL_MAC);
+                cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H + (int64_t)e->layerRow[l] * e->P, e->irSlot, e->Y,
+                                    e->P, e->nCh, kPad, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P);
+            }
+            {
+                ProfScope p(e, CPQ_K_DCNYQ);
+                cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN + e->layerRow[l], e->irSlot, e->Y, e->P, e->nCh,
+                                          e->layerK[l], e->ringSlots, e->head, T, e->hRows);
+            }
+            {
+                ProfScope p(e, CPQ_K_RFFT_INV);
+                cpq::launch_rfft_inv_ols(e->stream, e->Y, dst, stride, tables(e), e->P, e->nCh, T);
+            }
+        }
+        {
+            ProfScope p(e, CPQ_K_MIX);
+            const int ppc1 = pl.parts_per_callback[1], ppc2 = nTail > 1 ? pl.parts_per_callback[2] : 1;
+            const int d1 = (pl.num_parts_ir[1] + ppc1 - 1) / ppc1 - 1;
+            const int d2 = nTail > 1 ? (pl.num_parts_ir[2] + ppc2 - 1) / ppc2 - 1 : 0;
+            cpq::launch_tail_layers(e->stream, e->tailState, e->tailSched, e->layerOut, e->tailRing, dOut, e->nCh,
+                                    (int)stride, e->B, e->tailRingSlots, nTail, pl.part_size[1], pl.output_delay[1], d1,
+                                    nTail > 1 ? pl.part_size[2] : e->B, nTail > 1 ? pl.output_delay[2] : 0, d2,
+                                    pl.gain[1], nTail > 1 ? pl.gain[2] : 0.0);
+        }
+        CPQ_HIP(e, hipGetLastError());
+        e->head = (e->head + T) & (e->ringSlots - 1);
+        e->histSel ^= 1;
+        return CPQ_OK;
+    }
     {
         ProfScope p(e, CPQ_K_RFFT_FWD);
         cpq::launch_rfft_fwd_ols(e->stream, dIn, stride, e->hist[e->histSel], e->hist[e->histSel ^ 1], e->X, e->XDN,
@@ -190,7 +243,8 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     }
     {
         ProfScope p(e, CPQ_K_FDL_MAC);
-        cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh, e->kActive, e->ringSlots,
+        cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh,
+                            (int)alignUp(e->kMaxReal, (e->macTile == 0 && T >= 32) ? 8 : (e->macTile ? e->macTile : 16)), e->ringSlots,
                             e->head, T, (int64_t)e->hRows * e->P);
     }
     {
@@ -269,6 +323,8 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * e->P * sizeof(double), e->stream));
         e->head = 0;
         e->histSel = 0;
+        if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 3 * sizeof(long long), e->stream));
+        if (e->tailRing) CPQ_HIP(e, hipMemsetAsync(e->tailRing, 0, sizeof(double) * (size_t)(e->layerPlan.num_layers - 1) * e->nCh * e->tailRingSlots, e->stream));
         for (double* p : { e->dryHist[0], e->dryHist[1] })
             if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, (size_t)e->nCh * e->dryHistCap * sizeof(double), e->stream));
     }
@@ -407,7 +463,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     const int taps = (d->semantics == CPQ_SEM_REFERENCE) ? std::max(pl.heff_len, d->max_ir_len) : d->max_ir_len;
     const int kReal = (taps + e->P - 1) / e->P;
     e->kCap = (int)alignUp(kReal, cpq::kMacMaxTile);
-    e->hRows = e->kCap + cpq::kMacMaxTile;   // zero rows read by the prefetch past the last partition
+    e->hRows = e->kCap + 4 * cpq::kMacMaxTile;   // zero rows read by the prefetch past the last partition (per layer in layered mode)
     e->ringSlots = nextPow2(e->kCap + cpq::kMacMaxTile + e->tMax);
     e->heffCap = (int64_t)e->kCap * e->P;
 
@@ -495,7 +551,9 @@ void cpq_engine_destroy(cpq_engine* e)
         for (auto& ev : s.freeList) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     }
     if (e->arena) (void)hipFree(e->arena);
-    for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy }) if (p) (void)hipFree(p);
+    for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing }) if (p) (void)hipFree(p);
+    if (e->tailState) (void)hipFree(e->tailState);
+    if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
     if (e->procDelay) (void)hipFree(e->procDelay);
     delete e;
@@ -569,9 +627,77 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     // IR slots: stream s owns slots 2s, 2s+1; CPQ_ALL_STREAMS shares slots 0 and 1 between all streams
     const int slotBase = (stream == CPQ_ALL_STREAMS) ? 0 : 2 * stream;
     std::vector<double> heff;
+    // does the reference stay LTI for this IR length / block size?  If not (tail partition longer than the IR that
+    // precedes it), switch the engine to layered mode: one convolution per layer + replay of the delay-line reader.
+    bool wantLayered = false;
+    if (e->desc.semantics == CPQ_SEM_REFERENCE && !spec) {
+        cpq_nuc_plan probe;
+        if (cpq::computeNucPlan(irLen, e->desc.block_size, false, nullptr, &probe) != CPQ_OK)
+            return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
+        wantLayered = !probe.lti_valid && probe.num_layers > 1;
+        if (wantLayered) {
+            if (e->P != e->B)
+                return fail(e, CPQ_ERR_UNSUPPORTED, "time-varying reference semantics need partition_size == block_size");
+            bool anyLoaded = false;
+            for (char l : e->irLoaded) anyLoaded = anyLoaded || l;
+            if (anyLoaded && (!e->layered || std::memcmp(&probe, &e->layerPlan, sizeof(probe)) != 0))
+                return fail(e, CPQ_ERR_UNSUPPORTED, "time-varying reference semantics need the same IR length on every stream");
+            if (!e->layered) {
+                // lazily allocate the per-layer buffers
+                const int nTail = probe.num_layers - 1;
+                int span = 0;
+                for (int l = 1; l < probe.num_layers; ++l) span = std::max(span, probe.output_delay[l] + 2 * probe.part_size[l]);
+                e->tailRingSlots = nextPow2(span + 2 * e->B + e->tMax * e->P);
+                const size_t callSamples = (size_t)e->tMax * e->P;
+                if (hipMalloc((void**)&e->layerOut, sizeof(double) * nTail * e->nCh * callSamples) != hipSuccess ||
+                    hipMalloc((void**)&e->tailRing, sizeof(double) * (size_t)nTail * e->nCh * e->tailRingSlots) != hipSuccess ||
+                    hipMalloc(&e->tailState, 3 * sizeof(long long)) != hipSuccess ||
+                    hipMalloc((void**)&e->tailSched, sizeof(long long) * 2 * (size_t)e->tMax) != hipSuccess)
+                    return fail(e, CPQ_ERR_OOM, "layered-mode buffers could not be allocated");
+                CPQ_HIP(e, hipMemset(e->tailRing, 0, sizeof(double) * (size_t)nTail * e->nCh * e->tailRingSlots));
+                CPQ_HIP(e, hipMemset(e->tailState, 0, 3 * sizeof(long long)));
+                e->layerPlan = probe;
+                int row = 0;
+                for (int l = 0; l < probe.num_layers; ++l) {
+                    e->layerRow[l] = row;
+                    e->layerK[l] = (probe.len[l] + e->P - 1) / e->P;
+                    row += (int)alignUp(e->layerK[l], cpq::kMacMaxTile) + cpq::kMacMaxTile;
+                }
+                if (row > e->hRows) return fail(e, CPQ_ERR_INVALID_ARG, "layered IR needs %d rows, capacity %d", row, e->hRows);
+                e->layered = true;
+            }
+        } else if (e->layered) {
+            return fail(e, CPQ_ERR_UNSUPPORTED, "engine is in time-varying (layered) mode: every IR must share that plan");
+        }
+    }
+
     for (int ch = 0; ch < 2; ++ch) {
         cpq_nuc_plan pl;
         int rc;
+        const int slot = slotBase + ch;
+        double2* Hs = e->H + (int64_t)slot * e->hRows * e->P;
+        double2* HDNs = e->HDN + (int64_t)slot * e->hRows;
+        if (wantLayered) {
+            pl = e->layerPlan;
+            CPQ_HIP(e, hipMemsetAsync(Hs, 0, (size_t)e->hRows * e->P * sizeof(double2), e->stream));
+            CPQ_HIP(e, hipMemsetAsync(HDNs, 0, (size_t)e->hRows * sizeof(double2), e->stream));
+            const bool scaled = std::abs(scale - 1.0) > 1e-12;
+            for (int l = 0; l < pl.num_layers; ++l) {
+                heff.assign(irs[ch] + pl.offset[l], irs[ch] + pl.offset[l] + pl.len[l]);
+                if (scaled) for (double& v : heff) v *= scale;
+                CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Hs + (int64_t)e->layerRow[l] * e->P,
+                                       HDNs + e->layerRow[l], tables(e), e->P, e->layerK[l]);
+                CPQ_HIP(e, hipGetLastError());
+                CPQ_HIP(e, hipStreamSynchronize(e->stream));
+            }
+            e->irParts[slot] = e->hRows;
+            e->plan = pl;
+            e->plan.direct_taps = direct ? std::min(irLen, std::min(pl.part_size[0], 32)) : 0;
+            e->planValid = true;
+            e->directHead = direct != 0;
+            continue;
+        }
         if (e->desc.semantics == CPQ_SEM_REFERENCE) {
             rc = cpq::buildHeff(irs[ch], irLen, e->desc.block_size, scale, spec, heff, &pl);
             if (rc != CPQ_OK) return fail(e, rc, "layer plan failed");
@@ -586,10 +712,7 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         }
         const int parts = ((int)heff.size() + e->P - 1) / e->P;
         if (parts > e->kCap) return fail(e, CPQ_ERR_INVALID_ARG, "h_eff needs %d partitions, capacity %d", parts, e->kCap);
-        const int slot = slotBase + ch;
         CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        double2* Hs = e->H + (int64_t)slot * e->hRows * e->P;
-        double2* HDNs = e->HDN + (int64_t)slot * e->hRows;
         // stale partitions of a longer previous IR in this slot become zero rows
         if (e->irParts[slot] > parts) {
             CPQ_HIP(e, hipMemsetAsync(Hs + (int64_t)parts * e->P, 0, (size_t)(e->irParts[slot] - parts) * e->P * sizeof(double2), e->stream));

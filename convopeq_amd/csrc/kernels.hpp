@@ -68,4 +68,11 @@ void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dr
                          int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
                          double* histNew, int histCap, int wetValid);
 
+// Layered (time-varying) reference semantics: replay of the reference's tail delay-line reader on per-layer
+// natural-time convolutions.  state: 3 long long (callback counter, read cursors), sched: [nTail][T] long long,
+// layerOut: [nTail][nCh][nSamples], ring: [nTail][nCh][ringSlots]; out already holds the layer-0 convolution.
+void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,
+                        double* out, int nCh, int nSamples, int B, int ringSlots, int nTail, int pl1, int ol1, int d1,
+                        int pl2, int ol2, int d2, double g1, double g2);
+
 }  // namespace cpq

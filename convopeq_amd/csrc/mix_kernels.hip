@@ -48,7 +48,100 @@ __global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, const d
         hn[i] = dry_at(ho, x, histCap, nSamples - histCap + i);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Layered (time-varying) reference semantics.  When a tail layer's partition is longer than the IR that precedes it
+// (partSize_L > outputDelaySamples_L, e.g. block 1024 with the default tail start), the reference's delay-line
+// reader (delayLineReadAdd, src/MKLNonUniformConvolver.cpp:1653-1688) skips ahead after every tail block and then
+// runs dry until the next one: the output is NOT one linear convolution.  The engine then convolves every layer
+// segment separately (natural time, no offset) and replays the reader on those streams:
+//   out[cB + j] = (x*h0)[cB + j] + sum_L g_L * ynat_L[start_L(c) + j]   when callback c reads, else no tail term.
+
+struct TailState {            // device-resident, zeroed by reset
+    long long cb;             // callbacks (blocks of B) processed since reset
+    long long R[2];           // delayReadCursor of tail layers 1, 2
+};
+
+// one thread per tail layer replays the reader for the T callbacks of this call
+__global__ void k_tail_schedule(TailState* st, long long* __restrict__ sched, int T, int B, int nTail, int2 l1, int2 l2,
+                                int d1, int d2)
+{
+    const int l = threadIdx.x;
+    const long long cb0 = st->cb;
+    if (l < nTail) {
+        const int PL = l == 0 ? l1.x : l2.x;       // layer partition size
+        const int oL = l == 0 ? l1.y : l2.y;       // outputDelaySamples
+        const int D = l == 0 ? d1 : d2;            // callbacks between partition fill and delay-line write
+        const int bpp = PL / B;
+        long long R = st->R[l];
+        for (int i = 0; i < T; ++i) {
+            const long long c = cb0 + i;
+            const long long done = (c - D + 1 > 0) ? (c - D + 1) / bpp : 0;
+            const long long W = done * PL;                               // delayWriteCursor after Add() of callback c
+            const long long maxRead = W - oL > 0 ? W - oL : 0;
+            const long long start = R > maxRead ? R : maxRead;
+            if (start + B > W) sched[(long long)l * T + i] = -1;         // "writer not far enough ahead": skip
+            else { sched[(long long)l * T + i] = start; R = start + B; }
+        }
+        st->R[l] = R;
+    }
+    __syncthreads();
+    if (l == 0) st->cb = cb0 + T;
+}
+
+// append this call's natural-time tail outputs to the per-layer rings at (global sample index & mask); runs BEFORE
+// the schedule kernel advances the callback counter
+__global__ __launch_bounds__(256) void k_tail_append(const double* __restrict__ layerOut, double* __restrict__ ring,
+                                                     const TailState* __restrict__ st, int nSamples, int B, int ringMask)
+{
+    const int v = blockIdx.y;                      // (tail layer, channel)
+    const double* src = layerOut + (long long)v * nSamples;
+    double* dst = ring + (long long)v * (ringMask + 1);
+    const long long g0 = st->cb * (long long)B;    // global index of the call's first sample
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nSamples; i += stride)
+        dst[(g0 + i) & ringMask] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_layer_combine(double* out, const double* __restrict__ ring,
+                                                       const long long* __restrict__ sched, int nCh, int nSamples,
+                                                       int T, int B, int ringMask, int nTail, double g1, double g2)
+{
+    const int c = blockIdx.y;
+    double* o = out + (long long)c * nSamples;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nSamples; i += stride) {
+        const int cbk = i / B, j = i - cbk * B;
+        double y = o[i];
+        for (int l = 0; l < nTail; ++l) {
+            const long long s = sched[(long long)l * T + cbk];
+            if (s >= 0) {
+                const double g = l == 0 ? g1 : g2;
+                const double t = ring[((long long)l * nCh + c) * (ringMask + 1) + ((s + j) & ringMask)];
+                // delayLineReadAdd: dst += src (gain within 1e-12 of 1) else dst += src * gain (:1673-1676)
+                y = (fabs(g - 1.0) < 1.0e-12) ? (y + t) : (y + t * g);
+            }
+        }
+        o[i] = y;
+    }
+}
+
 }  // namespace
+
+void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,
+                        double* out, int nCh, int nSamples, int B, int ringSlots, int nTail, int pl1, int ol1, int d1,
+                        int pl2, int ol2, int d2, double g1, double g2)
+{
+    const int T = nSamples / B;
+    TailState* st = reinterpret_cast<TailState*>(state);
+    int bx = (nSamples + 255) / 256;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(k_tail_append, dim3(bx, nCh * nTail), dim3(256), 0, stream, layerOut, ring, st, nSamples, B,
+                       ringSlots - 1);
+    hipLaunchKernelGGL(k_tail_schedule, dim3(1), dim3(64), 0, stream, st, sched, T, B, nTail, make_int2(pl1, ol1),
+                       make_int2(pl2, ol2), d1, d2);
+    hipLaunchKernelGGL(k_layer_combine, dim3(bx, nCh), dim3(256), 0, stream, out, ring, sched, nCh, nSamples, T, B,
+                       ringSlots - 1, nTail, g1, g2);
+}
 
 void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dryIn, double* out, int64_t chStride,
                          int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
