@@ -102,6 +102,15 @@ struct cpq_engine {
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
 
+    // EQ AGC (allocated on first use)
+    std::vector<int> agcOnHost;
+    bool anyAgc = false;
+    int* agcOn = nullptr;           // [streams]
+    double* agcState = nullptr;     // [streams][3]
+    double* agcRmsIn = nullptr;     // [nCh][callbacks]
+    double* agcRmsOut = nullptr;
+    double* agcGains = nullptr;     // [streams][callbacks][2]
+
     // layered (time-varying) reference semantics: per-layer convolutions + replay of the tail delay-line reader
     bool layered = false;
     cpq_nuc_plan layerPlan{};
@@ -285,8 +294,27 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
     bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO);
     for (char s : e->eqTpSafe) tp = tp && s;
-    return enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
-                          e->svfState, e->svfTp);
+    const int n = T * e->P;
+    const int cbs = n / e->B;            // callback blocks in this call (AGC is block-rate)
+    if (e->anyAgc) {
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_agc_block_rms(e->stream, dIn, (int64_t)n, e->nCh, e->B, cbs, e->agcRmsIn);     // cachedInputRMS (:1116-1127)
+    }
+    const int rc = enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
+                                  e->svfState, e->svfTp);
+    if (rc != CPQ_OK || !e->anyAgc) return rc;
+    {
+        ProfScope p(e, CPQ_K_MIX);
+        // block coefficients of the tables prepareToPlay builds (src/eqprocessor/EQProcessor.Core.cpp:776-784)
+        const double nn = (double)e->B, sr = e->sampleRate;
+        const double bAtt = 1.0 - std::exp(-nn / (sr * 0.2)), bRel = 1.0 - std::exp(-nn / (sr * 2.0)),
+                     bSm = 1.0 - std::exp(-nn / (sr * 0.2));
+        cpq::launch_agc_block_rms(e->stream, dOut, (int64_t)n, e->nCh, e->B, cbs, e->agcRmsOut);
+        cpq::launch_agc_apply(e->stream, dOut, (int64_t)n, e->desc.n_streams, e->B, cbs, e->agcRmsIn, e->agcRmsOut,
+                              e->agcState, e->agcOn, e->agcGains, bAtt, bRel, bSm);
+    }
+    CPQ_HIP(e, hipGetLastError());
+    return CPQ_OK;
 }
 
 int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T)
@@ -331,6 +359,7 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
     if (eq) {
         CPQ_HIP(e, hipMemsetAsync(e->svfState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
         CPQ_HIP(e, hipMemsetAsync(e->ofState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
+        if (e->agcState) CPQ_HIP(e, hipMemsetAsync(e->agcState, 0, (size_t)e->desc.n_streams * 3 * sizeof(double), e->stream));
     }
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     return CPQ_OK;
@@ -533,6 +562,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->irParts.assign(e->nCh, 0);
     e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
     e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0 });
+    e->agcOnHost.assign(d->n_streams, 0);
     if (hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice) != hipSuccess) {
         cpq_engine_destroy(e);
         return fail(nullptr, CPQ_ERR_DEVICE, "irSlot upload failed");
@@ -551,7 +581,8 @@ void cpq_engine_destroy(cpq_engine* e)
         for (auto& ev : s.freeList) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     }
     if (e->arena) (void)hipFree(e->arena);
-    for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing }) if (p) (void)hipFree(p);
+    for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
+    if (e->agcOn) (void)hipFree(e->agcOn);
     if (e->tailState) (void)hipFree(e->tailState);
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
@@ -926,7 +957,6 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     if (!e || !p) return CPQ_ERR_INVALID_ARG;
     if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
         return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
-    if (p->agc_enabled) return fail(e, CPQ_ERR_UNSUPPORTED, "AGC is not implemented");
     if (p->filter_structure != 0 && p->filter_structure != 1) return fail(e, CPQ_ERR_INVALID_ARG, "filter_structure must be 0 (serial) or 1 (parallel)");
     for (int b = 0; b < kBands; ++b)
         if (p->bands[b].enabled && (p->bands[b].channel_mode < 0 || p->bands[b].channel_mode > 2))
@@ -954,7 +984,8 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0) | (p->filter_structure == 1 ? 8 : 0);
         }
     }
-    const double satGain[2] = { (double)p->nonlinear_saturation, cpq::totalGainLinear(p->total_gain_db) };
+    // with AGC the total-gain ramp is replaced by processAGC (Processing.cpp:1256-1259): unity gain in the cascade kernel
+    const double satGain[2] = { (double)p->nonlinear_saturation, p->agc_enabled ? 1.0 : cpq::totalGainLinear(p->total_gain_db) };
 
     CPQ_HIP(e, hipSetDevice(e->device));
     const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
@@ -980,6 +1011,25 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     CPQ_HIP(e, hipMemcpy(e->svfSatGain + c0 * 2, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->svfTp + (size_t)s0 * tp.size(), ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
     e->eqSet = true;   // streams never given parameters keep all bands inactive (pass-through)
+    for (int s = s0; s < s1; ++s) e->agcOnHost[s] = p->agc_enabled ? 1 : 0;
+    e->anyAgc = false;
+    for (int v : e->agcOnHost) e->anyAgc = e->anyAgc || v;
+    if (e->anyAgc) {
+        const int S = e->desc.n_streams;
+        const size_t cbMax = (size_t)e->tMax * e->P / e->B;
+        if (!e->agcOn) {
+            if (hipMalloc((void**)&e->agcOn, sizeof(int) * S) != hipSuccess ||
+                hipMalloc((void**)&e->agcState, sizeof(double) * 3 * S) != hipSuccess ||
+                hipMalloc((void**)&e->agcRmsIn, sizeof(double) * e->nCh * cbMax) != hipSuccess ||
+                hipMalloc((void**)&e->agcRmsOut, sizeof(double) * e->nCh * cbMax) != hipSuccess ||
+                hipMalloc((void**)&e->agcGains, sizeof(double) * 2 * S * cbMax) != hipSuccess)
+                return fail(e, CPQ_ERR_OOM, "AGC buffers could not be allocated");
+            CPQ_HIP(e, hipMemset(e->agcState, 0, sizeof(double) * 3 * S));
+        }
+        CPQ_HIP(e, hipMemcpy(e->agcOn, e->agcOnHost.data(), sizeof(int) * S, hipMemcpyHostToDevice));
+    } else if (e->agcOn) {
+        CPQ_HIP(e, hipMemcpy(e->agcOn, e->agcOnHost.data(), sizeof(int) * e->desc.n_streams, hipMemcpyHostToDevice));
+    }
     return CPQ_OK;
 }
 

@@ -68,6 +68,14 @@ void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dr
                          int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
                          double* histNew, int histCap, int wetValid);
 
+// EQ AGC (EQProcessor::processAGC): per-callback-block RMS in the reference's accumulation order, then envelopes /
+// gain per block (one thread per stream) and the linear gain ramp with the reference's incremental-add pattern.
+// rms: [nCh][T]; state: [S][3] = envIn, envOut, gain-1; gains: [S][T][2] = start gain, per-sample increment.
+void launch_agc_block_rms(hipStream_t stream, const double* x, int64_t chStride, int nCh, int B, int T, double* rms);
+void launch_agc_apply(hipStream_t stream, double* data, int64_t chStride, int S, int B, int T, const double* rmsIn,
+                      const double* rmsOut, double* state, const int* agcOn, double* gains, double bAtt, double bRel,
+                      double bSm);
+
 // Layered (time-varying) reference semantics: replay of the reference's tail delay-line reader on per-layer
 // natural-time convolutions.  state: 3 long long (callback counter, read cursors), sched: [nTail][T] long long,
 // layerOut: [nTail][nCh][nSamples], ring: [nTail][nCh][ringSlots]; out already holds the layer-0 convolution.

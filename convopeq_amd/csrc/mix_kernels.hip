@@ -125,6 +125,112 @@ __global__ __launch_bounds__(256) void k_layer_combine(double* out, const double
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// AGC of the EQ (EQProcessor::processAGC, src/eqprocessor/EQProcessor.Processing.cpp:367-445): block-rate RMS
+// envelopes, one gain per callback block, applied as a linear ramp.  The arithmetic replays the reference's
+// accumulation orders so the result is bit-identical given the same inputs.
+
+// calculateRMS (:21-52): four FMA accumulator lanes over i%4, summed left to right, sqrt(sum / n).
+// 4 threads per (channel, block); 16 such groups per wave.
+__global__ __launch_bounds__(64) void k_agc_block_rms(const double* __restrict__ x, int64_t chStride, int nCh, int B, int T,
+                                                      double* __restrict__ rms)
+{
+    const int grp = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const int j = threadIdx.x & 3;
+    const bool live = grp < nCh * T;
+    const int c = live ? grp / T : 0;
+    const int t = live ? grp - c * T : 0;
+    const double* d = x + (int64_t)c * chStride + (int64_t)t * B;
+    double acc = 0.0;
+    if (live)
+        for (int i = j; i < B; i += 4) acc = fma(d[i], d[i], acc);
+    const int base = threadIdx.x & ~3;
+    const double a0 = __shfl(acc, base), a1 = __shfl(acc, base + 1), a2 = __shfl(acc, base + 2), a3 = __shfl(acc, base + 3);
+    if (live && j == 0) {
+        const double sumSq = ((a0 + a1) + a2) + a3;
+        rms[grp] = sqrt(sumSq / (double)B);
+    }
+}
+
+// one thread per stream walks the callbacks of the call: envelopes, target gain, smoothed gain (:411-438)
+__global__ __launch_bounds__(64) void k_agc_gains(const double* __restrict__ rmsIn, const double* __restrict__ rmsOut,
+                                                  double* __restrict__ state, const int* __restrict__ agcOn,
+                                                  double* __restrict__ gains, int S, int T, int B, double bAtt, double bRel,
+                                                  double bSm)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S || !agcOn[s]) return;
+    double envIn = state[3 * s], envOut = state[3 * s + 1], cur = state[3 * s + 2] + 1.0;
+    for (int t = 0; t < T; ++t) {
+        double inR = fmax(rmsIn[(2 * s) * T + t], rmsIn[(2 * s + 1) * T + t]);        // max over channels, starting from 0
+        double outR = fmax(rmsOut[(2 * s) * T + t], rmsOut[(2 * s + 1) * T + t]);
+        inR = fmax(inR, 0.0); outR = fmax(outR, 0.0);
+        if (!((inR - inR) == 0.0) || inR > 1000.0) inR = 1000.0;
+        if (!((outR - outR) == 0.0) || outR > 1000.0) outR = 1000.0;
+        const double inA = (inR > envIn) ? bAtt : bRel;
+        const double outA = (outR > envOut) ? bAtt : bRel;
+        envIn = envIn * (1.0 - inA) + inR * inA;
+        envOut = envOut * (1.0 - outA) + outR * outA;
+        if (envIn < 1.0e-20) envIn = 0.0;
+        if (envOut < 1.0e-20) envOut = 0.0;
+        double target = 1.0;                                   // calculateAGCGain (:343-358)
+        if (!(envOut < 1.0e-6)) {
+            const double ratio = envIn / envOut;
+            if (!(ratio > 1.0 / 1.059 && ratio < 1.059)) {
+                const double lo = (double)0.06f, hi = (double)16.0f;
+                target = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+            }
+        }
+        const double next = cur * (1.0 - bSm) + target * bSm;
+        gains[((int64_t)s * T + t) * 2] = cur;
+        gains[((int64_t)s * T + t) * 2 + 1] = (next - cur) / (double)B;
+        cur = next;
+    }
+    state[3 * s] = envIn; state[3 * s + 1] = envOut; state[3 * s + 2] = cur - 1.0;
+}
+
+// applyGainRamp_AVX2 (:279-337): gain of sample i = 16 m + 4 q + j is lane j's start value advanced m times by
+// 16*inc and then q times by 4*inc, each advance a separate rounded addition
+__global__ __launch_bounds__(256) void k_agc_ramp(double* data, int64_t chStride, const double* __restrict__ gains,
+                                                  const int* __restrict__ agcOn, int B, int T)
+{
+    const int c = blockIdx.y;
+    const int s = c >> 1;
+    if (!agcOn[s]) return;
+    double* d = data + (int64_t)c * chStride;
+    const int n = B * T;
+    const int stride = gridDim.x * blockDim.x;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+        const int t = idx / B, i = idx - t * B;
+        const double start = gains[((int64_t)s * T + t) * 2], inc = gains[((int64_t)s * T + t) * 2 + 1];
+        const int j = i & 3, q = (i >> 2) & 3, mm = i >> 4;
+        double g = (j == 0) ? start : (j == 1 ? start + inc : (j == 2 ? start + 2.0 * inc : start + 3.0 * inc));
+        const double inc4 = 4.0 * inc, inc16 = 16.0 * inc;
+        for (int k = 0; k < mm; ++k) g = g + inc16;
+        for (int k = 0; k < q; ++k) g = g + inc4;
+        d[idx] *= g;
+    }
+}
+
+}  // namespace
+
+void launch_agc_block_rms(hipStream_t stream, const double* x, int64_t chStride, int nCh, int B, int T, double* rms)
+{
+    hipLaunchKernelGGL(k_agc_block_rms, dim3((nCh * T + 15) / 16), dim3(64), 0, stream, x, chStride, nCh, B, T, rms);
+}
+
+void launch_agc_apply(hipStream_t stream, double* data, int64_t chStride, int S, int B, int T, const double* rmsIn,
+                      const double* rmsOut, double* state, const int* agcOn, double* gains, double bAtt, double bRel,
+                      double bSm)
+{
+    hipLaunchKernelGGL(k_agc_gains, dim3((S + 63) / 64), dim3(64), 0, stream, rmsIn, rmsOut, state, agcOn, gains, S, T, B,
+                       bAtt, bRel, bSm);
+    int bx = (B * T + 255) / 256;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(k_agc_ramp, dim3(bx, 2 * S), dim3(256), 0, stream, data, chStride, gains, agcOn, B, T);
+}
+
+namespace {
 }  // namespace
 
 void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,

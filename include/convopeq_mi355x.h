@@ -104,7 +104,7 @@ typedef struct {
 typedef struct {
     cpq_eq_band bands[CPQ_NUM_BANDS];
     float   total_gain_db;
-    int32_t agc_enabled;             /* must be 0 (AGC: CPQ_ERR_UNSUPPORTED) */
+    int32_t agc_enabled;             /* block-rate AGC (processAGC): replaces the total-gain stage */
     float   nonlinear_saturation;    /* default 0.2 */
     int32_t filter_structure;        /* 0 Serial, 1 Parallel (parallel runs on the lane-skewed kernel) */
 } cpq_eq_params;

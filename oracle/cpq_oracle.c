@@ -962,6 +962,44 @@ void orc_svf_band_mono(double* data, int64_t n, const orc_svf_coeffs* c,
     state[0] = ic1; state[1] = ic2;
 }
 
+/* calculateRMS, Processing.cpp:21-52: four FMA accumulator lanes, summed left to right, scalar tail, sqrt(sum/n) */
+static double rms_avx_pattern(const double* d, int n)
+{
+    if (!d || n <= 0) return 0.0;
+    double acc[4] = { 0, 0, 0, 0 };
+    int i = 0;
+    const int vEnd = n / 4 * 4;
+    for (; i < vEnd; i += 4)
+        for (int j = 0; j < 4; ++j) acc[j] = fma(d[i + j], d[i + j], acc[j]);
+    double sumSq = acc[0] + acc[1] + acc[2] + acc[3];
+    for (; i < n; ++i) sumSq += d[i] * d[i];
+    return sqrt(sumSq / (double)n);
+}
+
+/* applyGainRamp_AVX2, Processing.cpp:279-337: four gain lanes advanced by repeated additions of 4*inc / 16*inc */
+static void gain_ramp_avx_pattern(double* data, int n, double startGain, double inc)
+{
+    double vg[4] = { startGain, startGain + inc, startGain + 2.0 * inc, startGain + 3.0 * inc };
+    const double inc4 = 4.0 * inc, inc16 = 16.0 * inc;
+    int i = 0;
+    const int vEnd16 = n / 16 * 16, vEnd4 = n / 4 * 4;
+    for (; i < vEnd16; i += 16) {
+        double g[4];
+        for (int j = 0; j < 4; ++j) g[j] = vg[j];
+        for (int q = 0; q < 4; ++q) {
+            for (int j = 0; j < 4; ++j) data[i + 4 * q + j] *= g[j];
+            if (q < 3) for (int j = 0; j < 4; ++j) g[j] = g[j] + inc4;
+        }
+        for (int j = 0; j < 4; ++j) vg[j] = vg[j] + inc16;
+    }
+    for (; i < vEnd4; i += 4) {
+        for (int j = 0; j < 4; ++j) data[i + j] *= vg[j];
+        for (int j = 0; j < 4; ++j) vg[j] = vg[j] + inc4;
+    }
+    double gain = startGain + (double)i * inc;
+    for (; i < n; ++i) { data[i] *= gain; gain += inc; }
+}
+
 void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSize,
                            const orc_eq_params* p, double sr, double* state)
 {
@@ -975,8 +1013,16 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
     /* juce::Decibels::decibelsToGain<double>: > -100 dB ? 10^(dB/20) : 0 (EQProcessor.h:450) */
     const double gdb = (double)p->totalGainDb;
     const double gain = gdb > -100.0 ? pow(10.0, gdb * 0.05) : 0.0;
+    /* AGC state lives behind the filter states: state[80..82] = envIn, envOut, currentGain-1 (stored as gain-1 so a
+     * zeroed state means unity gain, rtAgcCurrentGainShadow's initial value) */
     for (int64_t off = 0; off < n; off += blockSize) {
         const int64_t len = (n - off < blockSize) ? (n - off) : blockSize;
+        double inputRMS = 0.0;
+        if (p->agcEnabled) {      /* Processing.cpp:1116-1127 */
+            const double r0 = rms_avx_pattern(dataL + off, (int)len), r1 = rms_avx_pattern(dataR + off, (int)len);
+            if (r0 > inputRMS) inputRMS = r0;
+            if (r1 > inputRMS) inputRMS = r1;
+        }
         if (p->filterStructure == 1) {
             /* FilterStructure::Parallel, Processing.cpp:1164-1226: out = src + sum over bands of (band(src) - src),
              * accumulated in band order as accum += work; accum -= src */
@@ -999,12 +1045,11 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
                 }
             }
             for (int64_t i = 0; i < len; ++i) {
-                dataL[off + i] = (srcL[i] + accL[i]) * gain;
-                dataR[off + i] = (srcR[i] + accR[i]) * gain;
+                dataL[off + i] = (srcL[i] + accL[i]);
+                dataR[off + i] = (srcR[i] + accR[i]);
             }
             free(srcL); free(srcR); free(accL); free(accR); free(wrk);
-            continue;
-        }
+        } else {
         for (int b = 0; b < 20; ++b) {
             if (!active[b]) continue;
             const int mode = p->bands[b].channelMode;
@@ -1017,8 +1062,39 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
                 orc_svf_band_mono(dataR + off, len, &co[b], state + (1 * 20 + b) * 2, sat);
             }
         }
-        /* steady-state total gain: startGain == endGain, increment 0 (Processing.cpp:1262-1274) */
-        for (int64_t i = 0; i < len; ++i) { dataL[off + i] *= gain; dataR[off + i] *= gain; }
+        }
+        if (p->agcEnabled) {
+            /* processAGC, Processing.cpp:367-445; block coefficients from the tables of prepareToPlay
+             * (EQProcessor.Core.cpp:776-784): 1 - exp(-n / (sr * tau)), tau = 0.2 / 2.0 / 0.2 s */
+            const double nn = (double)len;
+            const double bAtt = 1.0 - exp(-nn / (sr * 0.2)), bRel = 1.0 - exp(-nn / (sr * 2.0)), bSm = 1.0 - exp(-nn / (sr * 0.2));
+            double outputRMS = 0.0;
+            const double r0 = rms_avx_pattern(dataL + off, (int)len), r1 = rms_avx_pattern(dataR + off, (int)len);
+            if (r0 > outputRMS) outputRMS = r0;
+            if (r1 > outputRMS) outputRMS = r1;
+            if (!(inputRMS - inputRMS == 0.0) || inputRMS > 1000.0) inputRMS = 1000.0;
+            if (!(outputRMS - outputRMS == 0.0) || outputRMS > 1000.0) outputRMS = 1000.0;
+            double envIn = state[80], envOut = state[81], cur = state[82] + 1.0;
+            const double inA = (inputRMS > envIn) ? bAtt : bRel, outA = (outputRMS > envOut) ? bAtt : bRel;
+            envIn = envIn * (1.0 - inA) + inputRMS * inA;
+            envOut = envOut * (1.0 - outA) + outputRMS * outA;
+            if (envIn < 1.0e-20) envIn = 0.0;
+            if (envOut < 1.0e-20) envOut = 0.0;
+            double target = 1.0;       /* calculateAGCGain, :343-358 */
+            if (!(envOut < 1e-6)) {
+                const double ratio = envIn / envOut;
+                if (!(ratio > 1.0 / 1.059 && ratio < 1.059))
+                    target = ratio < (double)0.06f ? (double)0.06f : (ratio > (double)16.0f ? (double)16.0f : ratio);
+            }
+            const double next = cur * (1.0 - bSm) + target * bSm;
+            state[80] = envIn; state[81] = envOut; state[82] = next - 1.0;
+            const double incr = (next - cur) / nn;
+            gain_ramp_avx_pattern(dataL + off, (int)len, cur, incr);
+            gain_ramp_avx_pattern(dataR + off, (int)len, cur, incr);
+        } else {
+            /* steady-state total gain: startGain == endGain, increment 0 (Processing.cpp:1262-1274) */
+            for (int64_t i = 0; i < len; ++i) { dataL[off + i] *= gain; dataR[off + i] *= gain; }
+        }
     }
 }
 

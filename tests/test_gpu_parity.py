@@ -162,6 +162,7 @@ def _copy_params(po, pa):
     pa.nonlinear_saturation = po.nonlinearSaturation
     pa.total_gain_db = po.totalGainDb
     pa.filter_structure = po.filterStructure
+    pa.agc_enabled = po.agcEnabled
     return pa
 
 
@@ -292,7 +293,7 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     with pytest.raises(amd.CpqError):
         eng.conv_process(x[:, :100])                    # not a multiple of the block size
     p = amd.eq_params_default()
-    p.agc_enabled = 1
+    p.bands[3].channel_mode = 3          # Mid/Side: falls back to the RCU path in the reference -> not implemented
     with pytest.raises(amd.CpqError):
         eng.set_eq_params(0, p)
     eng.close()
@@ -572,4 +573,38 @@ def test_time_varying_reference_semantics_large_blocks(amd, oracle, block, ir_le
     eng.conv_reset()
     y2 = eng.conv_process(x[:, :step])
     assert np.array_equal(y2, y[:, :step])
+    eng.close()
+
+
+@pytest.mark.parametrize("mode,structure", [("sequential", 0), ("auto", 0), ("sequential", 1)])
+def test_eq_agc_block_rate(amd, oracle, mode, structure):
+    """AGC -- per-callback RMS envelopes (attack 0.2 s / release 2 s), gain smoothing and the
+    linear gain ramp, replayed in the reference's accumulation orders."""
+    O = oracle
+    S, T = 3, 16
+    x = make_inputs(O, S, 6 * T * B)
+    x[:, 20000:30000] *= 6.0                     # level step so that the gain moves
+    x[2:4] *= 0.2
+    po = O.eq_params_bench(0.2)
+    po.agcEnabled = 1
+    po.filterStructure = structure
+    po.totalGainDb = -3.0                        # ignored while AGC is on
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    pa = _copy_params(po, amd.eq_params_default())
+    eng.set_eq_params(0, pa)
+    eng.set_eq_params(1, pa)
+    po_off = O.eq_params_bench(0.2)
+    po_off.filterStructure = structure
+    eng.set_eq_params(2, _copy_params(po_off, amd.eq_params_default()))      # stream 2 without AGC
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    y = np.concatenate([eng.eq_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    worst = 0.0
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po if s < 2 else po_off)
+        worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+        if s == 0:
+            plain, _, _ = O.eq_process_stereo(x[0], x[1], po_off)
+            assert np.abs(yl - plain).max() > 1e-3          # the AGC really changes the signal
+    print("agc", mode, structure, "max abs diff", worst)
+    assert worst <= (0.0 if mode == "sequential" else 1e-12)
     eng.close()
