@@ -102,6 +102,13 @@ struct cpq_engine {
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
 
+    // total-gain LinearRamp per stream (src/DspNumericPolicy.h:319-421; 50 ms, EQProcessor.h SMOOTHING_TIME_SEC)
+    struct GainRamp { double current = 1.0, target = 1.0, step = 0.0; int remaining = 0; double wanted = 1.0; bool devUnity = false; };
+    std::vector<GainRamp> gainRamp;     // per stream
+    bool eqProcessed = false;           // a process call has consumed EQ parameters since prepare
+    int* rampOn = nullptr;              // [streams] device
+    double* rampGains = nullptr;        // [streams][callbacks][2] device
+
     // EQ AGC (allocated on first use)
     std::vector<int> agcOnHost;
     bool anyAgc = false;
@@ -296,13 +303,76 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     for (char s : e->eqTpSafe) tp = tp && s;
     const int n = T * e->P;
     const int cbs = n / e->B;            // callback blocks in this call (AGC is block-rate)
+    // total-gain ramp (Processing.cpp:1262-1274): per callback setTargetValue / skip on a LinearRamp (50 ms);
+    // evaluated on the host (scalar per-stream state), applied by the ramp kernel only while some stream is moving
+    std::vector<int> rampOnHost;
+    std::vector<double> rampHost;
+    bool anyRamp = false;
+    {
+        const int S = e->desc.n_streams;
+        const int total = std::max(1, (int)(e->sampleRate * 0.05 + 0.5));
+        for (int s = 0; s < S; ++s) {
+            auto& r = e->gainRamp[s];
+            if (e->agcOnHost[s]) continue;
+            const bool moving = r.remaining > 0 || std::fabs(r.target - r.wanted) > 1e-6 || r.current != r.wanted;
+            if (!moving) continue;
+            if (!anyRamp) { rampOnHost.assign(S, 0); rampHost.assign((size_t)S * cbs * 2, 0.0); anyRamp = true; }
+            rampOnHost[s] = 1;
+            for (int t = 0; t < cbs; ++t) {
+                if (std::fabs(r.target - r.wanted) > 1e-6) {           // setTargetValue
+                    if (r.wanted != r.target) {
+                        r.target = r.wanted;
+                        const int steps = r.remaining > 0 ? r.remaining : total;
+                        r.step = (r.target - r.current) / (double)steps;
+                        r.remaining = steps;
+                    }
+                }
+                const double start = r.current;
+                if (r.remaining > 0) {                                  // skip(numSamples)
+                    if (e->B >= r.remaining) { r.current = r.target; r.remaining = 0; }
+                    else { r.current += r.step * (double)e->B; r.remaining -= e->B; }
+                }
+                rampHost[((size_t)s * cbs + t) * 2] = start;
+                rampHost[((size_t)s * cbs + t) * 2 + 1] = (r.current - start) / (double)e->B;
+            }
+        }
+        // streams whose gain is applied by the ramp kernel need unity gain in the cascade kernel, and back again
+        for (int s = 0; s < S; ++s) {
+            auto& r = e->gainRamp[s];
+            if (e->agcOnHost[s]) continue;
+            const bool needUnity = anyRamp && rampOnHost[s];
+            if (needUnity != r.devUnity) {
+                const double g = needUnity ? 1.0 : r.wanted;
+                for (int ch = 0; ch < 2; ++ch)
+                    CPQ_HIP(e, hipMemcpyAsync(e->svfSatGain + (size_t)(2 * s + ch) * 2 + 1, &g, sizeof(double), hipMemcpyHostToDevice, e->stream));
+                r.devUnity = needUnity;
+            }
+        }
+        if (anyRamp) {
+            const size_t cbMax = (size_t)e->tMax * e->P / e->B;
+            if (!e->rampOn) {
+                if (hipMalloc((void**)&e->rampOn, sizeof(int) * S) != hipSuccess ||
+                    hipMalloc((void**)&e->rampGains, sizeof(double) * 2 * S * cbMax) != hipSuccess)
+                    return fail(e, CPQ_ERR_OOM, "gain ramp buffers could not be allocated");
+            }
+            CPQ_HIP(e, hipMemcpyAsync(e->rampOn, rampOnHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipMemcpyAsync(e->rampGains, rampHost.data(), sizeof(double) * rampHost.size(), hipMemcpyHostToDevice, e->stream));
+        }
+    }
+    e->eqProcessed = true;
     if (e->anyAgc) {
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_agc_block_rms(e->stream, dIn, (int64_t)n, e->nCh, e->B, cbs, e->agcRmsIn);     // cachedInputRMS (:1116-1127)
     }
     const int rc = enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
                                   e->svfState, e->svfTp);
-    if (rc != CPQ_OK || !e->anyAgc) return rc;
+    if (rc != CPQ_OK) return rc;
+    if (anyRamp) {
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_gain_ramp(e->stream, dOut, (int64_t)n, e->desc.n_streams, e->B, cbs, e->rampGains, e->rampOn);
+        CPQ_HIP(e, hipGetLastError());
+    }
+    if (!e->anyAgc) return rc;
     {
         ProfScope p(e, CPQ_K_MIX);
         // block coefficients of the tables prepareToPlay builds (src/eqprocessor/EQProcessor.Core.cpp:776-784)
@@ -563,6 +633,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
     e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0 });
     e->agcOnHost.assign(d->n_streams, 0);
+    e->gainRamp.assign(d->n_streams, cpq_engine::GainRamp{});
     if (hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice) != hipSuccess) {
         cpq_engine_destroy(e);
         return fail(nullptr, CPQ_ERR_DEVICE, "irSlot upload failed");
@@ -583,6 +654,8 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->arena) (void)hipFree(e->arena);
     for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
     if (e->agcOn) (void)hipFree(e->agcOn);
+    if (e->rampOn) (void)hipFree(e->rampOn);
+    if (e->rampGains) (void)hipFree(e->rampGains);
     if (e->tailState) (void)hipFree(e->tailState);
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
@@ -614,6 +687,8 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
     if (maxBlock <= 0 || maxBlock > e->P * e->tMax)
         return fail(e, CPQ_ERR_INVALID_ARG, "max_block %d exceeds block_size*max_blocks_per_call", maxBlock);
     e->sampleRate = sampleRate;
+    e->eqProcessed = false;
+    for (auto& r : e->gainRamp) { r.current = r.target = r.wanted; r.step = 0.0; r.remaining = 0; }   // setCurrentAndTargetValue (Core.cpp:765)
     return zeroRuntimeState(e, true, true);
 }
 
@@ -1011,6 +1086,12 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     CPQ_HIP(e, hipMemcpy(e->svfSatGain + c0 * 2, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->svfTp + (size_t)s0 * tp.size(), ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
     e->eqSet = true;   // streams never given parameters keep all bands inactive (pass-through)
+    for (int s = s0; s < s1; ++s) {
+        auto& r = e->gainRamp[s];
+        r.wanted = cpq::totalGainLinear(p->total_gain_db);
+        r.devUnity = false;               // the upload above put the constant gain (or 1.0 with AGC) on the device
+        if (!e->eqProcessed || p->agc_enabled) { r.current = r.target = r.wanted; r.step = 0.0; r.remaining = 0; }
+    }
     for (int s = s0; s < s1; ++s) e->agcOnHost[s] = p->agc_enabled ? 1 : 0;
     e->anyAgc = false;
     for (int v : e->agcOnHost) e->anyAgc = e->anyAgc || v;

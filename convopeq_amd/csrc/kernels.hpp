@@ -76,6 +76,10 @@ void launch_agc_apply(hipStream_t stream, double* data, int64_t chStride, int S,
                       const double* rmsOut, double* state, const int* agcOn, double* gains, double bAtt, double bRel,
                       double bSm);
 
+// applyGainRamp_AVX2 for the streams flagged in `on`: gains [S][T][2] = start gain, per-sample increment per callback
+void launch_gain_ramp(hipStream_t stream, double* data, int64_t chStride, int S, int B, int T, const double* gains,
+                      const int* on);
+
 // Layered (time-varying) reference semantics: replay of the reference's tail delay-line reader on per-layer
 // natural-time convolutions.  state: 3 long long (callback counter, read cursors), sched: [nTail][T] long long,
 // layerOut: [nTail][nCh][nSamples], ring: [nTail][nCh][ringSlots]; out already holds the layer-0 convolution.

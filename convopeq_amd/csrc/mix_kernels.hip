@@ -230,8 +230,13 @@ void launch_agc_apply(hipStream_t stream, double* data, int64_t chStride, int S,
     hipLaunchKernelGGL(k_agc_ramp, dim3(bx, 2 * S), dim3(256), 0, stream, data, chStride, gains, agcOn, B, T);
 }
 
-namespace {
-}  // namespace
+void launch_gain_ramp(hipStream_t stream, double* data, int64_t chStride, int S, int B, int T, const double* gains,
+                      const int* on)
+{
+    int bx = (B * T + 255) / 256;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(k_agc_ramp, dim3(bx, 2 * S), dim3(256), 0, stream, data, chStride, gains, on, B, T);
+}
 
 void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,
                         double* out, int nCh, int nSamples, int B, int ringSlots, int nTail, int pl1, int ol1, int d1,

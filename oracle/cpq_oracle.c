@@ -1092,8 +1092,26 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
             gain_ramp_avx_pattern(dataL + off, (int)len, cur, incr);
             gain_ramp_avx_pattern(dataR + off, (int)len, cur, incr);
         } else {
-            /* steady-state total gain: startGain == endGain, increment 0 (Processing.cpp:1262-1274) */
-            for (int64_t i = 0; i < len; ++i) { dataL[off + i] *= gain; dataR[off + i] *= gain; }
+            /* total gain through smoothTotalGain (LinearRamp, src/DspNumericPolicy.h:319-421, 50 ms) and
+             * applyGainRamp_AVX2 (Processing.cpp:1262-1274).  state[83] = initialised flag (prepareToPlay does
+             * setCurrentAndTargetValue, Core.cpp:765), [84] current, [85] target, [86] step, [87] remaining */
+            if (state[83] == 0.0) { state[83] = 1.0; state[84] = gain; state[85] = gain; state[86] = 0.0; state[87] = 0.0; }
+            if (fabs(state[85] - gain) > 1e-6 && gain != state[85]) {          /* setTargetValue */
+                int total = (int)(sr * 0.05 + 0.5);
+                if (total <= 0) total = 1;
+                const int steps = state[87] > 0.0 ? (int)state[87] : total;
+                state[85] = gain;
+                state[86] = (state[85] - state[84]) / (double)steps;
+                state[87] = (double)steps;
+            }
+            const double startG = state[84];
+            if (state[87] > 0.0) {                                               /* skip(numSamples) */
+                if ((double)len >= state[87]) { state[84] = state[85]; state[87] = 0.0; }
+                else { state[84] += state[86] * (double)len; state[87] -= (double)len; }
+            }
+            const double incr = (state[84] - startG) / (double)len;
+            gain_ramp_avx_pattern(dataL + off, (int)len, startG, incr);
+            gain_ramp_avx_pattern(dataR + off, (int)len, startG, incr);
         }
     }
 }

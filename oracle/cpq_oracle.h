@@ -143,10 +143,11 @@ void   orc_svf_band_stereo_lane(double* data, int64_t n, const orc_svf_coeffs* c
 void   orc_svf_band_mono(double* data, int64_t n, const orc_svf_coeffs* c,
                          double* state, double saturation);
 /* :1019-1276 serial structure, Stereo channel mode, AGC off, steady total gain.
- * dataL/dataR in place; state: [2][20][2] filter states + 3 AGC doubles (envIn, envOut, gain-1) = 83 doubles;
+ * dataL/dataR in place; state: [2][20][2] filter states + 3 AGC doubles (envIn, envOut, gain-1) + 5 doubles of the
+ * total-gain LinearRamp (initialised, current, target, step, remaining) = 88 doubles;
  * processed in blocks of blockSize like the caller does; AGC (processAGC, :367-445) when agcEnabled. */
 void   orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSize,
-                             const orc_eq_params* p, double sr, double* state /*[83]*/);
+                             const orc_eq_params* p, double sr, double* state /*[88]*/);
 
 /* ------------------------------------------------------- OutputFilter (N2) ---- */
 /* mirrors convo::BiquadCoeff, src/OutputFilter.h:40-44 */

@@ -608,3 +608,31 @@ def test_eq_agc_block_rate(amd, oracle, mode, structure):
     print("agc", mode, structure, "max abs diff", worst)
     assert worst <= (0.0 if mode == "sequential" else 1e-12)
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+def test_eq_total_gain_ramp_on_parameter_change(amd, oracle, mode):
+    """A16: a new total gain reaches the output through a 50 ms LinearRamp (2400 samples at 48 kHz) applied with
+    applyGainRamp_AVX2's incremental-add pattern; a second change in mid-ramp restarts from the current value."""
+    O = oracle
+    S, T = 2, 2
+    n_calls = 12
+    x = make_inputs(O, S, n_calls * T * B)
+    gains_db = {0: -2.0, 3: 4.5, 4: -12.0, 9: 0.0}            # change points (call index -> new total gain)
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    po = O.eq_params_bench(0.2)
+    state = [np.zeros(88), np.zeros(88)]
+    worst = 0.0
+    for k in range(n_calls):
+        if k in gains_db:
+            po.totalGainDb = gains_db[k]
+            eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+        seg = x[:, k * T * B:(k + 1) * T * B]
+        y = eng.eq_process(seg)
+        for s in range(S):
+            yl, yr, state[s] = O.eq_process_stereo(seg[2 * s], seg[2 * s + 1], po, state=state[s])
+            worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+    print("gain ramp", mode, "max abs diff", worst)
+    assert worst <= (0.0 if mode == "sequential" else 1e-13)
+    eng.close()
