@@ -146,8 +146,9 @@ def main():
     ap.add_argument("--shared-ir", action="store_true")
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-buffers", action="store_true", help="diagnostic: host-pointer entry point (PCIe-inclusive rate)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json"))
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -206,8 +207,15 @@ def main():
     k_parts = (taps + P - 1) // P
     setup_s = time.perf_counter() - t_setup
 
+    host_out = np.empty_like(host) if args.host_buffers else None
+
     def step():
-        if args.eq_only:
+        if args.host_buffers:
+            # PCIe-inclusive: pageable host buffers through cpq_engine_process_block (H2D + kernels + D2H + sync)
+            rc = eng._lib.cpq_engine_process_block(eng._h, host.ctypes.data_as(amd._capi.c_double_p),
+                                                   host_out.ctypes.data_as(amd._capi.c_double_p), n)
+            assert rc == 0
+        elif args.eq_only:
             eng.eq_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
         elif use_eq:
             eng.process_device(d_in.data_ptr(), d_out.data_ptr(), n)
