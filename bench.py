@@ -87,7 +87,7 @@ def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
         for ch in range(2):
             nucs[ch].set_impulse(irs[ch], B)
         x = [O.gen_pcm(n_blocks * B, stream=tid, channel=ch) for ch in range(2)]
-        state = np.zeros(88)
+        state = np.zeros(168)
         barrier.wait()
         while True:
             y = [nucs[ch].run(x[ch], B) for ch in range(2)]

@@ -38,6 +38,20 @@ struct ProfileSlot {
 
 }  // namespace
 
+// One tail layer of a FilterSpec plan, run at the reference's OWN partition size: the HC/LC gains (and the air-absorption
+// damping) multiply every partition spectrum of the layer at that layer's FFT size, which folds time-aliased energy
+// into the frame (src/MKLNonUniformConvolver.cpp:336-443) -- only reproducible with the same partitioning.
+struct SpecTail {
+    int P = 0, K = 0, kPad = 0, hRows = 0, ringSlots = 0, nbMax = 0, accCap = 0, outRing = 0;
+    int head = 0, histSel = 0, accSel = 0, fill = 0;
+    long long blocksDone = 0;
+    int delay = 0;              // done_callback * B: absolute lag of block j's output behind its first input sample
+    double gain = 1.0;          // tail-layer gain applied by the delay-line reader
+    char* mem = nullptr;
+    double2 *X = nullptr, *XDN = nullptr, *H = nullptr, *HDN = nullptr, *Y = nullptr, *tw = nullptr, *tw2 = nullptr;
+    double *hist[2] = { nullptr, nullptr }, *acc[2] = { nullptr, nullptr }, *z = nullptr, *ring = nullptr, *gainDev = nullptr;
+};
+
 struct cpq_engine {
     cpq_engine_desc desc{};
     int device = 0;
@@ -94,10 +108,12 @@ struct cpq_engine {
     std::vector<int> irSlotHost;
     std::vector<char> irLoaded; // per channel
     std::vector<int> irParts;   // per IR slot: partitions in use
+    std::vector<char> slotSpecTail;   // per IR slot: loaded with a FilterSpec plan that has tail layers
     cpq_nuc_plan plan{};        // plan of the most recent set_impulse
     bool planValid = false;
     bool eqSet = false;
     std::vector<char> eqTpSafe; // per stream: time-parallel kernel proven guard-free
+    std::vector<char> eqMidSide; // per stream: some active band filters the Mid or Side component
     int eqMode = CPQ_EQ_MODE_AUTO;
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
@@ -128,6 +144,11 @@ struct cpq_engine {
     int tailRingSlots = 0;
     void* tailState = nullptr;          // device: callback counter + read cursors
     long long* tailSched = nullptr;     // device: [nTail][tMax]
+
+    // FilterSpec plans with tail layers (LTI-valid ones): layer 0 runs in the main path, each tail layer in a SpecTail
+    std::vector<SpecTail> specTails;
+    cpq_nuc_plan specPlan{};
+    long long specPos = 0;              // absolute sample position of the next call
 
     // processor-level wrapper (N1)
     int convLevel = CPQ_LEVEL_NUC;
@@ -180,12 +201,12 @@ struct ProfScope {
         ProfileSlot& s = e->prof[id];
         std::pair<hipEvent_t, hipEvent_t> ev;
         if (!s.freeList.empty()) { ev = s.freeList.back(); s.freeList.pop_back(); }
-        else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
-        hipEventRecord(ev.first, e->stream);
+        else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+        (void)hipEventRecord(ev.first, e->stream);
         stop = ev.second;
         s.pending.push_back(ev);
     }
-    ~ProfScope() { if (stop) hipEventRecord(stop, e->stream); }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, e->stream); }
 };
 
 int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int* T)
@@ -205,11 +226,154 @@ int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int*
     return CPQ_OK;
 }
 
+// --- FilterSpec tail layers ---------------------------------------------------------------------------
+void freeSpecTails(cpq_engine* e)
+{
+    for (SpecTail& t : e->specTails) if (t.mem) (void)hipFree(t.mem);
+    e->specTails.clear();
+}
+
+int resetSpecTails(cpq_engine* e)
+{
+    for (SpecTail& t : e->specTails) {
+        CPQ_HIP(e, hipMemsetAsync(t.X, 0, (size_t)e->nCh * t.ringSlots * t.P * sizeof(double2), e->stream));
+        CPQ_HIP(e, hipMemsetAsync(t.XDN, 0, (size_t)e->nCh * t.ringSlots * sizeof(double2), e->stream));
+        for (int i = 0; i < 2; ++i) {
+            CPQ_HIP(e, hipMemsetAsync(t.hist[i], 0, (size_t)e->nCh * t.P * sizeof(double), e->stream));
+            CPQ_HIP(e, hipMemsetAsync(t.acc[i], 0, (size_t)e->nCh * t.accCap * sizeof(double), e->stream));
+        }
+        CPQ_HIP(e, hipMemsetAsync(t.ring, 0, (size_t)e->nCh * t.outRing * sizeof(double), e->stream));
+        t.head = t.histSel = t.accSel = t.fill = 0;
+        t.blocksDone = 0;
+    }
+    e->specPos = 0;
+    return CPQ_OK;
+}
+
+int allocSpecTails(cpq_engine* e, const cpq_nuc_plan& pl)
+{
+    freeSpecTails(e);
+    const int64_t nCh = e->nCh;
+    const int nMax = e->tMax * e->P;
+    for (int l = 1; l < pl.num_layers; ++l) {
+        SpecTail t;
+        t.P = pl.part_size[l];
+        t.K = pl.num_parts_ir[l];
+        t.kPad = (int)alignUp(t.K, cpq::kMacMaxTile);
+        t.hRows = t.kPad + 4 * cpq::kMacMaxTile;
+        t.nbMax = (t.P - 1 + nMax) / t.P;
+        t.ringSlots = nextPow2(t.kPad + cpq::kMacMaxTile + t.nbMax);
+        t.accCap = t.P + nMax;
+        t.delay = pl.done_callback[l] * e->B;
+        t.gain = pl.gain[l];
+        t.outRing = nextPow2(t.delay + 2 * t.P + nMax);
+        struct Item { void** ptr; int64_t bytes; };
+        Item items[] = {
+            { (void**)&t.X, nCh * t.ringSlots * t.P * (int64_t)sizeof(double2) },
+            { (void**)&t.XDN, nCh * t.ringSlots * (int64_t)sizeof(double2) },
+            { (void**)&t.H, nCh * t.hRows * t.P * (int64_t)sizeof(double2) },
+            { (void**)&t.HDN, nCh * t.hRows * (int64_t)sizeof(double2) },
+            { (void**)&t.Y, nCh * t.nbMax * t.P * (int64_t)sizeof(double2) },
+            { (void**)&t.tw, t.P * (int64_t)sizeof(double2) },
+            { (void**)&t.tw2, t.P * (int64_t)sizeof(double2) },
+            { (void**)&t.hist[0], nCh * t.P * (int64_t)sizeof(double) },
+            { (void**)&t.hist[1], nCh * t.P * (int64_t)sizeof(double) },
+            { (void**)&t.acc[0], nCh * t.accCap * (int64_t)sizeof(double) },
+            { (void**)&t.acc[1], nCh * t.accCap * (int64_t)sizeof(double) },
+            { (void**)&t.z, nCh * t.nbMax * t.P * (int64_t)sizeof(double) },
+            { (void**)&t.ring, nCh * t.outRing * (int64_t)sizeof(double) },
+            { (void**)&t.gainDev, (t.P + 1) * (int64_t)sizeof(double) },
+        };
+        int64_t total = 0;
+        for (const Item& it : items) total += alignUp(it.bytes, 256);
+        if (hipMalloc((void**)&t.mem, (size_t)total) != hipSuccess) {
+            (void)hipGetLastError();
+            freeSpecTails(e);
+            return fail(e, CPQ_ERR_OOM, "FilterSpec tail layer %d: %lld bytes could not be allocated", l, (long long)total);
+        }
+        int64_t off = 0;
+        for (const Item& it : items) { *it.ptr = t.mem + off; off += alignUp(it.bytes, 256); }
+        e->specTails.push_back(t);
+        CPQ_HIP(e, hipMemsetAsync(t.mem, 0, (size_t)total, e->stream));
+        std::vector<double2> w(t.P), w2(t.P);
+        const long double twoPi = 6.283185307179586476925286766559005768L;
+        for (int m = 0; m < t.P; ++m) {
+            const long double a = -twoPi * m / (long double)t.P, b = -twoPi * m / (long double)(2 * t.P);
+            w[m] = make_double2((double)cosl(a), (double)sinl(a));
+            w2[m] = make_double2((double)cosl(b), (double)sinl(b));
+        }
+        CPQ_HIP(e, hipStreamSynchronize(e->stream));
+        CPQ_HIP(e, hipMemcpy(t.tw, w.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
+        CPQ_HIP(e, hipMemcpy(t.tw2, w2.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    e->specPlan = pl;
+    e->specPos = 0;
+    return CPQ_OK;
+}
+
+// the call's input joins every tail layer's accumulator (inputAccBuf, NUC.cpp:1433-1452); must run before the main
+// path writes dOut, which may alias dIn
+void specTailsAppend(cpq_engine* e, const double* dIn, int n)
+{
+    for (SpecTail& t : e->specTails)
+        cpq::launch_rows_copy(e->stream, dIn, n, 0, t.acc[t.accSel], t.accCap, t.fill, n, e->nCh);
+}
+
+// every partition that filled up is convolved (FFT, FDL push, MAC over the layer's partitions, IFFT; NUC.cpp:1456-1544)
+// and written to the layer's delay line at the position the reference's reader takes it from (block j is read from
+// callback done_callback on); then the reader adds gain * delay line to the call's output (:1653-1688)
+int specTailsRun(cpq_engine* e, double* dOut, int n)
+{
+    for (SpecTail& t : e->specTails) {
+        const int total = t.fill + n;
+        const int nb = total / t.P;
+        const int rem = total - nb * t.P;
+        if (nb > 0) {
+            const cpq::FftTables tw{ t.tw, t.tw2 };
+            {
+                ProfScope p(e, CPQ_K_RFFT_FWD);
+                cpq::launch_rfft_fwd_ols(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X,
+                                         t.XDN, tw, t.P, e->nCh, nb, t.head, t.ringSlots);
+            }
+            {
+                ProfScope p(e, CPQ_K_FDL_MAC);
+                cpq::launch_fdl_mac(e->stream, e->macTile, t.X, t.H, e->irSlot, t.Y, t.P, e->nCh, t.kPad, t.ringSlots, t.head,
+                                    nb, (int64_t)t.hRows * t.P);
+            }
+            {
+                ProfScope p(e, CPQ_K_DCNYQ);
+                cpq::launch_fdl_mac_dcnyq(e->stream, t.XDN, t.HDN, e->irSlot, t.Y, t.P, e->nCh, t.K, t.ringSlots, t.head, nb,
+                                          t.hRows);
+            }
+            {
+                ProfScope p(e, CPQ_K_RFFT_INV);
+                cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, e->nCh, nb);
+            }
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_ring_put(e->stream, t.z, (int64_t)t.nbMax * t.P, nb * t.P, t.ring, t.outRing,
+                                 t.blocksDone * t.P + t.delay, e->nCh);
+            cpq::launch_rows_copy(e->stream, t.acc[t.accSel], t.accCap, (int64_t)nb * t.P, t.acc[t.accSel ^ 1], t.accCap, 0, rem,
+                                  e->nCh);
+            t.blocksDone += nb;
+            t.head = (t.head + nb) & (t.ringSlots - 1);
+            t.histSel ^= 1;
+            t.accSel ^= 1;
+        }
+        t.fill = rem;
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_ring_add(e->stream, dOut, n, n, t.ring, t.outRing, e->specPos, t.gain, e->nCh);
+    }
+    e->specPos += n;
+    CPQ_HIP(e, hipGetLastError());
+    return CPQ_OK;
+}
+
 // --- enqueue helpers (device pointers, no sync) -----------------------------------------------------
 int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!cpq_conv_is_ready(e)) return fail(e, CPQ_ERR_NOT_READY, "set_impulse has not covered every stream");
     const int64_t stride = (int64_t)T * e->P;
+    if (!e->specTails.empty()) specTailsAppend(e, dIn, (int)stride);
     if (e->layered) {
         const cpq_nuc_plan& pl = e->layerPlan;
         const int nTail = pl.num_layers - 1;
@@ -275,11 +439,13 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     CPQ_HIP(e, hipGetLastError());
     e->head = (e->head + T) & (e->ringSlots - 1);
     e->histSel ^= 1;
+    if (!e->specTails.empty()) return specTailsRun(e, dOut, (int)stride);
     return CPQ_OK;
 }
 
 int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int T, bool tp, int idTp, int idSeq,
-                   const double* coef, const int* flags, const double* satGain, double* state, const double* tables)
+                   const double* coef, const int* flags, const double* satGain, double* state, const double* tables,
+                   bool streamPairs = false)
 {
     const int n = T * e->P;
     const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
@@ -290,7 +456,7 @@ int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int T, bool t
     if (n > nTp) {
         ProfScope p(e, idSeq);
         cpq::launch_svf_cascade(e->stream, dIn + nTp, dOut + nTp, (int64_t)n, e->nCh, n - nTp, coef, flags, satGain,
-                                state);
+                                state, streamPairs);
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
@@ -364,8 +530,10 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_agc_block_rms(e->stream, dIn, (int64_t)n, e->nCh, e->B, cbs, e->agcRmsIn);     // cachedInputRMS (:1116-1127)
     }
+    bool midSide = false;
+    for (char m : e->eqMidSide) midSide = midSide || m;
     const int rc = enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
-                                  e->svfState, e->svfTp);
+                                  e->svfState, e->svfTp, midSide);
     if (rc != CPQ_OK) return rc;
     if (anyRamp) {
         ProfScope p(e, CPQ_K_MIX);
@@ -421,6 +589,7 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * e->P * sizeof(double), e->stream));
         e->head = 0;
         e->histSel = 0;
+        { const int rc = resetSpecTails(e); if (rc != CPQ_OK) return rc; }
         if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 3 * sizeof(long long), e->stream));
         if (e->tailRing) CPQ_HIP(e, hipMemsetAsync(e->tailRing, 0, sizeof(double) * (size_t)(e->layerPlan.num_layers - 1) * e->nCh * e->tailRingSlots, e->stream));
         for (double* p : { e->dryHist[0], e->dryHist[1] })
@@ -630,7 +799,9 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     for (int c = 0; c < e->nCh; ++c) e->irSlotHost[c] = c;
     e->irLoaded.assign(e->nCh, 0);
     e->irParts.assign(e->nCh, 0);
+    e->slotSpecTail.assign(e->nCh, 0);
     e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
+    e->eqMidSide.assign(d->n_streams, 0);
     e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0 });
     e->agcOnHost.assign(d->n_streams, 0);
     e->gainRamp.assign(d->n_streams, cpq_engine::GainRamp{});
@@ -648,9 +819,10 @@ void cpq_engine_destroy(cpq_engine* e)
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     for (auto& s : e->prof) {
-        for (auto& ev : s.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-        for (auto& ev : s.freeList) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+        for (auto& ev : s.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto& ev : s.freeList) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     }
+    freeSpecTails(e);
     if (e->arena) (void)hipFree(e->arena);
     for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
     if (e->agcOn) (void)hipFree(e->agcOn);
@@ -713,18 +885,38 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     // FFT path (difference: rounding, and the reference's flush of |direct output| < 1e-20).
     // FilterSpec: the HC/LC gains multiply every partition spectrum of every layer at that layer's FFT size
     // (:336-443), which this engine reproduces exactly only for a single-layer plan at P == block size.
+    // With tail layers every layer keeps the reference's own partition size: layer 0 in the main path, each tail layer in
+    // a SpecTail (partition sizes up to 4096, LTI-valid plans; all such IRs of an engine share one plan).
     std::vector<double> gains;
+    cpq_nuc_plan sp{};
+    bool specTails = false;
+    const int slotFirst = (stream == CPQ_ALL_STREAMS) ? 0 : 2 * stream;
     if (spec) {
-        cpq_nuc_plan sp;
         if (cpq::computeNucPlan(irLen, e->desc.block_size, direct != 0, spec, &sp) != CPQ_OK)
             return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
-        if (sp.num_layers != 1)
-            return fail(e, CPQ_ERR_UNSUPPORTED,
-                        "FilterSpec with tail layers: per-layer HC/LC spectral gains need the reference's layer partition sizes");
         if (e->P != sp.part_size[0])
             return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec needs partition_size == the reference layer-0 partition (%d)", sp.part_size[0]);
         if (direct) return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec together with the direct head is not implemented");
         if (e->desc.semantics != CPQ_SEM_REFERENCE) return fail(e, CPQ_ERR_INVALID_ARG, "FilterSpec requires reference semantics");
+        if (sp.num_layers > 1) {
+            if (!sp.lti_valid)
+                return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec on a time-varying plan (tail partition longer than the IR before it) is not implemented");
+            if (e->layered) return fail(e, CPQ_ERR_UNSUPPORTED, "engine is in time-varying (layered) mode");
+            for (int l = 1; l < sp.num_layers; ++l)
+                if (sp.part_size[l] > 4096 || (sp.part_size[l] & (sp.part_size[l] - 1)))
+                    return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec tail layer %d has partition size %d; supported: powers of two up to 4096",
+                                l, sp.part_size[l]);
+            if (e->specTails.empty() || std::memcmp(&sp, &e->specPlan, sizeof(sp)) != 0) {
+                for (int slot = 0; slot < e->nCh; ++slot)
+                    if (e->slotSpecTail[slot] && !(slot == slotFirst || slot == slotFirst + 1) && stream != CPQ_ALL_STREAMS)
+                        return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec IRs with tail layers must share one layer plan (IR length and spec)");
+                CPQ_HIP(e, hipSetDevice(e->device));
+                const int rc = allocSpecTails(e, sp);
+                if (rc != CPQ_OK) return rc;
+                std::fill(e->slotSpecTail.begin(), e->slotSpecTail.end(), 0);
+            }
+            specTails = true;
+        }
         cpq::spectrumFilterGains(*spec, 2 * e->P, gains);
     }
 
@@ -804,7 +996,18 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             e->directHead = direct != 0;
             continue;
         }
-        if (e->desc.semantics == CPQ_SEM_REFERENCE) {
+        // tail rows of this slot left by an earlier FilterSpec IR
+        for (SpecTail& t : e->specTails) {
+            CPQ_HIP(e, hipMemsetAsync(t.H + (int64_t)slot * t.hRows * t.P, 0, (size_t)t.hRows * t.P * sizeof(double2), e->stream));
+            CPQ_HIP(e, hipMemsetAsync(t.HDN + (int64_t)slot * t.hRows, 0, (size_t)t.hRows * sizeof(double2), e->stream));
+        }
+        if (!e->specTails.empty()) e->slotSpecTail[slot] = specTails ? 1 : 0;
+        if (specTails) {
+            // layer 0 here, the tail layers below: each on its own partition grid
+            pl = sp;
+            heff.assign(irs[ch], irs[ch] + sp.len[0]);
+            if (std::abs(scale - 1.0) > 1e-12) for (double& v : heff) v *= scale;
+        } else if (e->desc.semantics == CPQ_SEM_REFERENCE) {
             rc = cpq::buildHeff(irs[ch], irLen, e->desc.block_size, scale, spec, heff, &pl);
             if (rc != CPQ_OK) return fail(e, rc, "layer plan failed");
             if (!pl.lti_valid)
@@ -831,6 +1034,29 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         }
         CPQ_HIP(e, hipGetLastError());
         CPQ_HIP(e, hipStreamSynchronize(e->stream));   // heffDev is reused for the next channel
+        if (specTails) {
+            std::vector<double> g;
+            int l = 1;
+            for (SpecTail& t : e->specTails) {
+                heff.assign(irs[ch] + sp.offset[l], irs[ch] + sp.offset[l] + sp.len[l]);
+                if (std::abs(scale - 1.0) > 1e-12) for (double& v : heff) v *= scale;
+                double2* Ht = t.H + (int64_t)slot * t.hRows * t.P;
+                double2* HDNt = t.HDN + (int64_t)slot * t.hRows;
+                CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Ht, HDNt, cpq::FftTables{ t.tw, t.tw2 }, t.P, t.K);
+                cpq::spectrumFilterGains(*spec, 2 * t.P, g);            // applySpectrumFilter at this layer's FFT size
+                CPQ_HIP(e, hipMemcpyAsync(t.gainDev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                cpq::launch_spectrum_gain(e->stream, Ht, HDNt, t.gainDev, t.P, t.K);
+                CPQ_HIP(e, hipStreamSynchronize(e->stream));
+                if (cpq::airAbsorptionGains(*spec, l, t.P + 1, g)) {     // tail mode 0 (:1060-1097)
+                    CPQ_HIP(e, hipMemcpyAsync(t.gainDev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                    cpq::launch_spectrum_gain(e->stream, Ht, HDNt, t.gainDev, t.P, t.K);
+                    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+                }
+                CPQ_HIP(e, hipGetLastError());
+                ++l;
+            }
+        }
         e->irParts[slot] = parts;
         e->plan = pl;
         e->plan.direct_taps = direct ? std::min(irLen, std::min(pl.part_size[0], 32)) : 0;
@@ -1034,18 +1260,24 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
         return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
     if (p->filter_structure != 0 && p->filter_structure != 1) return fail(e, CPQ_ERR_INVALID_ARG, "filter_structure must be 0 (serial) or 1 (parallel)");
     for (int b = 0; b < kBands; ++b)
-        if (p->bands[b].enabled && (p->bands[b].channel_mode < 0 || p->bands[b].channel_mode > 2))
-            return fail(e, CPQ_ERR_UNSUPPORTED, "band %d: Mid/Side channel modes are not implemented", b);
+        if (p->bands[b].enabled && (p->bands[b].channel_mode < 0 || p->bands[b].channel_mode > 4))
+            return fail(e, CPQ_ERR_INVALID_ARG, "band %d: channel_mode must be 0..4 (Stereo, Left, Right, Mid, Side)", b);
 
     // createCoeffCache: bandActive = enabled && sr > 0; coefficients only for active bands
-    // (src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90)
+    // (src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90).  An active Mid/Side band makes the reference fall
+    // back to the basic process(block) for the whole call (Processing.cpp:1036-1044); its band nodes are inactive
+    // for non-LP/HP bands within 0.01 dB of flat (createBandNode, Coefficients.cpp:48-53).
+    bool midSide = false;
+    for (int b = 0; b < kBands; ++b)
+        midSide = midSide || (p->bands[b].enabled && e->sampleRate > 0.0 && p->bands[b].channel_mode >= 3);
     double coef[2][kBands][6];
     int flags[2][kBands];
     std::vector<double> tp((size_t)kBands * cpq::kSvfTpTableDoubles, 0.0);
     bool tpSafe = true;
     for (int b = 0; b < kBands; ++b) {
         const cpq_eq_band& bp = p->bands[b];
-        const bool active = bp.enabled && e->sampleRate > 0.0;
+        bool active = bp.enabled && e->sampleRate > 0.0;
+        if (midSide && bp.type != 3 && bp.type != 4 && std::fabs(bp.gain) < 0.01f) active = false;
         cpq_svf_coeffs c{ 0, 0, 0, 0, 0, 1, 0, 0 };
         if (active) {
             cpq::designSvf(bp.type, bp.frequency, bp.gain, bp.q, e->sampleRate, &c);
@@ -1055,8 +1287,10 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             const double v[6] = { c.a1, c.a2, c.a3, c.m0, c.m1, c.m2 };
             std::memcpy(coef[ch][b], v, sizeof(v));
             // Stereo -> both channels through the packed SSE2+FMA kernel; Left/Right -> one channel, scalar kernel
-            const bool on = active && (bp.channel_mode == 0 || bp.channel_mode == 1 + ch);
-            flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0) | (p->filter_structure == 1 ? 8 : 0);
+            // Mid/Side -> both channel lanes run the scalar kernel on the encoded component (flag bit 4 / 5)
+            const bool on = active && (bp.channel_mode == 0 || bp.channel_mode == 1 + ch || bp.channel_mode >= 3);
+            flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0) | (p->filter_structure == 1 ? 8 : 0) |
+                           (bp.channel_mode == 3 ? 16 : 0) | (bp.channel_mode == 4 ? 32 : 0);
         }
     }
     // with AGC the total-gain ramp is replaced by processAGC (Processing.cpp:1256-1259): unity gain in the cascade kernel
@@ -1077,8 +1311,8 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             hs[ci * 2 + 1] = satGain[1];
         }
     for (int s = s0; s < s1; ++s) std::memcpy(&ht[(size_t)(s - s0) * tp.size()], tp.data(), tp.size() * sizeof(double));
-    if (p->filter_structure == 1) tpSafe = false;     // parallel structure runs on the lane-skewed kernel
-    for (int s = s0; s < s1; ++s) e->eqTpSafe[s] = tpSafe ? 1 : 0;
+    if (p->filter_structure == 1 || midSide) tpSafe = false;     // parallel structure and Mid/Side bands run on the lane-skewed kernel
+    for (int s = s0; s < s1; ++s) { e->eqTpSafe[s] = tpSafe ? 1 : 0; e->eqMidSide[s] = midSide ? 1 : 0; }
     const size_t c0 = (size_t)s0 * 2;
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     CPQ_HIP(e, hipMemcpy(e->svfCoef + c0 * kBands * 6, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -174,6 +174,28 @@ void spectrumFilterGains(const cpq_filter_spec& spec, int N, std::vector<double>
     }
 }
 
+// Air-absorption HF damping of tail layer `layer` (1 or 2) in tail mode 0 (src/MKLNonUniformConvolver.cpp:1060-1097):
+// gains[k] = exp(-coeff (k / (complexSize - 1))^2), the same curve on every partition of the layer.
+// Returns false when the spec does not select it (tail disabled or tail mode != 0).
+bool airAbsorptionGains(const cpq_filter_spec& spec, int layer, int complexSize, std::vector<double>& gains)
+{
+    const int tailMode = limit(0, 2, static_cast<int>(spec.tail_mode));
+    const bool tailEnabled = (tailMode != 2) && spec.tail_enabled != 0;
+    if (!tailEnabled || tailMode != 0 || layer < 1) return false;
+    const double userStrength = limit(0.0, 2.0, spec.tail_strength);
+    const double s01 = limit(0.0, 1.0, userStrength * 0.5);
+    const double tailStart = limit(0.01, 0.80, std::max(limit(0.01, 0.80, spec.tail_start_seconds), 0.055));   // :648-650
+    const double startNorm = limit(0.65, 1.55, tailStart / 0.085);
+    const double coeff = (0.35 + 1.10 * s01) * startNorm * ((layer == 1) ? 1.0 : 1.6);
+    const double denom = static_cast<double>(std::max(1, complexSize - 1));
+    gains.resize(static_cast<size_t>(complexSize));
+    for (int k = 0; k < complexSize; ++k) {
+        const double fn = static_cast<double>(k) / denom;
+        gains[static_cast<size_t>(k)] = std::exp(-coeff * fn * fn);
+    }
+    return true;
+}
+
 // src/eqprocessor/EQProcessor.Coefficients.cpp:84-96 (clamps, float), :101-130, :431-618
 void designSvf(int type, float freq, float gainDb, float q, double sr, cpq_svf_coeffs* c)
 {

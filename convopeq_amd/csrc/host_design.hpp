@@ -12,6 +12,7 @@ int    computeNucPlan(int irLen, int blockSize, bool enableDirectHead, const cpq
 int    buildHeff(const double* ir, int irLen, int blockSize, double scale, const cpq_filter_spec* spec,
                  std::vector<double>& heff, cpq_nuc_plan* planOut);
 void   spectrumFilterGains(const cpq_filter_spec& spec, int N, std::vector<double>& gains);
+bool   airAbsorptionGains(const cpq_filter_spec& spec, int layer, int complexSize, std::vector<double>& gains);
 void   designSvf(int type, float freq, float gainDb, float q, double sr, cpq_svf_coeffs* c);
 void   defaultEqParams(cpq_eq_params* p);
 double totalGainLinear(float db);

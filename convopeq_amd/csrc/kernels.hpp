@@ -44,10 +44,12 @@ void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2*
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw,
                          int P, int nCh, int T);
 
-// 20-band TPT-SVF cascade, lane = (channel, band), bands skewed in time across lanes.
+// 20-band TPT-SVF cascade, lane = (channel, band), bands skewed in time across lanes.  streamPairs: one wave per
+// stream (its L and R channel) instead of 3 channels per wave -- required when a band has flag bits 4/5
+// (Mid / Side component band).
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh,
                         int nSamples, const double* coef, const int* flags, const double* satGain,
-                        double* state);
+                        double* state, bool streamPairs);
 
 // Time-parallel SVF cascade: one 4-wave workgroup per channel, 256 chunks of a span in flight per band
 // (zero-state chunk runs + state scan + linear state response), span resident in LDS across the 20 bands.
@@ -86,5 +88,13 @@ void launch_gain_ramp(hipStream_t stream, double* data, int64_t chStride, int S,
 void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,
                         double* out, int nCh, int nSamples, int B, int ringSlots, int nTail, int pl1, int ol1, int d1,
                         int pl2, int ol2, int d2, double g1, double g2);
+
+// FilterSpec tail layers at the reference's partition size: input accumulation, delay-line write, delay-line read-add
+void launch_rows_copy(hipStream_t stream, const double* src, int64_t srcStride, int64_t srcOff, double* dst,
+                      int64_t dstStride, int64_t dstOff, int n, int nCh);
+void launch_ring_put(hipStream_t stream, const double* z, int64_t zStride, int n, double* ring, int ringSize,
+                     long long pos, int nCh);
+void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, const double* ring, int ringSize,
+                     long long pos, double gain, int nCh);
 
 }  // namespace cpq

@@ -212,6 +212,40 @@ __global__ __launch_bounds__(256) void k_agc_ramp(double* data, int64_t chStride
     }
 }
 
+
+// ---- FilterSpec tail layers run at the reference's own partition size (cpq_api.cpp, SpecTail) -------------------
+// dst[c][dstOff + i] = src[c][srcOff + i], i < n: input accumulation of a tail layer (inputAccBuf, NUC.cpp:1433-1452)
+__global__ __launch_bounds__(256) void k_rows_copy(const double* __restrict__ src, int64_t srcStride, int64_t srcOff,
+                                                   double* __restrict__ dst, int64_t dstStride, int64_t dstOff, int n)
+{
+    const double* s = src + (int64_t)blockIdx.y * srcStride + srcOff;
+    double* d = dst + (int64_t)blockIdx.y * dstStride + dstOff;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// ring[c][(pos + i) & mask] = z[c][i]: completed tail blocks into the delay line (delayLineWrite, NUC.cpp:1639-1648)
+__global__ __launch_bounds__(256) void k_ring_put(const double* __restrict__ z, int64_t zStride, int n,
+                                                  double* __restrict__ ring, int mask, long long pos)
+{
+    const double* s = z + (int64_t)blockIdx.y * zStride;
+    double* r = ring + (int64_t)blockIdx.y * (mask + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        r[(pos + i) & mask] = s[i];
+}
+
+// out[c][i] += ring[c][(pos + i) & mask] * gain  (delayLineReadAdd, NUC.cpp:1653-1688)
+__global__ __launch_bounds__(256) void k_ring_add(double* out, int64_t outStride, int n, const double* __restrict__ ring,
+                                                  int mask, long long pos, double gain)
+{
+    double* o = out + (int64_t)blockIdx.y * outStride;
+    const double* r = ring + (int64_t)blockIdx.y * (mask + 1);
+    const bool unity = fabs(gain - 1.0) < 1.0e-12;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = r[(pos + i) & mask];
+        o[i] = unity ? (o[i] + v) : (o[i] + v * gain);
+    }
+}
+
 }  // namespace
 
 void launch_agc_block_rms(hipStream_t stream, const double* x, int64_t chStride, int nCh, int B, int T, double* rms)
@@ -263,6 +297,29 @@ void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dr
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(k_convproc_mix, dim3(bx, nCh), dim3(256), 0, stream, wet, dryIn, out, chStride, nSamples, gains,
                        delay, histOld, histNew, histCap, wetValid);
+}
+
+static dim3 rowsGrid(int n, int nCh) { int bx = (n + 255) / 256; if (bx > 64) bx = 64; if (bx < 1) bx = 1; return dim3(bx, nCh); }
+
+void launch_rows_copy(hipStream_t stream, const double* src, int64_t srcStride, int64_t srcOff, double* dst,
+                      int64_t dstStride, int64_t dstOff, int n, int nCh)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rows_copy, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, srcOff, dst, dstStride, dstOff, n);
+}
+
+void launch_ring_put(hipStream_t stream, const double* z, int64_t zStride, int n, double* ring, int ringSize,
+                     long long pos, int nCh)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_ring_put, rowsGrid(n, nCh), dim3(256), 0, stream, z, zStride, n, ring, ringSize - 1, pos);
+}
+
+void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, const double* ring, int ringSize,
+                     long long pos, double gain, int nCh)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_ring_add, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, n, ring, ringSize - 1, pos, gain);
 }
 
 }  // namespace cpq

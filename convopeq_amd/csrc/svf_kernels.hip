@@ -7,7 +7,9 @@
 // The recurrence is serial in time per (channel, band) and, because every band output passes through the
 // fastTanh saturation blend, serial across bands too.  The only parallelism is channel x band with the bands
 // skewed in time: lane = (channel, band); at step s band b processes sample s-b and hands its output to
-// band b+1 of the same channel through a one-lane wave shift.  One wave carries 3 channels x 20 bands.
+// band b+1 of the same channel through a one-lane wave shift.  One wave carries 3 channels x 20 bands, or the
+// 2 channels of one stream when a band works on the Mid or Side component (the two lanes of such a band swap
+// their inputs, both run the same mono recurrence on the encoded component and each decodes its own channel).
 // Samples enter and leave through LDS in 64-sample coalesced chunks.
 //
 // Arithmetic follows the reference operation for operation (same FMA sites, IEEE division, same guards),
@@ -19,7 +21,6 @@ namespace cpq {
 
 namespace {
 
-constexpr int kChPerWave = 3;
 
 // sanitizeFiniteInRangeV(v, 0, 1e15): non-finite or |v| >= 1e15 -> 0  (Processing.cpp:90-101)
 __device__ __forceinline__ double sanitize(double v)
@@ -30,6 +31,8 @@ __device__ __forceinline__ double sanitize(double v)
 
 
 // in and out may alias (in-place processing like the reference): no __restrict__ on them.
+// kChPerWave = 3 packs channels densely; kChPerWave = 2 keeps the L/R pair of a stream in one wave (Mid/Side bands).
+template <int kChPerWave>
 __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* out,
                                                     int64_t chStride, int nCh, int nSamples,
                                                     const double* __restrict__ coef, const int* __restrict__ flags,
@@ -62,6 +65,14 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
     // FilterStructure::Parallel (Processing.cpp:1164-1226): every band filters the block INPUT; out = src + accum with
     // accum = (((0 + y_0) - src) + y_1) - src ... in band order.  Bit 3 is set on all 20 band slots of the channel.
     const bool parallel = (flag & 8) != 0;
+    // Mid (1) / Side (2) band of the basic process(block) path (Processing.cpp:690-739, :792-836); bit 1 is set too
+    // (processBand arithmetic).  The component state is the L slot's; both lanes carry it.
+    const int msMode = (kChPerWave == 2) ? ((flag >> 4) & 3) : 0;
+    const int partner = (lane < kBands) ? lane + kBands : lane - kBands;
+    if (kChPerWave == 2) {
+        const double l1 = __shfl(ic1, band), l2 = __shfl(ic2, band);
+        if (msMode) { ic1 = l1; ic2 = l2; }
+    }
     const double oneMinusSat = 1.0 - sat;
 
     double ylast = 0.0, xlast = 0.0;
@@ -84,8 +95,17 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
             // serial: v0 = previous band's output.  parallel: v0 = the raw input sample, ylast carries the accumulator
             const double xv = (band == 0) ? xRaw : xPrev;
             const double accIn = (band == 0) ? 0.0 : fromPrev;
-            const double v0 = parallel ? xv : ((band == 0) ? xRaw : fromPrev);
+            const double vOwn = parallel ? xv : ((band == 0) ? xRaw : fromPrev);
+            const double vOther = (kChPerWave == 2) ? __shfl(vOwn, partner) : 0.0;
             if (live && n >= 0 && n < nSamples) {
+                double v0 = vOwn, mid = 0.0, side = 0.0;
+                if (active && msMode) {
+                    // M = (L + R) * 0.5, S = (L - R) * 0.5  (copy / add|subtract / multiply, :699-704)
+                    const double l = (chl == 0) ? vOwn : vOther, r = (chl == 0) ? vOther : vOwn;
+                    mid = (l + r) * 0.5;
+                    side = (l - r) * 0.5;
+                    v0 = (msMode == 1) ? mid : side;
+                }
                 double y = v0;
                 if (active && df2t) {
                     // biquadStep128_FMA (src/OutputFilter.cpp:143-165): state (w1, w2) in (ic1, ic2);
@@ -136,9 +156,15 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
                         ic2 = sanitize(ic2);
                     }
                 }
+                if (active && msMode) {
+                    // decode: L = M + S, R = M - S with the filtered component replaced (:711-714)
+                    const double mo = (msMode == 1) ? y : mid, so = (msMode == 1) ? side : y;
+                    y = (chl == 0) ? (mo + so) : (mo - so);
+                }
                 if (parallel) {
-                    // accum += work; accum -= src  (juce::FloatVectorOperations::add / subtract, :1195-1198)
-                    const double acc = active ? ((accIn + y) - xv) : accIn;
+                    // accum += work; accum -= src  (juce::FloatVectorOperations::add / subtract, :1195-1198);
+                    // Mid/Side bands: accum += work - src (:831-835)
+                    const double acc = active ? (msMode ? (accIn + (y - xv)) : ((accIn + y) - xv)) : accIn;
                     ylast = acc;
                     xlast = xv;
                     if (band == kBands - 1) yout[chl][n & 127] = (xv + acc) * gain;     // block = src + accum (:1220-1221)
@@ -531,11 +557,14 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
 }  // namespace
 
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
-                        const double* coef, const int* flags, const double* satGain, double* state)
+                        const double* coef, const int* flags, const double* satGain, double* state, bool streamPairs)
 {
-    const int grid = (nCh + kChPerWave - 1) / kChPerWave;
-    hipLaunchKernelGGL(k_svf_cascade, dim3(grid), dim3(64), 0, stream, in, out, chStride, nCh, nSamples, coef, flags,
-                       satGain, state);
+    if (streamPairs)
+        hipLaunchKernelGGL(k_svf_cascade<2>, dim3((nCh + 1) / 2), dim3(64), 0, stream, in, out, chStride, nCh, nSamples,
+                           coef, flags, satGain, state);
+    else
+        hipLaunchKernelGGL(k_svf_cascade<3>, dim3((nCh + 2) / 3), dim3(64), 0, stream, in, out, chStride, nCh, nSamples,
+                           coef, flags, satGain, state);
 }
 
 }  // namespace cpq

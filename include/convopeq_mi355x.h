@@ -98,7 +98,7 @@ typedef struct {
     float   q;
     int32_t enabled;
     int32_t type;                    /* 0 LowShelf, 1 Peaking, 2 HighShelf, 3 LowPass, 4 HighPass */
-    int32_t channel_mode;            /* 0 Stereo, 1 Left, 2 Right (3 Mid / 4 Side: CPQ_ERR_UNSUPPORTED) */
+    int32_t channel_mode;            /* 0 Stereo, 1 Left, 2 Right, 3 Mid, 4 Side (Mid/Side: basic process(block) path) */
 } cpq_eq_band;
 
 typedef struct {
@@ -178,10 +178,13 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
  * MKLNonUniformConvolver::SetImpulse(impulse, irLen, blockSize, scale, enableDirectHead, filterSpec)
  * (src/MKLNonUniformConvolver.h:197-200).  stream = index or CPQ_ALL_STREAMS (one shared stereo IR).
  * The caller keeps ownership of ir_l/ir_r (copied).
- * spec: NULL (the primary parity surface), or a FilterSpec whose plan has ONE layer (IR inside layer 0, or tail
- * disabled / tail mode 2, which truncates the IR to 32 partitions): its HC/LC spectral gains (:336-443) are then
- * applied to the partition spectra exactly as the reference does.  With tail layers the gains depend on the
- * reference's per-layer partition sizes -> CPQ_ERR_UNSUPPORTED.
+ * spec: NULL (the primary parity surface), or a FilterSpec: its HC/LC spectral gains (:336-443) and, in tail mode 0,
+ * the air-absorption damping (:1060-1097) are applied to every partition spectrum at that LAYER's FFT size, exactly
+ * as the reference does.  Layer 0 runs in the main path; every tail layer of the plan runs on the reference's own
+ * partition grid (block_size * multiplier, ...) and reaches the output through the delay-line lag done_callback * B.
+ * Limits (CPQ_ERR_UNSUPPORTED): tail partitions above 4096 samples (e.g. layer 2 at block 512), plans that are
+ * time-varying in the reference (cpq_nuc_plan.lti_valid == 0), FilterSpec IRs with different layer plans in one
+ * engine, partition_size != block_size.
  * enable_direct_head: accepted; the <= 32 head taps stay in the FFT path (same h_eff, rounding-level difference). */
 int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* ir_l, const double* ir_r,
                              int32_t ir_len, double scale, int32_t enable_direct_head,

@@ -1009,6 +1009,16 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
         active[b] = p->bands[b].enabled && sr > 0.0;
         if (active[b]) orc_svf_design(p->bands[b].type, p->bands[b].frequency, p->bands[b].gain, p->bands[b].q, sr, &co[b]);
     }
+    /* an active Mid/Side band sends the whole call to the basic process(block) (Processing.cpp:1036-1044), whose
+     * band nodes are inactive for non-LP/HP bands within 0.01 dB of flat (createBandNode, Coefficients.cpp:48-53) */
+    int basicPath = 0;
+    for (int b = 0; b < 20; ++b) if (active[b] && p->bands[b].channelMode >= 3) basicPath = 1;
+    if (basicPath)
+        for (int b = 0; b < 20; ++b)
+            if (active[b] && p->bands[b].type != 3 && p->bands[b].type != 4 && fabsf(p->bands[b].gain) < 0.01f) active[b] = 0;
+    /* Mid / Side band states (states[2], states[3] of filterState[4][20][2]) live at state[88..127] / [128..167] */
+    double* stMid = state + 88;
+    double* stSide = state + 128;
     const double sat = (double)p->nonlinearSaturation;
     /* juce::Decibels::decibelsToGain<double>: > -100 dB ? 10^(dB/20) : 0 (EQProcessor.h:450) */
     const double gdb = (double)p->totalGainDb;
@@ -1034,6 +1044,19 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
             for (int b = 0; b < 20; ++b) {
                 if (!active[b]) continue;
                 const int mode = p->bands[b].channelMode;
+                if (mode >= 3) {       /* basic path, Processing.cpp:792-836 */
+                    double* ms = alloc_d((size_t)len * 2);
+                    for (int64_t i = 0; i < len; ++i) { ms[i] = (srcL[i] + srcR[i]) * 0.5; ms[len + i] = (srcL[i] - srcR[i]) * 0.5; }
+                    if (mode == 3) orc_svf_band_mono(ms, len, &co[b], stMid + b * 2, sat);
+                    else           orc_svf_band_mono(ms + len, len, &co[b], stSide + b * 2, sat);
+                    for (int64_t i = 0; i < len; ++i) {
+                        const double wl = ms[i] + ms[len + i], wr = ms[i] - ms[len + i];
+                        accL[i] += wl - srcL[i];
+                        accR[i] += wr - srcR[i];
+                    }
+                    free(ms);
+                    continue;
+                }
                 for (int ch = 0; ch < 2; ++ch) {
                     if (!(mode == 0 || mode == 1 + ch)) continue;
                     const double* src = ch ? srcR : srcL;
@@ -1060,6 +1083,14 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
                 orc_svf_band_mono(dataL + off, len, &co[b], state + (0 * 20 + b) * 2, sat);
             } else if (mode == 2) {
                 orc_svf_band_mono(dataR + off, len, &co[b], state + (1 * 20 + b) * 2, sat);
+            } else {                  /* Mid / Side: encode, filter one component, decode (Processing.cpp:690-739) */
+                double* L = dataL + off; double* R = dataR + off;
+                double* ms = alloc_d((size_t)len * 2);
+                for (int64_t i = 0; i < len; ++i) { ms[i] = (L[i] + R[i]) * 0.5; ms[len + i] = (L[i] - R[i]) * 0.5; }
+                if (mode == 3) orc_svf_band_mono(ms, len, &co[b], stMid + b * 2, sat);
+                else           orc_svf_band_mono(ms + len, len, &co[b], stSide + b * 2, sat);
+                for (int64_t i = 0; i < len; ++i) { L[i] = ms[i] + ms[len + i]; R[i] = ms[i] - ms[len + i]; }
+                free(ms);
             }
         }
         }

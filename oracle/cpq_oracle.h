@@ -142,12 +142,14 @@ void   orc_svf_band_stereo_lane(double* data, int64_t n, const orc_svf_coeffs* c
 /* :128-186 scalar mono kernel, no explicit FMA */
 void   orc_svf_band_mono(double* data, int64_t n, const orc_svf_coeffs* c,
                          double* state, double saturation);
-/* :1019-1276 serial structure, Stereo channel mode, AGC off, steady total gain.
+/* :1019-1276 (and the basic process(block), :486-1016, that Mid/Side bands fall back to): serial and parallel
+ * structures, every channel mode, total-gain ramp or AGC.
  * dataL/dataR in place; state: [2][20][2] filter states + 3 AGC doubles (envIn, envOut, gain-1) + 5 doubles of the
- * total-gain LinearRamp (initialised, current, target, step, remaining) = 88 doubles;
+ * total-gain LinearRamp (initialised, current, target, step, remaining) = 88 doubles, then the Mid and the Side
+ * band states ([20][2] each) = 168 doubles;
  * processed in blocks of blockSize like the caller does; AGC (processAGC, :367-445) when agcEnabled. */
 void   orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSize,
-                             const orc_eq_params* p, double sr, double* state /*[88]*/);
+                             const orc_eq_params* p, double sr, double* state /*[168]*/);
 
 /* ------------------------------------------------------- OutputFilter (N2) ---- */
 /* mirrors convo::BiquadCoeff, src/OutputFilter.h:40-44 */

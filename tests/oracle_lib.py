@@ -261,7 +261,7 @@ def eq_process_stereo(xl, xr, params, sr=48000.0, block=512, state=None):
     yl = np.array(xl, dtype=np.float64, copy=True)
     yr = np.array(xr, dtype=np.float64, copy=True)
     if state is None:
-        state = np.zeros(2 * 20 * 2 + 3 + 5, dtype=np.float64)
+        state = np.zeros(2 * 20 * 2 + 3 + 5 + 2 * 20 * 2, dtype=np.float64)
     lib().orc_eq_process_stereo(dp(yl), dp(yr), len(yl), block, C.byref(params), sr, dp(state))
     return yl, yr, state
 

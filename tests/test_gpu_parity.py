@@ -293,13 +293,13 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     with pytest.raises(amd.CpqError):
         eng.conv_process(x[:, :100])                    # not a multiple of the block size
     p = amd.eq_params_default()
-    p.bands[3].channel_mode = 3          # Mid/Side: falls back to the RCU path in the reference -> not implemented
+    p.bands[3].channel_mode = 5          # outside Stereo / Left / Right / Mid / Side
     with pytest.raises(amd.CpqError):
         eng.set_eq_params(0, p)
     eng.close()
-    long_ir = O.gen_ir(131072)
-    # FilterSpec with tail layers: per-layer spectral gains need the reference's layer partition sizes
-    eng = amd.BatchedEngine(1, max_ir_len=131072, max_blocks_per_call=2)
+    long_ir = O.gen_ir(524288)
+    # FilterSpec whose third layer has a 32768-sample partition: beyond the 4096-point workgroup FFT
+    eng = amd.BatchedEngine(1, max_ir_len=524288, max_blocks_per_call=2)
     with pytest.raises(amd.CpqError) as e4:
         eng.set_impulse(0, long_ir, long_ir, spec=amd.FilterSpec.defaults())
     assert e4.value.status == -5
@@ -622,7 +622,7 @@ def test_eq_total_gain_ramp_on_parameter_change(amd, oracle, mode):
     eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
     eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
     po = O.eq_params_bench(0.2)
-    state = [np.zeros(88), np.zeros(88)]
+    state = [np.zeros(168), np.zeros(168)]
     worst = 0.0
     for k in range(n_calls):
         if k in gains_db:
@@ -635,4 +635,76 @@ def test_eq_total_gain_ramp_on_parameter_change(amd, oracle, mode):
             worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
     print("gain ramp", mode, "max abs diff", worst)
     assert worst <= (0.0 if mode == "sequential" else 1e-13)
+    eng.close()
+
+
+@pytest.mark.parametrize("structure", [0, 1])
+@pytest.mark.parametrize("sat", [0.0, 0.2])
+def test_eq_mid_side_channel_modes(amd, oracle, sat, structure):
+    """Mid / Side bands.  The reference sends the whole call to the basic process(block)
+    (Processing.cpp:1036-1044): M = (L+R)/2, S = (L-R)/2, scalar processBand on one component with its own state,
+    L = M+S, R = M-S (:690-739 serial, :792-836 parallel); bands within 0.01 dB of flat are inactive on that path
+    (createBandNode, Coefficients.cpp:48-53).  Second stream keeps Stereo/Left/Right bands only (cache path)."""
+    O = oracle
+    S, T = 2, 5
+    x = make_inputs(O, S, 4 * T * B)
+    x[1] = 0.7 * x[1] + 0.5 * x[0]                      # correlated L/R so Mid and Side differ in level
+    po = [O.eq_params_bench(sat), O.eq_params_bench(sat)]
+    for q in po:
+        q.filterStructure = structure
+        q.totalGainDb = -1.25
+        q.bands[2].channelMode = 1
+        q.bands[7].channelMode = 2
+    for i in (0, 5, 11, 19):
+        po[0].bands[i].channelMode = 3
+    for i in (3, 8, 14):
+        po[0].bands[i].channelMode = 4
+    po[0].bands[6].gain = 0.005                          # flat: inactive on the basic path only
+    po[1].bands[6].gain = 0.005                          # ... but active (and saturating) on the cache path
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_eq_params(s, _copy_params(po[s], amd.eq_params_default()))
+    y = np.concatenate([eng.eq_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po[s])
+        assert np.array_equal(y[2 * s], yl) and np.array_equal(y[2 * s + 1], yr), (s, np.abs(y[2 * s] - yl).max())
+    assert rms(y[0] - x[0]) > 1e-3
+    eng.close()
+
+
+@pytest.mark.parametrize("kw,ir_len,block,T", [(dict(), 131072, 512, 8), (dict(), 131072, 512, 3),
+                                               (dict(tail_mode=0, tail_strength=1.6, hc_mode=0, tail_start_seconds=0.1), 131072, 512, 20),
+                                               (dict(tail_mode=0, lc_mode=1), 100000, 256, 5),
+                                               (dict(hc_mode=2, tail_strength=0.4), 50000, 64, 40),
+                                               (dict(), 100000, 256, 16)])
+def test_filter_spec_with_tail_layers(amd, oracle, kw, ir_len, block, T):
+    """non-NULL FilterSpec on a multi-layer plan.  The HC/LC gains (and, in tail mode 0, the air-absorption
+    damping) multiply every partition spectrum at that LAYER's FFT size (NUC.cpp:336-443, :1060-1097), so each tail
+    layer runs on the reference's own partition grid (4096 for B = 512) and reaches the output through the delay line
+    at done_callback * B.  Checked against the stateful NUC emulation with the same spec."""
+    O = oracle
+    names = {"hc_mode": "hcMode", "lc_mode": "lcMode", "tail_enabled": "tailEnabled", "tail_mode": "tailMode",
+             "sample_rate": "sampleRate", "tail_start_seconds": "tailStartSeconds", "tail_strength": "tailStrength"}
+    sa = amd.FilterSpec.defaults(**kw)
+    so = O.FilterSpec.defaults(applySpectrumFilter=1, **{names[k]: v for k, v in kw.items()})
+    irs = [O.gen_ir(ir_len, channel=ch) for ch in range(2)]
+    n_calls = max(4, (ir_len + 40000) // (T * block))
+    x = make_inputs(O, 1, n_calls * T * block)
+    ref = np.empty_like(x)
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], block, spec=so)
+        pl = nuc.plan()
+        assert pl.numLayers >= 2
+        ref[c] = nuc.run(x[c], block)
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=T)
+    eng.set_impulse(0, irs[0], irs[1], spec=sa)
+    y = np.concatenate([eng.conv_process(x[:, o:o + T * block]) for o in range(0, x.shape[1], T * block)], axis=1)
+    err = rms(y - ref)
+    # the plain h_eff convolution (no spectral shaping) must differ visibly: the test would not see a missing filter otherwise
+    print("filterspec+tails", kw, ir_len, block, T, "layers", pl.numLayers, "rms err", err, "signal", rms(ref))
+    assert err <= 1e-13 and rms(ref) > 1e-3
+    eng.conv_reset()
+    y2 = eng.conv_process(x[:, :T * block])
+    assert np.array_equal(y2, y[:, :T * block])            # Reset() restores the initial state of every layer
     eng.close()

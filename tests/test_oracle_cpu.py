@@ -210,3 +210,37 @@ def test_guards_zero_nonfinite(oracle):
 def test_equal_power_sin_quirk(oracle):
     v = oracle.lib().orc_equal_power_sin(1.0)
     assert abs(v - load("survey_observations.json")["equal_power_sin_1"]) < 1e-7 and v != 1.0
+
+
+def test_mid_side_bands_properties(oracle):
+    """Mid/Side bands (basic process(block), Processing.cpp:690-739): with L == R the Side component is zero, so Side
+    bands are the identity and Mid bands equal the scalar band kernel on the common signal; a flat (< 0.01 dB) band is
+    inactive on that path (createBandNode, Coefficients.cpp:48-53) although it is enabled."""
+    O = oracle
+    x = O.gen_pcm(2048)
+    p = O.eq_params_bench(0.2)
+    for b in range(20):
+        p.bands[b].enabled = 1 if b in (4, 9) else 0
+    p.bands[4].channelMode = 4            # Side
+    p.bands[9].channelMode = 3            # Mid
+    p.totalGainDb = 0.0
+    yl, yr, st = O.eq_process_stereo(x, x, p)
+    c = O.svf_design(p.bands[9].type, p.bands[9].frequency, p.bands[9].gain, p.bands[9].q, 48000.0)
+    # the Mid band sees M = (x + x) * 0.5 = x exactly and S = 0: L = M' + 0, R = M' - 0
+    m = x.copy()
+    stm = np.zeros(2)
+    O.lib().orc_svf_band_mono(O.dp(m), len(m), c, O.dp(stm), float(np.float32(0.2)))   # saturation is a float parameter
+    assert np.array_equal(yl, m) and np.array_equal(yr, m)
+    assert np.array_equal(st[88 + 2 * 9:88 + 2 * 9 + 2], stm) and not st[:80].any() and not st[128:].any()
+    # flat band: enabled, Peaking, |gain| < 0.01 dB -> skipped on the basic path, so the output does not change
+    p.bands[10].enabled = 1
+    p.bands[10].gain = 0.004
+    yl2, yr2, _ = O.eq_process_stereo(x, x, p)
+    assert np.array_equal(yl2, yl)
+    # without a Mid/Side band the same flat band is active (cache path) and the saturation blend alters the signal
+    p.bands[4].channelMode = 0
+    p.bands[9].channelMode = 0
+    a, _, _ = O.eq_process_stereo(x, x, p)
+    p.bands[10].enabled = 0
+    b, _, _ = O.eq_process_stereo(x, x, p)
+    assert np.abs(a - b).max() > 1e-6
