@@ -301,7 +301,7 @@ bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double*
         for (int q = 0; q < 4; ++q) r[q] = acc[q];
     };
     // layout: struct TpLcTables { Mk[6][4]; Mw[4]; P[64][4]; G[16][2]; } for LC = 16 then LC = 2 (svf_kernels.hip)
-    const int lcs[2] = { 16, 2 };
+    const int lcs[2] = { kSvfTpLc[0], kSvfTpLc[1] };
     constexpr int kPerLc = 6 * 4 + 4 + 64 * 4 + 16 * 2;
     for (int li = 0; li < 2; ++li) {
         double* o = out + li * kPerLc;

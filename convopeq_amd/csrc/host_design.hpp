@@ -7,6 +7,15 @@
 
 namespace cpq {
 
+// geometry of the time-parallel SVF kernel (svf_kernels.hip), shared with buildSvfTpTables()
+#ifndef CPQ_TP_WAVES
+#define CPQ_TP_WAVES 4          // waves per channel in k_svf_cascade_tp (4096-sample spans of 64*W chunks)
+#endif
+constexpr int kSvfTpWaves = CPQ_TP_WAVES;
+constexpr int kSvfTpLc[2] = { 4096 / (64 * kSvfTpWaves), 512 / (64 * kSvfTpWaves) };
+constexpr int kSvfTpLcDoubles = 6 * 4 + 4 + 64 * 4 + 16 * 2;
+constexpr int kSvfTpTableDoubles = 2 * kSvfTpLcDoubles;
+
 int    computeNucPlan(int irLen, int blockSize, bool enableDirectHead, const cpq_filter_spec* spec,
                       cpq_nuc_plan* out);
 int    buildHeff(const double* ir, int irLen, int blockSize, double scale, const cpq_filter_spec* spec,

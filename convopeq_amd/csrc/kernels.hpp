@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "host_design.hpp"
+
 namespace cpq {
 
 // partition size with dedicated wave-level FFT kernels; other powers of two (64..2048) use generic kernels
@@ -54,11 +56,9 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 // Time-parallel SVF cascade: one 4-wave workgroup per channel, 256 chunks of a span in flight per band
 // (zero-state chunk runs + state scan + linear state response), span resident in LDS across the 20 bands.
 // nSamples must be a multiple of 512.  tables: kSvfTpTableDoubles doubles per (stream, band):
-// for each chunk length LC in {16, 2}: Mk[6][4] = A^(LC 2^k), Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)),
+// for each chunk length LC in kSvfTpLc ({16, 2} at 4 waves per channel): Mk[6][4] = A^(LC 2^k), Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)),
 // G[16][2] = C A^i.
-constexpr int kSvfTpLc[2] = { 16, 2 };
-constexpr int kSvfTpLcDoubles = 6 * 4 + 4 + 64 * 4 + 16 * 2;
-constexpr int kSvfTpTableDoubles = 2 * kSvfTpLcDoubles;
+// geometry constants kSvfTpWaves / kSvfTpLc / kSvfTpTableDoubles: host_design.hpp (shared with the table builder)
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh,
                            int nSamples, const double* coef, const int* flags, const double* satGain,
                            double* state, const void* tables);

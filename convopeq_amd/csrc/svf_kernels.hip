@@ -213,11 +213,12 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
 // Result differs from the sequential recurrence by rounding only (measured <= 3e-15 abs over 20 bands).
 
 constexpr double kTpInputBound = 1.0e9;
-constexpr int kTpWaves = 4;                  // waves per channel
+constexpr int kTpWaves = kSvfTpWaves;        // waves per channel
 constexpr int kTpChunks = 64 * kTpWaves;     // chunks (= threads) per span
-constexpr int kTpLcMain = 16;                // samples per chunk, main spans (4096 samples)
-constexpr int kTpLcTail = 2;                 // samples per chunk, 512-sample remainder spans
-constexpr int kTpStride = kTpLcMain + 1;     // LDS row stride in doubles (odd: chunk rows on distinct banks)
+constexpr int kTpLcMain = kSvfTpLc[0];       // samples per chunk, main spans (4096 samples)
+constexpr int kTpLcTail = kSvfTpLc[1];       // samples per chunk, 512-sample remainder spans
+constexpr int kTpStride = kTpLcMain + 2;     // LDS row stride in doubles: rows 16-byte aligned for b128 access, 36 dwords
+                                             // apart so that 16 consecutive rows cover all 64 banks
 
 // per (stream, band); one block per chunk length (kTpLcMain, kTpLcTail); must match host buildSvfTpTables()
 struct TpLcTables {
@@ -232,11 +233,15 @@ struct TpBandTables { TpLcTables t[2]; };
 // fix-up of the generic fp64 division (v_div_scale / v_div_fmas / v_div_fixup, which serialise on VCC) are
 // no-ops and are omitted; what remains is the same Newton + residual sequence, so the quotient equals the IEEE
 // result for every normal-range quotient and independent divisions can be interleaved.
+// ONE_STEP (fast path of the time-parallel kernel): a single Newton step.  v_rcp_f64 is good to 4.6e-8 here, one step
+// leaves r within 2.2e-15 and the residual correction absorbs that: 0 mismatches against the IEEE quotient in 2.1e9
+// operand pairs of this range (tools/ubench/pade_div_check.hip); a miss would be a 1-ulp difference in fastTanh.
+template <bool ONE_STEP = false>
 __device__ __forceinline__ double pade_div(double num, double den)
 {
     double r = __builtin_amdgcn_rcp(den);
     r = fma(fma(-den, r, 1.0), r, r);
-    r = fma(fma(-den, r, 1.0), r, r);
+    if (!ONE_STEP) r = fma(fma(-den, r, 1.0), r, r);
     const double q = num * r;
     return fma(fma(-den, q, num), r, q);
 }
@@ -251,16 +256,22 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 #pragma unroll
         for (int j = 0; j < N; ++j) xc[j] = MONO ? y[j] : fmin(fmax(y[j], -4.5), 4.5);
 #pragma unroll
-        for (int j = 0; j < N; ++j) { const double x2 = xc[j] * xc[j]; num[j] = xc[j] * (27.0 + x2); den[j] = 27.0 + 9.0 * x2; }
+        for (int j = 0; j < N; ++j) {
+            const double x2 = xc[j] * xc[j];
+            num[j] = xc[j] * (27.0 + x2);
+            // fast path: one rounding less in the denominator and in the blend (rounding-level, like the rest of the
+            // time-parallel evaluation); the guarded path keeps the reference's operation order
+            den[j] = GUARD ? (27.0 + 9.0 * x2) : fma(9.0, x2, 27.0);
+        }
 #pragma unroll
-        for (int j = 0; j < N; ++j) num[j] = pade_div(num[j], den[j]);
+        for (int j = 0; j < N; ++j) num[j] = pade_div<!GUARD>(num[j], den[j]);
         if (MONO) {
             // scalar fastTanh: +-1 beyond the clip threshold (FastTanhApprox.h:101-107)
 #pragma unroll
             for (int j = 0; j < N; ++j) { num[j] = (y[j] >= 4.5) ? 1.0 : num[j]; num[j] = (y[j] <= -4.5) ? -1.0 : num[j]; }
         }
 #pragma unroll
-        for (int j = 0; j < N; ++j) y[j] = (y[j] * oneMinusSat) + (num[j] * sat);
+        for (int j = 0; j < N; ++j) y[j] = GUARD ? ((y[j] * oneMinusSat) + (num[j] * sat)) : fma(num[j], sat, y[j] * oneMinusSat);
     }
     // output guard (non-finite or |y| >= 1e15 -> 0): the host only enables the time-parallel kernel when it has
     // proven |y| stays below 1e15 for every span this path accepts (inputs and carried states below kTpInputBound),
@@ -320,47 +331,90 @@ struct TpLds {
     double G[kBands][32];        // G[16][2]
 };
 
-// chunk start states of band b from the chunk end states (ic1, ic2) of the zero-state runs
+// cross-lane move of a double through the DPP network (2 x v_mov_b32_dpp, no LDS traffic); lanes whose source is
+// outside the row / wave, and rows disabled by ROWMASK, receive +0.0
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kDppRowShr = 0x110;      // + n: lane i <- lane i-n inside its row of 16
+constexpr int kDppWaveShr1 = 0x138;    // lane i <- lane i-1 across the whole wave
+constexpr int kDppRowBcast15 = 0x142;  // lane 15 of each row -> every lane of the next row
+constexpr int kDppRowBcast31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
+
+// chunk start states of band b from the chunk end states (ic1, ic2) of the zero-state runs: inclusive scan of
+// S_c = M S_(c-1) + e_c.  Inside a wave: 4 shift-and-combine steps within each row of 16 lanes (row_shr 1/2/4/8 with
+// the powers A^(LC 2^k)), then lane 15 of a row carries into the next row and lane 31 into the upper half
+// (row_bcast 15/31) with per-lane powers A^(LC (n+1)), n = lane mod 16 / mod 32; across the W waves the totals are
+// chained through LDS as before.
 __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const TpLds* L, int b,
                                         const double* __restrict__ Pglob, double* wtot, double* sState, int tid)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    // this lane's power A^(LC (lane+1)): issued now, consumed after the in-wave scan
-    const double p0 = Pglob[lane * 4 + 0], p1 = Pglob[lane * 4 + 1], p2 = Pglob[lane * 4 + 2], p3 = Pglob[lane * 4 + 3];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the chain below branches on it
+    // per-lane powers, issued now and consumed after the row scan
+    const double2* Pv = reinterpret_cast<const double2*>(Pglob);
+    const double2 pa01 = Pv[(lane & 15) * 2], pa23 = Pv[(lane & 15) * 2 + 1];
+    const double2 pb01 = Pv[(lane & 31) * 2], pb23 = Pv[(lane & 31) * 2 + 1];
+    const double2 pc01 = Pv[lane * 2], pc23 = Pv[lane * 2 + 1];
+    // band row of the LDS tables through a VGPR base, so that every read below is base + immediate offset
+    uint32_t mOff = (uint32_t)b * (uint32_t)sizeof(L->M[0]);
+    asm volatile("" : "+v"(mOff));
+    const double* Mb = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&L->M[0][0]) + mOff);
     double sx = ic1, sy = ic2;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double k0 = L->M[b][k * 4 + 0], k1 = L->M[b][k * 4 + 1], k2 = L->M[b][k * 4 + 2], k3 = L->M[b][k * 4 + 3];
-        const double px = __shfl_up(sx, 1 << k);
-        const double py = __shfl_up(sy, 1 << k);
-        if (lane >= (1 << k)) {
-            const double nx = fma(k1, py, fma(k0, px, sx));
-            const double ny = fma(k3, py, fma(k2, px, sy));
-            sx = nx;
-            sy = ny;
-        }
+#define CPQ_ROW_STEP(k)                                                                                       \
+    {                                                                                                         \
+        const double k0 = Mb[(k) * 4 + 0], k1 = Mb[(k) * 4 + 1], k2 = Mb[(k) * 4 + 2], k3 = Mb[(k) * 4 + 3];  \
+        const double px = dpp_f64<kDppRowShr + (1 << (k)), 0xF>(sx);                                          \
+        const double py = dpp_f64<kDppRowShr + (1 << (k)), 0xF>(sy);                                          \
+        const double nx = fma(k1, py, fma(k0, px, sx));                                                       \
+        const double ny = fma(k3, py, fma(k2, px, sy));                                                       \
+        sx = nx;                                                                                              \
+        sy = ny;                                                                                              \
+    }
+    CPQ_ROW_STEP(0)
+    CPQ_ROW_STEP(1)
+    CPQ_ROW_STEP(2)
+    CPQ_ROW_STEP(3)
+#undef CPQ_ROW_STEP
+    {   // rows 1 and 3 <- total of the row below
+        const double px = dpp_f64<kDppRowBcast15, 0xA>(sx);
+        const double py = dpp_f64<kDppRowBcast15, 0xA>(sy);
+        const double nx = fma(pa01.y, py, fma(pa01.x, px, sx));
+        const double ny = fma(pa23.y, py, fma(pa23.x, px, sy));
+        sx = nx;
+        sy = ny;
+    }
+    {   // rows 2 and 3 <- total of the lower half
+        const double px = dpp_f64<kDppRowBcast31, 0xC>(sx);
+        const double py = dpp_f64<kDppRowBcast31, 0xC>(sy);
+        const double nx = fma(pb01.y, py, fma(pb01.x, px, sx));
+        const double ny = fma(pb23.y, py, fma(pb23.x, px, sy));
+        sx = nx;
+        sy = ny;
     }
     if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
     __syncthreads();
-    // state at the start of this wave's segment: chain the totals of the preceding waves
+    // state at the start of this wave's segment: the span's start state carried through the totals of the waves before it
     double bx = sState[2 * b], by = sState[2 * b + 1];
-    const double mw0 = L->M[b][24], mw1 = L->M[b][25], mw2 = L->M[b][26], mw3 = L->M[b][27];
-    double endx = bx, endy = by;
-#pragma unroll
-    for (int w = 0; w < kTpWaves; ++w) {
+    const double mw0 = Mb[24], mw1 = Mb[25], mw2 = Mb[26], mw3 = Mb[27];
+    for (int w = 0; w < wave; ++w) {
         const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
-        const double nx = fma(mw1, endy, fma(mw0, endx, tx));
-        const double ny = fma(mw3, endy, fma(mw2, endx, ty));
-        endx = nx; endy = ny;
-        if (w + 1 == wave) { bx = endx; by = endy; }
+        const double nx = fma(mw1, by, fma(mw0, bx, tx));
+        const double ny = fma(mw3, by, fma(mw2, bx, ty));
+        bx = nx;
+        by = ny;
     }
-    sx = fma(p1, by, fma(p0, bx, sx));
-    sy = fma(p3, by, fma(p2, bx, sy));
-    s0x = __shfl_up(sx, 1);
-    s0y = __shfl_up(sy, 1);
+    sx = fma(pc01.y, by, fma(pc01.x, bx, sx));
+    sy = fma(pc23.y, by, fma(pc23.x, bx, sy));
+    s0x = dpp_f64<kDppWaveShr1, 0xF>(sx);
+    s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
     if (lane == 0) { s0x = bx; s0y = by; }
     __syncthreads();                          // every thread has read sState[b] and wtot
-    if (tid == 0) { sState[2 * b] = endx; sState[2 * b + 1] = endy; }
+    if (tid == kTpChunks - 1) { sState[2 * b] = sx; sState[2 * b + 1] = sy; }     // end of the span
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
@@ -388,6 +442,30 @@ __device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sa
         }
     sState[0] = ic1;
     sState[1] = ic2;
+}
+
+// U samples of a chunk row <-> registers; rows are 16-byte aligned (kTpStride even), so pairs move as one b128 access
+template <int U>
+__device__ __forceinline__ void tp_row_load(double (&v)[U], const double* p)
+{
+    if (U % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < U; j += 2) { const double2 t = *reinterpret_cast<const double2*>(p + j); v[j] = t.x; v[j + (U > 1)] = t.y; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = p[j];
+    }
+}
+template <int U>
+__device__ __forceinline__ void tp_row_store(const double (&v)[U], double* p)
+{
+    if (U % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < U; j += 2) *reinterpret_cast<double2*>(p + j) = make_double2(v[j], v[j + (U > 1)]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) p[j] = v[j];
+    }
 }
 
 // One span (kTpChunks chunks of LC samples) through all active bands.  Every thread owns one chunk = one LDS
@@ -443,13 +521,11 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 #pragma unroll 1
                 for (int i0 = 0; i0 < LC; i0 += U) {
                     double v[U];
-#pragma unroll
-                    for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
+                    tp_row_load<U>(v, row + i0);
                     if (kind == 2)      tp_recur<2, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
                     else if (kind == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
                     else                tp_recur<0, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-#pragma unroll
-                    for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
+                    tp_row_store<U>(v, row + i0);
                 }
             }
             while (b < kBands) {
@@ -457,6 +533,10 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
                 while (nb < kBands && !(fl[nb] & 1)) ++nb;     // next active band (uniform)
                 double s0x, s0y;
                 tp_scan(ic1, ic2, s0x, s0y, L, b, &tb[b].t[LCI].P[0][0], wtot, sState, tid);
+                // response table row of band b through a VGPR base: reads below are base + immediate offset
+                uint32_t gOff = (uint32_t)b * (uint32_t)sizeof(L->G[0]);
+                asm volatile("" : "+v"(gOff));
+                const double* Gb = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&L->G[0][0]) + gOff);
                 const int kindB = (fl[b] >> 1) & 3;
                 const bool hasNext = nb < kBands;
                 const int kindN = hasNext ? ((fl[nb] >> 1) & 3) : 0;
@@ -469,11 +549,10 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 #pragma unroll 1
                 for (int i0 = 0; i0 < LC; i0 += U) {
                     double v[U];
-#pragma unroll
-                    for (int j = 0; j < U; ++j) v[j] = row[i0 + j];
+                    tp_row_load<U>(v, row + i0);
 #pragma unroll
                     for (int j = 0; j < U; ++j)
-                        v[j] = fma(L->G[b][2 * (i0 + j) + 1], s0y, fma(L->G[b][2 * (i0 + j)], s0x, v[j]));
+                        v[j] = fma(Gb[2 * (i0 + j) + 1], s0y, fma(Gb[2 * (i0 + j)], s0x, v[j]));
                     if (kindB == 1)      tp_nonlinear<true, SAT, U, false>(v, sat, oneMinusSat);
                     else if (kindB == 0) tp_nonlinear<false, SAT, U, false>(v, sat, oneMinusSat);
                     // kindB == 2 (OutputFilter biquad): linear section, no output stage
@@ -482,8 +561,7 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
                         else if (kindN == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
                         else                 tp_recur<0, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
                     }
-#pragma unroll
-                    for (int j = 0; j < U; ++j) row[i0 + j] = v[j];
+                    tp_row_store<U>(v, row + i0);
                 }
                 b = nb;
             }
