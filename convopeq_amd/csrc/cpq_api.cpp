@@ -45,7 +45,6 @@ struct SpecTail {
     int P = 0, K = 0, kPad = 0, hRows = 0, ringSlots = 0, nbMax = 0, accCap = 0, outRing = 0;
     int head = 0, histSel = 0, accSel = 0, fill = 0;
     long long blocksDone = 0;
-    int delay = 0;              // done_callback * B: absolute lag of block j's output behind its first input sample
     double gain = 1.0;          // tail-layer gain applied by the delay-line reader
     char* mem = nullptr;
     double2 *X = nullptr, *XDN = nullptr, *H = nullptr, *HDN = nullptr, *Y = nullptr, *tw = nullptr, *tw2 = nullptr;
@@ -148,7 +147,8 @@ struct cpq_engine {
     // FilterSpec plans with tail layers (LTI-valid ones): layer 0 runs in the main path, each tail layer in a SpecTail
     std::vector<SpecTail> specTails;
     cpq_nuc_plan specPlan{};
-    long long specPos = 0;              // absolute sample position of the next call
+    void* specState = nullptr;          // device: callback counter + delay-line read cursors of the tail layers
+    long long* specSched = nullptr;     // device: [2][callbacks per call] read positions (-1 = the reader skips)
 
     // processor-level wrapper (N1)
     int convLevel = CPQ_LEVEL_NUC;
@@ -231,6 +231,10 @@ void freeSpecTails(cpq_engine* e)
 {
     for (SpecTail& t : e->specTails) if (t.mem) (void)hipFree(t.mem);
     e->specTails.clear();
+    if (e->specState) (void)hipFree(e->specState);
+    if (e->specSched) (void)hipFree(e->specSched);
+    e->specState = nullptr;
+    e->specSched = nullptr;
 }
 
 int resetSpecTails(cpq_engine* e)
@@ -246,7 +250,7 @@ int resetSpecTails(cpq_engine* e)
         t.head = t.histSel = t.accSel = t.fill = 0;
         t.blocksDone = 0;
     }
-    e->specPos = 0;
+    if (e->specState) CPQ_HIP(e, hipMemsetAsync(e->specState, 0, 3 * sizeof(long long), e->stream));
     return CPQ_OK;
 }
 
@@ -264,9 +268,9 @@ int allocSpecTails(cpq_engine* e, const cpq_nuc_plan& pl)
         t.nbMax = (t.P - 1 + nMax) / t.P;
         t.ringSlots = nextPow2(t.kPad + cpq::kMacMaxTile + t.nbMax);
         t.accCap = t.P + nMax;
-        t.delay = pl.done_callback[l] * e->B;
         t.gain = pl.gain[l];
-        t.outRing = nextPow2(t.delay + 2 * t.P + nMax);
+        // the reader is at most outputDelay + one partition behind the writer
+        t.outRing = nextPow2(pl.output_delay[l] + 3 * t.P + nMax + e->B);
         struct Item { void** ptr; int64_t bytes; };
         Item items[] = {
             { (void**)&t.X, nCh * t.ringSlots * t.P * (int64_t)sizeof(double2) },
@@ -306,8 +310,14 @@ int allocSpecTails(cpq_engine* e, const cpq_nuc_plan& pl)
         CPQ_HIP(e, hipMemcpy(t.tw, w.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
         CPQ_HIP(e, hipMemcpy(t.tw2, w2.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
     }
+    if (hipMalloc(&e->specState, 3 * sizeof(long long)) != hipSuccess ||
+        hipMalloc((void**)&e->specSched, sizeof(long long) * 2 * (size_t)(nMax / e->B)) != hipSuccess) {
+        (void)hipGetLastError();
+        freeSpecTails(e);
+        return fail(e, CPQ_ERR_OOM, "FilterSpec tail schedule buffers could not be allocated");
+    }
+    CPQ_HIP(e, hipMemset(e->specState, 0, 3 * sizeof(long long)));
     e->specPlan = pl;
-    e->specPos = 0;
     return CPQ_OK;
 }
 
@@ -320,10 +330,23 @@ void specTailsAppend(cpq_engine* e, const double* dIn, int n)
 }
 
 // every partition that filled up is convolved (FFT, FDL push, MAC over the layer's partitions, IFFT; NUC.cpp:1456-1544)
-// and written to the layer's delay line at the position the reference's reader takes it from (block j is read from
-// callback done_callback on); then the reader adds gain * delay line to the call's output (:1653-1688)
+// and appended to the layer's delay line; the reference's reader (:1653-1688: readStart = max(readCursor, writeCursor -
+// outputDelay), skip when the writer is not far enough ahead) is replayed per callback by k_tail_schedule, so both the
+// constant-lag (LTI) plans and the block-skipping ones come out as in the reference
 int specTailsRun(cpq_engine* e, double* dOut, int n)
 {
+    const cpq_nuc_plan& pl = e->specPlan;
+    const int nTail = (int)e->specTails.size();
+    const int T = n / e->B;
+    {
+        ProfScope p(e, CPQ_K_MIX);
+        const int ppc1 = pl.parts_per_callback[1], ppc2 = nTail > 1 ? pl.parts_per_callback[2] : 1;
+        const int d1 = (pl.num_parts_ir[1] + ppc1 - 1) / ppc1 - 1;
+        const int d2 = nTail > 1 ? (pl.num_parts_ir[2] + ppc2 - 1) / ppc2 - 1 : 0;
+        cpq::launch_tail_schedule(e->stream, e->specState, e->specSched, T, e->B, nTail, pl.part_size[1], pl.output_delay[1], d1,
+                                  nTail > 1 ? pl.part_size[2] : e->B, nTail > 1 ? pl.output_delay[2] : 0, d2);
+    }
+    int li = 0;
     for (SpecTail& t : e->specTails) {
         const int total = t.fill + n;
         const int nb = total / t.P;
@@ -350,8 +373,8 @@ int specTailsRun(cpq_engine* e, double* dOut, int n)
                 cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, e->nCh, nb);
             }
             ProfScope p(e, CPQ_K_MIX);
-            cpq::launch_ring_put(e->stream, t.z, (int64_t)t.nbMax * t.P, nb * t.P, t.ring, t.outRing,
-                                 t.blocksDone * t.P + t.delay, e->nCh);
+            cpq::launch_ring_put(e->stream, t.z, (int64_t)t.nbMax * t.P, nb * t.P, t.ring, t.outRing, t.blocksDone * t.P,
+                                 e->nCh);
             cpq::launch_rows_copy(e->stream, t.acc[t.accSel], t.accCap, (int64_t)nb * t.P, t.acc[t.accSel ^ 1], t.accCap, 0, rem,
                                   e->nCh);
             t.blocksDone += nb;
@@ -361,9 +384,9 @@ int specTailsRun(cpq_engine* e, double* dOut, int n)
         }
         t.fill = rem;
         ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_ring_add(e->stream, dOut, n, n, t.ring, t.outRing, e->specPos, t.gain, e->nCh);
+        cpq::launch_ring_add(e->stream, dOut, n, n, e->B, t.ring, t.outRing, e->specSched + (size_t)li * T, t.gain, e->nCh);
+        ++li;
     }
-    e->specPos += n;
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
 }
@@ -899,8 +922,6 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         if (direct) return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec together with the direct head is not implemented");
         if (e->desc.semantics != CPQ_SEM_REFERENCE) return fail(e, CPQ_ERR_INVALID_ARG, "FilterSpec requires reference semantics");
         if (sp.num_layers > 1) {
-            if (!sp.lti_valid)
-                return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec on a time-varying plan (tail partition longer than the IR before it) is not implemented");
             if (e->layered) return fail(e, CPQ_ERR_UNSUPPORTED, "engine is in time-varying (layered) mode");
             for (int l = 1; l < sp.num_layers; ++l)
                 if (sp.part_size[l] > 4096 || (sp.part_size[l] & (sp.part_size[l] - 1)))

@@ -94,7 +94,10 @@ void launch_rows_copy(hipStream_t stream, const double* src, int64_t srcStride, 
                       int64_t dstStride, int64_t dstOff, int n, int nCh);
 void launch_ring_put(hipStream_t stream, const double* z, int64_t zStride, int n, double* ring, int ringSize,
                      long long pos, int nCh);
-void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, const double* ring, int ringSize,
-                     long long pos, double gain, int nCh);
+void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, int B, const double* ring, int ringSize,
+                     const long long* sched, double gain, int nCh);
+// replay of the delay-line reader for the T callbacks of a call (state: 3 long long; sched: [nTail][T], -1 = skip)
+void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,
+                          int pl2, int ol2, int d2);
 
 }  // namespace cpq

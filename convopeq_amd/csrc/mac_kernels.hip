@@ -104,13 +104,18 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
                                                                   const int* __restrict__ irSlot,
                                                                   double2* __restrict__ Y, int kPad, int ringMask,
                                                                   int head, int T, int nGroups, int64_t hSlotStride,
-                                                                  int P, int nCols)
+                                                                  int P, int nCols, int nWork)
 {
     __shared__ double2 ring[kWgRingBlocks * kWgTile * 64];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int grp = blockIdx.x % nGroups;
-    const int cg = blockIdx.x / nGroups;
+    // workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8): give each XCD a contiguous range of logical ids so
+    // that the nGroups workgroups of one (channel, column) -- same IR rows, overlapping FDL rows -- share one L2
+    const int perXcd = gridDim.x >> 3;                       // the grid is padded to a multiple of 8
+    const int logical = (blockIdx.x & 7) * perXcd + (blockIdx.x >> 3);
+    if (logical >= nWork) return;                            // uniform per workgroup: no barrier is skipped by part of it
+    const int grp = logical % nGroups;
+    const int cg = logical / nGroups;
     const int c = cg / nCols;
     const int bin = (cg - c * nCols) * 64 + lane;
     const int base = head + grp * (kWgWaves * kWgTile);          // FDL slot of the group's first output block
@@ -232,8 +237,9 @@ void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double
     if (tile == 0 && T >= 32) {      // default for long calls: workgroup-cooperative kernel
         const int nGroups = (T + kWgWaves * kWgTile - 1) / (kWgWaves * kWgTile);
         const int nCols = P / 64;
-        hipLaunchKernelGGL((k_fdl_mac_wg<4>), dim3(nCh * nCols * nGroups), dim3(64 * kWgWaves), 0, stream, X, H,
-                           irSlot, Y, kPad, ringSlots - 1, head, T, nGroups, hSlotStride, P, nCols);
+        const int nWork = nCh * nCols * nGroups;
+        hipLaunchKernelGGL((k_fdl_mac_wg<4>), dim3((nWork + 7) / 8 * 8), dim3(64 * kWgWaves), 0, stream, X, H,
+                           irSlot, Y, kPad, ringSlots - 1, head, T, nGroups, hSlotStride, P, nCols, nWork);
         return;
     }
     const int pf = 4;     // prefetch depth in partition steps (deeper measured slower: register pressure)

@@ -233,15 +233,20 @@ __global__ __launch_bounds__(256) void k_ring_put(const double* __restrict__ z, 
         r[(pos + i) & mask] = s[i];
 }
 
-// out[c][i] += ring[c][(pos + i) & mask] * gain  (delayLineReadAdd, NUC.cpp:1653-1688)
-__global__ __launch_bounds__(256) void k_ring_add(double* out, int64_t outStride, int n, const double* __restrict__ ring,
-                                                  int mask, long long pos, double gain)
+// delayLineReadAdd (NUC.cpp:1653-1688) for the callbacks of one call: callback cb reads B samples at delay-line position
+// sched[cb] (k_tail_schedule replays the reader; -1 = "writer not far enough ahead", nothing is added):
+// out[c][cb B + j] += ring[c][(sched[cb] + j) & mask] * gain
+__global__ __launch_bounds__(256) void k_ring_add(double* out, int64_t outStride, int n, int B, const double* __restrict__ ring,
+                                                  int mask, const long long* __restrict__ sched, double gain)
 {
     double* o = out + (int64_t)blockIdx.y * outStride;
     const double* r = ring + (int64_t)blockIdx.y * (mask + 1);
     const bool unity = fabs(gain - 1.0) < 1.0e-12;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double v = r[(pos + i) & mask];
+        const int cb = i / B, j = i - cb * B;
+        const long long s0 = sched[cb];
+        if (s0 < 0) continue;
+        const double v = r[(s0 + j) & mask];
         o[i] = unity ? (o[i] + v) : (o[i] + v * gain);
     }
 }
@@ -315,11 +320,18 @@ void launch_ring_put(hipStream_t stream, const double* z, int64_t zStride, int n
     hipLaunchKernelGGL(k_ring_put, rowsGrid(n, nCh), dim3(256), 0, stream, z, zStride, n, ring, ringSize - 1, pos);
 }
 
-void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, const double* ring, int ringSize,
-                     long long pos, double gain, int nCh)
+void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, int B, const double* ring, int ringSize,
+                     const long long* sched, double gain, int nCh)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_ring_add, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, n, ring, ringSize - 1, pos, gain);
+    hipLaunchKernelGGL(k_ring_add, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, n, B, ring, ringSize - 1, sched, gain);
+}
+
+void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,
+                          int pl2, int ol2, int d2)
+{
+    hipLaunchKernelGGL(k_tail_schedule, dim3(1), dim3(64), 0, stream, reinterpret_cast<TailState*>(state), sched, T, B, nTail,
+                       make_int2(pl1, ol1), make_int2(pl2, ol2), d1, d2);
 }
 
 }  // namespace cpq

@@ -676,7 +676,12 @@ def test_eq_mid_side_channel_modes(amd, oracle, sat, structure):
                                                (dict(tail_mode=0, tail_strength=1.6, hc_mode=0, tail_start_seconds=0.1), 131072, 512, 20),
                                                (dict(tail_mode=0, lc_mode=1), 100000, 256, 5),
                                                (dict(hc_mode=2, tail_strength=0.4), 50000, 64, 40),
-                                               (dict(), 100000, 256, 16)])
+                                               (dict(), 100000, 256, 16),
+                                               # time-varying in the reference (tail partition 4096 > layer-0 length 4080 / 2640):
+                                               # the delay-line reader skips blocks; replayed by k_tail_schedule
+                                               (dict(tail_mode=0), 131072, 512, 8),
+                                               (dict(tail_mode=0, tail_strength=0.7, hc_mode=1), 131072, 512, 3),
+                                               (dict(tail_mode=0, tail_start_seconds=0.03), 60000, 512, 5)])
 def test_filter_spec_with_tail_layers(amd, oracle, kw, ir_len, block, T):
     """non-NULL FilterSpec on a multi-layer plan.  The HC/LC gains (and, in tail mode 0, the air-absorption
     damping) multiply every partition spectrum at that LAYER's FFT size (NUC.cpp:336-443, :1060-1097), so each tail
@@ -702,9 +707,42 @@ def test_filter_spec_with_tail_layers(amd, oracle, kw, ir_len, block, T):
     y = np.concatenate([eng.conv_process(x[:, o:o + T * block]) for o in range(0, x.shape[1], T * block)], axis=1)
     err = rms(y - ref)
     # the plain h_eff convolution (no spectral shaping) must differ visibly: the test would not see a missing filter otherwise
-    print("filterspec+tails", kw, ir_len, block, T, "layers", pl.numLayers, "rms err", err, "signal", rms(ref))
+    print("filterspec+tails", kw, ir_len, block, T, "layers", pl.numLayers, "lti", pl.ltiValid, "rms err", err, "signal", rms(ref))
     assert err <= 1e-13 and rms(ref) > 1e-3
     eng.conv_reset()
     y2 = eng.conv_process(x[:, :T * block])
     assert np.array_equal(y2, y[:, :T * block])            # Reset() restores the initial state of every layer
+    eng.close()
+
+
+def test_filter_spec_tails_shared_ir_in_place_whole_path(amd, oracle):
+    """FilterSpec tail layers with one shared stereo IR (CPQ_ALL_STREAMS), the device entry point called IN PLACE
+    (d_in == d_out: the tail layers must take their input before layer 0 overwrites it) and the EQ behind it."""
+    import torch
+    O = oracle
+    S, T, ir_len = 3, 6, 70000
+    sa = amd.FilterSpec.defaults(hc_mode=0)
+    so = O.FilterSpec.defaults(applySpectrumFilter=1, hcMode=0)
+    irs = [O.gen_ir(ir_len, channel=ch) for ch in range(2)]
+    x = make_inputs(O, S, 30 * T * B)
+    po = O.eq_params_bench(0.2)
+    eng = amd.BatchedEngine(S, max_ir_len=ir_len, max_blocks_per_call=T)
+    eng.set_impulse(amd.CPQ_ALL_STREAMS, irs[0], irs[1], spec=sa)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    outs = []
+    for o in range(0, x.shape[1], T * B):
+        d = torch.from_numpy(np.ascontiguousarray(x[:, o:o + T * B])).cuda()
+        eng.process_device(d.data_ptr(), d.data_ptr(), T * B)
+        torch.cuda.synchronize()
+        outs.append(d.cpu().numpy())
+    y = np.concatenate(outs, axis=1)
+    for s in range(S):
+        w = []
+        for ch in range(2):
+            nuc = O.Nuc()
+            assert nuc.set_impulse(irs[ch], B, spec=so) and nuc.plan().numLayers == 2
+            w.append(nuc.run(x[2 * s + ch], B))
+        el, er, _ = O.eq_process_stereo(w[0], w[1], po)
+        assert rms(y[2 * s] - el) <= 1e-13 and rms(y[2 * s + 1] - er) <= 1e-13, (s, rms(y[2 * s] - el))
     eng.close()
