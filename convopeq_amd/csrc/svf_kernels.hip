@@ -289,6 +289,24 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
     }
 }
 
+// Output stage when every |y| of the group is below the fastTanh clip threshold (4.5): neither the argument clamp, nor
+// the scalar path's hard +-1, nor the +-100 clamp can act (|out| <= |y| for 0 <= sat <= 1), and the blend folds into
+// one rational function:  y (1 - s) + s y (27 + y^2) / (27 + 9 y^2)  =  y (27 + (9 - 8 s) y^2) / (27 + 9 y^2).
+// Same value as the reference expression up to rounding (one division, no separate blend); both band kinds share it.
+template <int N>
+__device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
+{
+    double num[N], den[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double x2 = y[j] * y[j];
+        num[j] = y[j] * fma(c1, x2, 27.0);
+        den[j] = fma(9.0, x2, 27.0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) y[j] = pade_div<true>(num[j], den[j]);
+}
+
 // zero-state (or continuing) recurrence of one band over N samples held in registers: v[j] <- y_lin[j]
 // KIND: 0 = SVF, packed stereo arithmetic (FMA), 1 = SVF scalar arithmetic (Left/Right modes), 2 = DF-II-T biquad
 // of the OutputFilter (coefficients b0 b1 b2 a1 a2 in a1 a2 a3 m0 m1; state w1 w2 in ic1 ic2)
@@ -480,6 +498,8 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
     constexpr int LCI = (LC == kTpLcMain) ? 0 : 1;
     constexpr int U = (LC < 8) ? LC : 8;
     const double oneMinusSat = 1.0 - sat;
+    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);      // |out| <= |y| on the small-signal output stage
+    const double smallC1 = 9.0 - 8.0 * sat;
     // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
     bool bad = false;
 #pragma unroll 4
@@ -553,9 +573,15 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 #pragma unroll
                     for (int j = 0; j < U; ++j)
                         v[j] = fma(Gb[2 * (i0 + j) + 1], s0y, fma(Gb[2 * (i0 + j)], s0x, v[j]));
-                    if (kindB == 1)      tp_nonlinear<true, SAT, U, false>(v, sat, oneMinusSat);
-                    else if (kindB == 0) tp_nonlinear<false, SAT, U, false>(v, sat, oneMinusSat);
-                    // kindB == 2 (OutputFilter biquad): linear section, no output stage
+                    if (kindB != 2) {     // kindB == 2 (OutputFilter biquad): linear section, no output stage
+                        double big = fabs(v[0]);
+#pragma unroll
+                        for (int j = 1; j < U; ++j) big = fmax(big, fabs(v[j]));
+                        if (smallOk && __all(big < 4.5)) {          // wave-uniform: the usual case at audio levels
+                            if (SAT) tp_nonlinear_small<U>(v, smallC1);
+                        } else if (kindB == 1) tp_nonlinear<true, SAT, U, false>(v, sat, oneMinusSat);
+                        else                   tp_nonlinear<false, SAT, U, false>(v, sat, oneMinusSat);
+                    }
                     if (hasNext) {
                         if (kindN == 2)      tp_recur<2, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
                         else if (kindN == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
