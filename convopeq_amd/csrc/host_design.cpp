@@ -328,6 +328,14 @@ bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double*
 
     // guard-freedom proof: sup_n |A^n|_inf (carried state) and the l1 gain input -> state must keep every
     // state below 1e15 for |input|, |carried state| < 1e9 (one decade of margin)
+    // spectral radius first: a section that does not decay (bypass coefficients: A = I) or decays too slowly for the
+    // bounded iteration below is rejected without running it
+    {
+        const ld tr = A[0] + A[3], det = A[0] * A[3] - A[1] * A[2], disc = tr * tr - 4 * det;
+        const ld rho = disc < 0 ? std::sqrt(std::fabs(det))
+                                : std::max(std::fabs(tr + std::sqrt(disc)), std::fabs(tr - std::sqrt(disc))) / 2;
+        if (!(rho < 1.0L - 6.0e-6L)) return false;
+    }
     ld Q[4] = { 1, 0, 0, 1 };
     ld s[2] = { Bv[0], Bv[1] };
     ld kappa = 1, l1 = 0;
