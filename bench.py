@@ -239,6 +239,18 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
+
+    # The same MAC path with ONE partition per call (the reference's own call pattern): every FDL and IR row is
+    # streamed for a single output row, so the kernel is HBM-bound there, whereas at T blocks per call it is past the
+    # fp64 ridge.  Measured after the timed region (not part of `value`) to give the roofline object both regimes.
+    prof1 = None
+    if not (args.eq_only or args.host_buffers) and rank == 0:
+        P1 = args.partition if args.partition else B
+        eng.profile_reset()
+        for _ in range(40):
+            eng.conv_process_device(d_in.data_ptr(), d_out.data_ptr(), P1)
+        torch.cuda.synchronize()
+        prof1 = eng.profile_read()
     eng.profile_enable(False)
 
     samples = float(S) * n * args.steps          # stereo samples this rank processed
@@ -283,6 +295,15 @@ def main():
         if "k_fdl_mac" in co_dominant:
             dominant = "k_fdl_mac"
         dk = per_kernel[dominant]
+        hbm_regime = None
+        if prof1 and prof1.get("k_fdl_mac", (0, 0.0))[0] > 0:
+            cnt1, ms1 = prof1["k_fdl_mac"]
+            b1 = (n_ch * k_parts + ir_rows + n_ch) * spec_bytes
+            gbs1 = b1 / (ms1 / cnt1 * 1e-3) / 1e9
+            hbm_regime = {"kernel": "k_fdl_mac", "blocks_per_call": P // B, "algorithmic_bytes_per_launch": b1,
+                          "avg_launch_ms": round(ms1 / cnt1, 4), "achieved": round(gbs1, 1),
+                          "frac": round(gbs1 / HBM_PEAK_GBS, 4), "launches": cnt1}
+        flop_per_byte = alg_flops["k_fdl_mac"] / alg_bytes["k_fdl_mac"]
         out = {
             "metric": "Mega stereo-samples/s convolved (131072-tap IR, blk=512)",
             "value": round(samples / elapsed / 1e6, 3),
@@ -320,6 +341,11 @@ def main():
                          "sample (~35 fp64 instructions per band-sample) against 16 B of HBM traffic per sample"
                          if dominant.startswith("k_svf") else "HBM stream of FDL and IR spectra"),
                 "fp64_vector": {"achieved_tflops": dk.get("fp64_tflops"), "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+                # k_fdl_mac at T partitions per call does 8 K T flop per 16 (2K + T) bytes: past the fp64 ridge
+                # (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) from T ~ 45 at K = 259, where the FMA rate binds instead of HBM
+                "mac_flop_per_byte": round(flop_per_byte, 2),
+                "ridge_flop_per_byte": round(FP64_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 2),
+                "hbm_regime": hbm_regime,
             },
             "kernels": per_kernel,
             "kernels_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof.items()},
