@@ -49,6 +49,7 @@ struct SpecTail {
     char* mem = nullptr;
     double2 *X = nullptr, *XDN = nullptr, *H = nullptr, *HDN = nullptr, *Y = nullptr, *tw = nullptr, *tw2 = nullptr;
     double *hist[2] = { nullptr, nullptr }, *acc[2] = { nullptr, nullptr }, *z = nullptr, *ring = nullptr, *gainDev = nullptr;
+    double2* scratch = nullptr;   // four-step FFT workspace (P > 4096): [max(nCh * nbMax, K)][P]
 };
 
 struct cpq_engine {
@@ -287,6 +288,7 @@ int allocSpecTails(cpq_engine* e, const cpq_nuc_plan& pl)
             { (void**)&t.z, nCh * t.nbMax * t.P * (int64_t)sizeof(double) },
             { (void**)&t.ring, nCh * t.outRing * (int64_t)sizeof(double) },
             { (void**)&t.gainDev, (t.P + 1) * (int64_t)sizeof(double) },
+            { (void**)&t.scratch, (t.P > 4096 ? std::max<int64_t>(nCh * t.nbMax, t.K) * t.P * (int64_t)sizeof(double2) : 256) },
         };
         int64_t total = 0;
         for (const Item& it : items) total += alignUp(it.bytes, 256);
@@ -356,7 +358,7 @@ int specTailsRun(cpq_engine* e, double* dOut, int n)
             {
                 ProfScope p(e, CPQ_K_RFFT_FWD);
                 cpq::launch_rfft_fwd_ols(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X,
-                                         t.XDN, tw, t.P, e->nCh, nb, t.head, t.ringSlots);
+                                         t.XDN, tw, t.P, e->nCh, nb, t.head, t.ringSlots, t.scratch);
             }
             {
                 ProfScope p(e, CPQ_K_FDL_MAC);
@@ -370,7 +372,7 @@ int specTailsRun(cpq_engine* e, double* dOut, int n)
             }
             {
                 ProfScope p(e, CPQ_K_RFFT_INV);
-                cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, e->nCh, nb);
+                cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, e->nCh, nb, t.scratch);
             }
             ProfScope p(e, CPQ_K_MIX);
             cpq::launch_ring_put(e->stream, t.z, (int64_t)t.nbMax * t.P, nb * t.P, t.ring, t.outRing, t.blocksDone * t.P,
@@ -924,8 +926,8 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         if (sp.num_layers > 1) {
             if (e->layered) return fail(e, CPQ_ERR_UNSUPPORTED, "engine is in time-varying (layered) mode");
             for (int l = 1; l < sp.num_layers; ++l)
-                if (sp.part_size[l] > 4096 || (sp.part_size[l] & (sp.part_size[l] - 1)))
-                    return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec tail layer %d has partition size %d; supported: powers of two up to 4096",
+                if (sp.part_size[l] > 32768 || (sp.part_size[l] & (sp.part_size[l] - 1)))
+                    return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec tail layer %d has partition size %d; supported: powers of two up to 32768",
                                 l, sp.part_size[l]);
             if (e->specTails.empty() || std::memcmp(&sp, &e->specPlan, sizeof(sp)) != 0) {
                 for (int slot = 0; slot < e->nCh; ++slot)
@@ -1064,7 +1066,8 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
                 double2* Ht = t.H + (int64_t)slot * t.hRows * t.P;
                 double2* HDNt = t.HDN + (int64_t)slot * t.hRows;
                 CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-                cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Ht, HDNt, cpq::FftTables{ t.tw, t.tw2 }, t.P, t.K);
+                cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Ht, HDNt, cpq::FftTables{ t.tw, t.tw2 }, t.P, t.K,
+                                       t.scratch);
                 cpq::spectrumFilterGains(*spec, 2 * t.P, g);            // applySpectrumFilter at this layer's FFT size
                 CPQ_HIP(e, hipMemcpyAsync(t.gainDev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
                 cpq::launch_spectrum_gain(e->stream, Ht, HDNt, t.gainDev, t.P, t.K);

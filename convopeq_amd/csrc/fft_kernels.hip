@@ -73,13 +73,15 @@ constexpr int kLdsPerWave = 72 * 8;   // complex elements
 //   pass 1 over a (registers), twiddle W512^((8b+c) p); exchange -> lane (p, c), registers over b
 //   pass 2 over b, twiddle W64^(c q);                   exchange -> lane (p + 8q), registers over c
 //   pass 3 over c.
+// twStride: tw512[m * twStride] = exp(-2 pi i m / 512) (1 for the 512-entry table; P / 512 when the table is the
+// P-entry one of a larger partition)
 template <bool INV>
 __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, const double2* __restrict__ tw512,
-                                             int lane)
+                                             int lane, int twStride = 1)
 {
     dft8<INV>(v);
 #pragma unroll
-    for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], tw512[lane * p]);
+    for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], tw512[lane * p * twStride]);
 #pragma unroll
     for (int p = 0; p < 8; ++p) lds[72 * p + lane] = v[p];
     __syncthreads();
@@ -89,7 +91,7 @@ __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, cons
     __syncthreads();
     dft8<INV>(v);
 #pragma unroll
-    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tw512[8 * cc * q]);
+    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tw512[8 * cc * q * twStride]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) lds[66 * cc + pp + 8 * q] = v[q];
     __syncthreads();
@@ -474,22 +476,262 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
         *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(dyn[n].x * s, dyn[n].y * s);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Partitions above 4096 samples (P = 8192, 16384, 32768: tail layers of a FilterSpec plan run at the reference's own
+// partition size): four-step FFT of the M = P complex points z[n] = x[2n] + i x[2n+1], M = M1 * 512, n = n1 * 512 + n2:
+//   column pass: for every column n2 the M1-point FFT over n1, times W_M^(n2 k1)          -> scratch A[k1][n2]
+//   row pass   : for every row k1 the 512-point FFT over n2 (the wave-level kernel above) -> Z[k1 + M1 k2]
+// The spectrum stays in that PERMUTED order, element k1 * 512 + k2 <-> bin k1 + M1 k2: the MAC is element-wise and
+// the forward, IR and inverse transforms agree on it; element 0 is still the packed (DC, Nyquist).  The real-FFT split
+// pairs (k1, k2) with (M1 - k1, 511 - k2) for k1 > 0 and with (0, (512 - k2) mod 512) for k1 = 0, so one workgroup of
+// two waves transforms the row pair (k1, M1 - k1).  tools/fft_fourstep_proto.py is the numpy model of this scheme.
+// tw.tw512 = exp(-2 pi i m / P) and tw.tw1024 = exp(-2 pi i k / 2P), P entries each.
+
+constexpr int kBigCols = 64;            // columns per workgroup in the column pass (one wave-width: coalesced rows)
+
+// Stockham stages over the element axis of a [element][column] LDS tile; thread = (column, j), j < M1 / 8
+template <bool INV>
+__device__ __forceinline__ void col_stage8(double2* lds, int M1, int ns, const double2* __restrict__ twP, int j, int col)
+{
+    const int stride = M1 >> 3;
+    const int k = j & (ns - 1);
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = lds[(j + q * stride) * kBigCols + col];
+    const int tstep = (M1 / (8 * ns)) * 512;             // exp(-2 pi i m / M1) = twP[m * 512]
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], twP[q * k * tstep]);
+    dft8<INV>(v);
+    __syncthreads();
+    const int o = ((j - k) << 3) + k;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds[(o + q * ns) * kBigCols + col] = v[q];
+    __syncthreads();
+}
+
+template <bool INV, int R>
+__device__ __forceinline__ void col_stage_small(double2* lds, int M1, int ns, const double2* __restrict__ twP, int j, int col)
+{
+    constexpr int NB = 8 / R;
+    const int nthr = M1 >> 3;
+    const int stride = M1 / R;
+    const int tstep = (M1 / (R * ns)) * 512;
+    double2 v[NB][R];
+    int outBase[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int jj = j + b * nthr;
+        const int k = jj & (ns - 1);
+        outBase[b] = (jj - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            v[b][q] = lds[(jj + q * stride) * kBigCols + col];
+            if (q > 0) v[b][q] = cmulw<INV>(v[b][q], twP[q * k * tstep]);
+        }
+        if (R == 4) dft4<INV>(v[b][0], v[b][1], v[b][2], v[b][3]);
+        else { const double2 a = v[b][0], c = v[b][1]; v[b][0] = cadd(a, c); v[b][1] = csub(a, c); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds[(outBase[b] + q * ns) * kBigCols + col] = v[b][q];
+    __syncthreads();
+}
+
+// M1-point FFT of the thread's column: the first radix-8 stage takes its inputs from registers (v[q] = element
+// j + q M1/8), the result ends in LDS in natural order
+template <bool INV>
+__device__ __forceinline__ void col_fft(double2 (&v)[8], double2* lds, int M1, const double2* __restrict__ twP, int j, int col)
+{
+    dft8<INV>(v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds[(8 * j + q) * kBigCols + col] = v[q];
+    __syncthreads();
+    if (M1 == 64) col_stage8<INV>(lds, M1, 8, twP, j, col);
+    else if (M1 == 32) col_stage_small<INV, 4>(lds, M1, 8, twP, j, col);
+    else col_stage_small<INV, 2>(lds, M1, 8, twP, j, col);
+}
+
+// column pass, forward.  FRAME = true: overlap-save frame [previous P | current P] of (channel c, block t);
+// FRAME = false: zero-padded IR partition blockIdx / 8 of heff.  grid = transforms * 8 column tiles, 8 M1 threads.
+template <bool FRAME>
+__global__ __launch_bounds__(512) void k_big_cols_fwd(const double* __restrict__ in, int64_t chStride,
+                                                      const double* __restrict__ histOld, double* __restrict__ histNew,
+                                                      int heffLen, double2* __restrict__ A, FftTables tw, int P, int T)
+{
+    extern __shared__ double2 dyn[];
+    const int M1 = P >> 9;
+    const int tr = blockIdx.x >> 3, tile = blockIdx.x & 7;
+    const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int n2 = tile * kBigCols + col;
+    const int halfM = P >> 1;
+    const int stride = M1 >> 3;
+    double2 v[8];
+    if (FRAME) {
+        const int c = tr / T, t = tr - c * T;
+        const double* cur = in + (int64_t)c * chStride + (int64_t)t * P;
+        const double* prev = (t > 0) ? (cur - P) : (histOld + (int64_t)c * P);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = (j + q * stride) * 512 + n2;
+            const double* src = (n < halfM) ? (prev + 2 * n) : (cur + 2 * (n - halfM));
+            v[q] = *reinterpret_cast<const double2*>(src);
+            if (t == T - 1 && n >= halfM)      // overlap history for the next call (prevInputBuf, NUC.cpp:1258)
+                *reinterpret_cast<double2*>(histNew + (int64_t)c * P + 2 * (n - halfM)) = v[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = (j + q * stride) * 512 + n2;
+            double2 x = make_double2(0.0, 0.0);
+            if (n < halfM) {
+                const int64_t i = (int64_t)tr * P + 2 * n;
+                x = make_double2(i < heffLen ? in[i] : 0.0, (i + 1) < heffLen ? in[i + 1] : 0.0);
+            }
+            v[q] = x;
+        }
+    }
+    col_fft<false>(v, dyn, M1, tw.tw512, j, col);
+    double2* a = A + (int64_t)tr * P;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k1 = j + q * stride;
+        a[k1 * 512 + n2] = cmulw<false>(dyn[k1 * kBigCols + col], tw.tw512[n2 * k1]);       // W_M^(n2 k1)
+    }
+}
+
+// row pass + real-FFT split, forward: workgroup = rows (k1, M1 - k1) of one transform, one wave each
+__global__ __launch_bounds__(128) void k_big_rows_fwd(const double2* __restrict__ A, double2* __restrict__ X,
+                                                      double2* __restrict__ XDN, FftTables tw, int P, int T, int head,
+                                                      int ringMask, int ringRows)
+{
+    __shared__ double2 lds[2][kLdsPerWave];
+    __shared__ double2 rows[2][512];
+    const int M1 = P >> 9;
+    const int nPairs = (M1 >> 1) + 1;
+    const int tr = blockIdx.x / nPairs, k1 = blockIdx.x - tr * nPairs;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int krow = (w == 0) ? k1 : ((M1 - k1) & (M1 - 1));
+    const double2* a = A + (int64_t)tr * P + krow * 512;
+    double2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = a[lane + 64 * r];
+    wave_cfft512<false>(v, lds[w], tw.tw512, lane, M1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rows[w][lane + 64 * r] = v[r];
+    __syncthreads();
+    // ringRows > 0: FDL ring of (channel, block); ringRows == 0: IR partition rows (tr = partition)
+    int64_t row = tr;
+    if (ringRows > 0) {
+        const int c = tr / T, t = tr - c * T;
+        row = (int64_t)c * ringRows + ((head + t) & ringMask);
+    }
+    double2* x = X + row * P + krow * 512;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k2 = lane + 64 * r;
+        const double2 zk = v[r];
+        const double2 zm = rows[w ^ 1][krow == 0 ? ((512 - k2) & 511) : (511 - k2)];
+        const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+        const double2 o = make_double2(d.y, -d.x);
+        const double2 wk = tw.tw1024[krow + M1 * k2];
+        double2 xk = make_double2(e.x + fma(o.x, wk.x, -(o.y * wk.y)), e.y + fma(o.x, wk.y, o.y * wk.x));
+        if (krow == 0 && k2 == 0) {
+            xk = make_double2(zk.x + zk.y, zk.x - zk.y);   // (DC, Nyquist)
+            XDN[row] = xk;
+        }
+        x[k2] = xk;
+    }
+}
+
+// inverse: undo the split, inverse 512-point FFT over k2, conj twiddle -> scratch A'[k1][n2]
+__global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict__ Y, double2* __restrict__ A, FftTables tw,
+                                                      int P)
+{
+    __shared__ double2 lds[2][kLdsPerWave];
+    const int M1 = P >> 9;
+    const int nPairs = (M1 >> 1) + 1;
+    const int tr = blockIdx.x / nPairs, k1 = blockIdx.x - tr * nPairs;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int krow = (w == 0) ? k1 : ((M1 - k1) & (M1 - 1));
+    const int prow = (M1 - krow) & (M1 - 1);
+    const double2* y = Y + (int64_t)tr * P + krow * 512;
+    const double2* ym = Y + (int64_t)tr * P + prow * 512;
+    const double2 y0 = Y[(int64_t)tr * P];
+    double2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k2 = lane + 64 * r;
+        const double2 yk = y[k2];
+        const double2 yp = ym[krow == 0 ? ((512 - k2) & 511) : (511 - k2)];
+        const double2 e = make_double2(0.5 * (yk.x + yp.x), 0.5 * (yk.y - yp.y));
+        const double2 d = make_double2(0.5 * (yk.x - yp.x), 0.5 * (yk.y + yp.y));
+        const double2 wk = tw.tw1024[krow + M1 * k2];
+        const double2 o = make_double2(fma(d.x, wk.x, d.y * wk.y), fma(d.y, wk.x, -(d.x * wk.y)));   // d * conj(w)
+        double2 z = make_double2(e.x - o.y, e.y + o.x);
+        if (krow == 0 && k2 == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
+        v[r] = z;
+    }
+    wave_cfft512<true>(v, lds[w], tw.tw512, lane, M1);
+    double2* a = A + (int64_t)tr * P + krow * 512;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n2 = lane + 64 * r;
+        a[n2] = cmulw<true>(v[r], tw.tw512[n2 * krow]);
+    }
+}
+
+// inverse column pass: M1-point inverse FFT over k1 per column, second half of the frame (n1 >= M1 / 2) to out, 1/M
+__global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict__ A, double* __restrict__ out,
+                                                      int64_t chStride, FftTables tw, int P, int T)
+{
+    extern __shared__ double2 dyn[];
+    const int M1 = P >> 9;
+    const int tr = blockIdx.x >> 3, tile = blockIdx.x & 7;
+    const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int n2 = tile * kBigCols + col;
+    const int stride = M1 >> 3;
+    const double2* a = A + (int64_t)tr * P;
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = a[(j + q * stride) * 512 + n2];
+    col_fft<true>(v, dyn, M1, tw.tw512, j, col);
+    const int c = tr / T, t = tr - c * T;
+    double* o = out + (int64_t)c * chStride + (int64_t)t * P;
+    const double s = 1.0 / (double)P;
+    const int halfM = P >> 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int n1 = j + q * stride;
+        if (n1 >= (M1 >> 1)) {
+            const double2 z = dyn[n1 * kBigCols + col];
+            const int n = n1 * 512 + n2;
+            *reinterpret_cast<double2*>(o + 2 * (n - halfM)) = make_double2(z.x * s, z.y * s);
+        }
+    }
+}
+
 // H[k][bin] *= gain[bin] for the IR partition spectra of one IR slot (the HC/LC spectral shaping of a non-NULL
 // FilterSpec, src/MKLNonUniformConvolver.cpp:433-441); packed bin 0 = (DC * gain[0], Nyquist * gain[P])
+// Above P = 4096 the spectra are stored permuted (element k1 * 512 + k2 holds bin k1 + (P / 512) k2, see k_big_*).
 __global__ __launch_bounds__(256) void k_spectrum_gain(double2* __restrict__ H, double2* __restrict__ HDN,
                                                        const double* __restrict__ gain, int P)
 {
     const int k = blockIdx.x;
     double2* row = H + (int64_t)k * P;
-    for (int b = threadIdx.x; b < P; b += blockDim.x) {
-        double2 v = row[b];
-        if (b == 0) {
+    const int M1 = (P > 4096) ? (P >> 9) : 0;
+    for (int e = threadIdx.x; e < P; e += blockDim.x) {
+        const int b = M1 ? ((e >> 9) + M1 * (e & 511)) : e;      // bin of element e
+        double2 v = row[e];
+        if (e == 0) {
             v = make_double2(v.x * gain[0], v.y * gain[P]);
             HDN[k] = v;
         } else {
             v = make_double2(v.x * gain[b], v.y * gain[b]);
         }
-        row[b] = v;
+        row[e] = v;
     }
 }
 
@@ -505,8 +747,16 @@ static int genericThreads(int P) { return P / 2 < 64 ? 64 : (P / 2 > 256 ? 256 :
 
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
                          double* histNew, double2* X, double2* XDN, FftTables tw, int P, int nCh, int T, int head,
-                         int ringSlots)
+                         int ringSlots, double2* scratch)
 {
+    if (P > 4096) {         // four-step: column pass into scratch [nCh * T][P], then row pass + split into the FDL ring
+        const int M1 = P >> 9;
+        hipLaunchKernelGGL(k_big_cols_fwd<true>, dim3(nCh * T * 8), dim3(8 * M1), (size_t)M1 * kBigCols * sizeof(double2),
+                           stream, in, chStride, histOld, histNew, 0, scratch, tw, P, T);
+        hipLaunchKernelGGL(k_big_rows_fwd, dim3(nCh * T * ((M1 >> 1) + 1)), dim3(128), 0, stream, scratch, X, XDN, tw, P,
+                           T, head, ringSlots - 1, ringSlots);
+        return;
+    }
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
                            tw, T, head, ringSlots - 1);
@@ -520,8 +770,16 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
 }
 
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN, FftTables tw,
-                       int P, int nParts)
+                       int P, int nParts, double2* scratch)
 {
+    if (P > 4096) {         // scratch [nParts][P]
+        const int M1 = P >> 9;
+        hipLaunchKernelGGL(k_big_cols_fwd<false>, dim3(nParts * 8), dim3(8 * M1), (size_t)M1 * kBigCols * sizeof(double2),
+                           stream, heff, 0, nullptr, nullptr, heffLen, scratch, tw, P, 1);
+        hipLaunchKernelGGL(k_big_rows_fwd, dim3(nParts * ((M1 >> 1) + 1)), dim3(128), 0, stream, scratch, H, HDN, tw, P, 1, 0,
+                           0, 0);
+        return;
+    }
     if (P == kP)
         hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
     else if (P >= 1024) {
@@ -539,8 +797,15 @@ void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const do
 }
 
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P,
-                         int nCh, int T)
+                         int nCh, int T, double2* scratch)
 {
+    if (P > 4096) {         // scratch [nCh * T][P]
+        const int M1 = P >> 9;
+        hipLaunchKernelGGL(k_big_rows_inv, dim3(nCh * T * ((M1 >> 1) + 1)), dim3(128), 0, stream, Y, scratch, tw, P);
+        hipLaunchKernelGGL(k_big_cols_inv, dim3(nCh * T * 8), dim3(8 * M1), (size_t)M1 * kBigCols * sizeof(double2), stream,
+                           scratch, out, chStride, tw, P, T);
+        return;
+    }
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
     else if (P >= 1024) {

@@ -24,11 +24,11 @@ struct FftTables {
 // line (FDL) ring; also saves the last block as the next call's overlap history.
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
                          double* histNew, double2* X, double2* XDN, FftTables tw, int P, int nCh, int T,
-                         int head, int ringSlots);
+                         int head, int ringSlots, double2* scratch = nullptr);
 
 // IR partition spectra: frames [h[k*P .. (k+1)*P) | 0] for k < nParts.
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN,
-                       FftTables tw, int P, int nParts);
+                       FftTables tw, int P, int nParts, double2* scratch = nullptr);
 
 // H[k][bin] *= gain[bin] (gain has P+1 entries: bins 0..P) for nParts partition spectra
 void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const double* gain, int P, int nParts);
@@ -43,8 +43,10 @@ void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2*
                           double2* Y, int P, int nCh, int K, int ringSlots, int head, int T, int hdnStride);
 
 // inverse 1024-point real FFT of Y, scaled 1/N, second half (P samples) to out.
+// P > 4096 (8192 / 16384 / 32768): four-step transforms through `scratch` ([transforms][P] double2); the spectra are
+// then stored permuted (element k1 * 512 + k2 = bin k1 + (P / 512) k2), consistently in all three launchers.
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw,
-                         int P, int nCh, int T);
+                         int P, int nCh, int T, double2* scratch = nullptr);
 
 // 20-band TPT-SVF cascade, lane = (channel, band), bands skewed in time across lanes.  streamPairs: one wave per
 // stream (its L and R channel) instead of 3 channels per wave -- required when a band has flag bits 4/5

@@ -182,9 +182,10 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
  * the air-absorption damping (:1060-1097) are applied to every partition spectrum at that LAYER's FFT size, exactly
  * as the reference does.  Layer 0 runs in the main path; every tail layer of the plan runs on the reference's own
  * partition grid (block_size * multiplier, ...) and reaches the output through the delay-line lag done_callback * B.
- * Limits (CPQ_ERR_UNSUPPORTED): tail partitions above 4096 samples (e.g. layer 2 at block 512), plans that are
- * time-varying in the reference (cpq_nuc_plan.lti_valid == 0), FilterSpec IRs with different layer plans in one
- * engine, partition_size != block_size.
+ * Tail partitions up to 32768 samples are supported (above 4096 through a four-step FFT); plans that are time-varying
+ * in the reference (cpq_nuc_plan.lti_valid == 0) follow the replayed delay-line reader.
+ * Limits (CPQ_ERR_UNSUPPORTED): tail partitions that are not a power of two or exceed 32768, FilterSpec IRs with
+ * different layer plans in one engine, partition_size != block_size, FilterSpec together with the direct head.
  * enable_direct_head: accepted; the <= 32 head taps stay in the FFT path (same h_eff, rounding-level difference). */
 int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* ir_l, const double* ir_r,
                              int32_t ir_len, double scale, int32_t enable_direct_head,

@@ -297,11 +297,11 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     with pytest.raises(amd.CpqError):
         eng.set_eq_params(0, p)
     eng.close()
-    long_ir = O.gen_ir(524288)
-    # FilterSpec whose third layer has a 32768-sample partition: beyond the 4096-point workgroup FFT
-    eng = amd.BatchedEngine(1, max_ir_len=524288, max_blocks_per_call=2)
+    long_ir = O.gen_ir(131072)
+    # FilterSpec whose tail partition is not a power of two (air-absorption mode with multiplier 6: 3072 samples)
+    eng = amd.BatchedEngine(1, max_ir_len=131072, max_blocks_per_call=2)
     with pytest.raises(amd.CpqError) as e4:
-        eng.set_impulse(0, long_ir, long_ir, spec=amd.FilterSpec.defaults())
+        eng.set_impulse(0, long_ir, long_ir, spec=amd.FilterSpec.defaults(tail_mode=0, tail_l1l2_multiplier=6))
     assert e4.value.status == -5
     eng.close()
     with pytest.raises(amd.CpqError):
@@ -681,7 +681,12 @@ def test_eq_mid_side_channel_modes(amd, oracle, sat, structure):
                                                # the delay-line reader skips blocks; replayed by k_tail_schedule
                                                (dict(tail_mode=0), 131072, 512, 8),
                                                (dict(tail_mode=0, tail_strength=0.7, hc_mode=1), 131072, 512, 3),
-                                               (dict(tail_mode=0, tail_start_seconds=0.03), 60000, 512, 5)])
+                                               (dict(tail_mode=0, tail_start_seconds=0.03), 60000, 512, 5),
+                                               # tail partitions above 4096: four-step FFT, permuted spectra
+                                               (dict(), 524288, 512, 8),                    # 512 / 4096 / 32768
+                                               (dict(hc_mode=0), 131072, 1024, 3),          # 1024 / 8192, time-varying
+                                               (dict(tail_mode=0, lc_mode=1), 200000, 2048, 2),     # 2048 / 16384
+                                               (dict(), 300000, 256, 32)])                  # 256 / 2048 / 16384
 def test_filter_spec_with_tail_layers(amd, oracle, kw, ir_len, block, T):
     """non-NULL FilterSpec on a multi-layer plan.  The HC/LC gains (and, in tail mode 0, the air-absorption
     damping) multiply every partition spectrum at that LAYER's FFT size (NUC.cpp:336-443, :1060-1097), so each tail
