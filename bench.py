@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--eq-only", action="store_true", help="diagnostic: time the EQ kernel alone")
     ap.add_argument("--saturation", type=float, default=0.2)
     ap.add_argument("--shared-ir", action="store_true")
+    ap.add_argument("--schedule", choices=["uniform", "nuc"], default="uniform",
+                    help="uniform: one partition size for the whole h_eff (headline, HBM-roofline path); nuc: the reference's "
+                         "own non-uniform schedule run natively (BASELINE.json configs[3])")
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="diagnostic: host-pointer entry point (PCIe-inclusive rate)")
@@ -180,7 +183,8 @@ def main():
     use_eq = not args.no_eq
     eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T,
                             semantics=amd.CPQ_SEM_EXACT if args.exact else amd.CPQ_SEM_REFERENCE,
-                            device=dev_index, mac_tile=args.mac_tile, partition_size=args.partition)
+                            device=dev_index, mac_tile=args.mac_tile, partition_size=args.partition,
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if args.schedule == "nuc" else amd.CPQ_SCHED_UNIFORM)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
 
@@ -244,7 +248,7 @@ def main():
     # streamed for a single output row, so the kernel is HBM-bound there, whereas at T blocks per call it is past the
     # fp64 ridge.  Measured after the timed region (not part of `value`) to give the roofline object both regimes.
     prof1 = None
-    if not (args.eq_only or args.host_buffers) and rank == 0:
+    if not (args.eq_only or args.host_buffers or args.schedule == "nuc") and rank == 0:
         P1 = args.partition if args.partition else B
         eng.profile_reset()
         for _ in range(40):
@@ -267,26 +271,36 @@ def main():
         # algorithmic HBM bytes per launch: every row / sample a kernel needs is moved once
         spec_bytes = P * 16
         ir_rows = (2 if args.shared_ir else n_ch) * k_parts
-        alg_bytes = {
-            "k_rfft_fwd_ols": n_ch * Tp * (P * 8 + spec_bytes),
-            "k_fdl_mac": (n_ch * (k_parts + Tp - 1) + ir_rows + n_ch * Tp) * spec_bytes,
-            "k_fdl_mac_dcnyq": n_ch * (k_parts + Tp - 1 + Tp) * 16 + ir_rows * 16,
-            "k_rfft_inv_ols": n_ch * Tp * (spec_bytes + P * 8),
+        # layers the convolver actually runs: (partition size, partitions, partitions per step)
+        if args.schedule == "nuc":
+            layers = [(plan.part_size[l], plan.num_parts_ir[l], n / plan.part_size[l]) for l in range(plan.num_layers)]
+        else:
+            layers = [(P, k_parts, Tp)]
+        ir_mult = 2 if args.shared_ir else n_ch
+        alg_bytes = {      # per STEP; one launch per step and kernel under the uniform schedule
+            "k_rfft_fwd_ols": sum(n_ch * nb * (pl * 8 + pl * 16) for pl, _, nb in layers),
+            "k_fdl_mac": sum((n_ch * (kl + nb - 1) + ir_mult * kl + n_ch * nb) * pl * 16 for pl, kl, nb in layers),
+            "k_fdl_mac_dcnyq": sum(n_ch * (kl + nb - 1 + nb) * 16 + ir_mult * kl * 16 for pl, kl, nb in layers),
+            "k_rfft_inv_ols": sum(n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb in layers),
             "k_svf_cascade_tp": n_ch * n * 16,
             "k_svf_cascade": n_ch * n * 16,
+            "k_convproc_mix": n_ch * n * 16 * max(0, len(layers) - 1),      # delay-line write / read-add of the tail layers
         }
-        # fp64 operations per launch (FMA = 2): MAC 8 per complex MAC; SVF ~35 fp64 instructions per band-sample
-        alg_flops = {"k_fdl_mac": 8.0 * n_ch * Tp * k_parts * P, "k_svf_cascade_tp": 2.0 * 35 * 20 * n_ch * n}
+        # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF ~35 fp64 instructions per band-sample
+        alg_flops = {"k_fdl_mac": sum(8.0 * n_ch * nb * kl * pl for pl, kl, nb in layers),
+                     "k_svf_cascade_tp": 2.0 * 35 * 20 * n_ch * n}
         per_kernel = {}
         for name, (cnt, ms) in prof.items():
             if cnt == 0:
                 continue
             avg_s = ms / cnt * 1e-3
+            step_s = ms / args.steps * 1e-3
+            per_launch = int(alg_bytes[name] * args.steps / cnt)
             per_kernel[name] = {"launches": cnt, "avg_launch_ms": round(avg_s * 1e3, 4),
-                                "algorithmic_bytes_per_launch": alg_bytes[name],
-                                "achieved_gbs": round(alg_bytes[name] / avg_s / 1e9, 1)}
+                                "algorithmic_bytes_per_launch": per_launch,
+                                "achieved_gbs": round(alg_bytes[name] / step_s / 1e9, 1)}
             if name in alg_flops:
-                per_kernel[name]["fp64_tflops"] = round(alg_flops[name] / avg_s / 1e12, 2)
+                per_kernel[name]["fp64_tflops"] = round(alg_flops[name] / step_s / 1e12, 2)
         tot = {k: v["avg_launch_ms"] * v["launches"] for k, v in per_kernel.items()}
         dominant = max(tot, key=tot.get)
         co_dominant = sorted(k for k in tot if tot[k] >= 0.9 * tot[dominant])
@@ -323,9 +337,11 @@ def main():
                             f"fp64 overlap-save conv{' + 20-band SVF EQ (sat %.1f)' % args.saturation if use_eq else ''}"
                             f" [BASELINE.json configs[1]{'' if (S == 256 and L == 131072) else ' (modified)'}]",
                 "streams_per_gpu": S, "ir_taps": L, "block": B, "blocks_per_call": T,
-                "schedule": f"uniform overlap-save, FFT partition P={P}, K={k_parts} partitions of "
-                            f"{'h' if args.exact else 'h_eff (reference NUC semantics at blk 512)'}, "
-                            f"{T} blocks ({n} samples) per call = {Tp} partitions per FDL pass",
+                "schedule": (f"uniform overlap-save, FFT partition P={P}, K={k_parts} partitions of "
+                             f"{'h' if args.exact else 'h_eff (reference NUC semantics at blk 512)'}, "
+                             f"{T} blocks ({n} samples) per call = {Tp} partitions per FDL pass") if args.schedule == "uniform"
+                            else ("non-uniform (the reference's own layer plan run natively): " +
+                                  " + ".join(f"{kl} x {pl}" for pl, kl, _ in layers) + f" partitions, {T} blocks per call"),
                 "partition": P,
                 "eq": use_eq, "parallelism": f"streams sharded, {world} rank(s)",
                 "gb_per_s_of_samples": round(samples / elapsed * 16 / 1e9, 3),

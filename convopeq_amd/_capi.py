@@ -19,6 +19,8 @@ CPQ_ERR_NOT_READY = -6
 CPQ_ALL_STREAMS = -1
 CPQ_SEM_REFERENCE = 0
 CPQ_SEM_EXACT = 1
+CPQ_SCHED_UNIFORM = 0
+CPQ_SCHED_REFERENCE_NUC = 1
 CPQ_ORDER_CONV_THEN_EQ = 0
 CPQ_ORDER_EQ_THEN_CONV = 1
 KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4,
@@ -79,7 +81,7 @@ class EngineDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_streams", C.c_int32),
                 ("block_size", C.c_int32), ("max_ir_len", C.c_int32), ("max_blocks_per_call", C.c_int32),
                 ("semantics", C.c_int32), ("mac_tile", C.c_int32), ("sample_rate", C.c_double),
-                ("partition_size", C.c_int32), ("reserved", C.c_int32)]
+                ("partition_size", C.c_int32), ("schedule", C.c_int32)]
 
 
 # every symbol include/convopeq_mi355x.h declares: (restype, argtypes)

@@ -264,8 +264,8 @@ int allocSpecTails(cpq_engine* e, const cpq_nuc_plan& pl)
         SpecTail t;
         t.P = pl.part_size[l];
         t.K = pl.num_parts_ir[l];
-        t.kPad = (int)alignUp(t.K, cpq::kMacMaxTile);
-        t.hRows = t.kPad + 4 * cpq::kMacMaxTile;
+        t.kPad = (int)alignUp(t.K, e->macTile == 32 ? 32 : 16);      // a multiple of every tile the MAC launcher may pick
+        t.hRows = t.kPad + 16;                                      // zero rows for the kernels' 4-row read-ahead
         t.nbMax = (t.P - 1 + nMax) / t.P;
         t.ringSlots = nextPow2(t.kPad + cpq::kMacMaxTile + t.nbMax);
         t.accCap = t.P + nMax;
@@ -716,6 +716,11 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "bad semantics");
     if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16 && d->mac_tile != 32)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "mac_tile must be 0, 4, 8, 16 or 32");
+    if (d->schedule != CPQ_SCHED_UNIFORM && d->schedule != CPQ_SCHED_REFERENCE_NUC)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "schedule must be CPQ_SCHED_UNIFORM or CPQ_SCHED_REFERENCE_NUC");
+    if (d->schedule == CPQ_SCHED_REFERENCE_NUC &&
+        (d->semantics != CPQ_SEM_REFERENCE || (d->partition_size != 0 && d->partition_size != d->block_size)))
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "the non-uniform schedule needs reference semantics and partition_size == block_size");
 
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
@@ -912,16 +917,18 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     // (:336-443), which this engine reproduces exactly only for a single-layer plan at P == block size.
     // With tail layers every layer keeps the reference's own partition size: layer 0 in the main path, each tail layer in
     // a SpecTail (partition sizes up to 4096, LTI-valid plans; all such IRs of an engine share one plan).
+    // CPQ_SCHED_REFERENCE_NUC runs every IR that way (spec or not): the reference's own partition schedule.
     std::vector<double> gains;
     cpq_nuc_plan sp{};
     bool specTails = false;
+    const bool nativeNuc = e->desc.schedule == CPQ_SCHED_REFERENCE_NUC;
     const int slotFirst = (stream == CPQ_ALL_STREAMS) ? 0 : 2 * stream;
-    if (spec) {
+    if (spec || nativeNuc) {
         if (cpq::computeNucPlan(irLen, e->desc.block_size, direct != 0, spec, &sp) != CPQ_OK)
             return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
         if (e->P != sp.part_size[0])
             return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec needs partition_size == the reference layer-0 partition (%d)", sp.part_size[0]);
-        if (direct) return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec together with the direct head is not implemented");
+        if (direct && spec) return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec together with the direct head is not implemented");
         if (e->desc.semantics != CPQ_SEM_REFERENCE) return fail(e, CPQ_ERR_INVALID_ARG, "FilterSpec requires reference semantics");
         if (sp.num_layers > 1) {
             if (e->layered) return fail(e, CPQ_ERR_UNSUPPORTED, "engine is in time-varying (layered) mode");
@@ -940,7 +947,7 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             }
             specTails = true;
         }
-        cpq::spectrumFilterGains(*spec, 2 * e->P, gains);
+        if (spec) cpq::spectrumFilterGains(*spec, 2 * e->P, gains);
     }
 
     CPQ_HIP(e, hipSetDevice(e->device));
@@ -951,7 +958,7 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     // does the reference stay LTI for this IR length / block size?  If not (tail partition longer than the IR that
     // precedes it), switch the engine to layered mode: one convolution per layer + replay of the delay-line reader.
     bool wantLayered = false;
-    if (e->desc.semantics == CPQ_SEM_REFERENCE && !spec) {
+    if (e->desc.semantics == CPQ_SEM_REFERENCE && !spec && !nativeNuc) {
         cpq_nuc_plan probe;
         if (cpq::computeNucPlan(irLen, e->desc.block_size, false, nullptr, &probe) != CPQ_OK)
             return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
@@ -1068,11 +1075,13 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
                 CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
                 cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Ht, HDNt, cpq::FftTables{ t.tw, t.tw2 }, t.P, t.K,
                                        t.scratch);
-                cpq::spectrumFilterGains(*spec, 2 * t.P, g);            // applySpectrumFilter at this layer's FFT size
-                CPQ_HIP(e, hipMemcpyAsync(t.gainDev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-                cpq::launch_spectrum_gain(e->stream, Ht, HDNt, t.gainDev, t.P, t.K);
+                if (spec) {
+                    cpq::spectrumFilterGains(*spec, 2 * t.P, g);        // applySpectrumFilter at this layer's FFT size
+                    CPQ_HIP(e, hipMemcpyAsync(t.gainDev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                    cpq::launch_spectrum_gain(e->stream, Ht, HDNt, t.gainDev, t.P, t.K);
+                }
                 CPQ_HIP(e, hipStreamSynchronize(e->stream));
-                if (cpq::airAbsorptionGains(*spec, l, t.P + 1, g)) {     // tail mode 0 (:1060-1097)
+                if (spec && cpq::airAbsorptionGains(*spec, l, t.P + 1, g)) {     // tail mode 0 (:1060-1097)
                     CPQ_HIP(e, hipMemcpyAsync(t.gainDev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
                     cpq::launch_spectrum_gain(e->stream, Ht, HDNt, t.gainDev, t.P, t.K);
                     CPQ_HIP(e, hipStreamSynchronize(e->stream));

@@ -55,6 +55,18 @@ typedef enum {
 
 typedef enum { CPQ_ORDER_CONV_THEN_EQ = 0, CPQ_ORDER_EQ_THEN_CONV = 1 } cpq_order;
 
+/* how the IR is partitioned on the GPU (reference semantics only) */
+typedef enum {
+    /* one partition size for the whole h_eff (block_size or partition_size): every FDL / IR row is streamed by one
+     * MAC kernel -- the HBM-roofline path of BASELINE.json configs[1] */
+    CPQ_SCHED_UNIFORM = 0,
+    /* the reference's own non-uniform (Gardner) schedule: layer 0 at block_size, tail layers at block_size * m and
+     * block_size * m^2 (src/MKLNonUniformConvolver.cpp:738-758), each on its own FFT grid, outputs merged through
+     * the replayed delay-line reader.  ~K0 + K1/m + K2/m^2 partition MACs per block instead of irLen / block_size
+     * (BASELINE.json configs[3]).  Every IR of the engine must have the same layer plan. */
+    CPQ_SCHED_REFERENCE_NUC = 1
+} cpq_schedule;
+
 /* POD mirror of convo::FilterSpec, src/MKLNonUniformConvolver.h:123-133 */
 typedef struct {
     double  sample_rate;
@@ -129,7 +141,7 @@ typedef struct {
                                         granularity for fewer partitions: every call must then carry a multiple
                                         of P samples (offline / batched use).  The reference itself runs its tail
                                         layers at 8x and 64x the block size (src/MKLNonUniformConvolver.cpp:738-740). */
-    int32_t reserved;
+    int32_t schedule;                /* cpq_schedule (was reserved: 0 = uniform) */
 } cpq_engine_desc;
 
 typedef struct cpq_engine cpq_engine;

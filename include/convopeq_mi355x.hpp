@@ -34,7 +34,8 @@ struct AudioBlockBatch {
 class Engine {
 public:
     Engine(int streams, int blockSize, int maxIrLen, int maxBlocksPerCall, double sampleRate = 48000.0,
-           cpq_semantics semantics = CPQ_SEM_REFERENCE, int device = 0, int partitionSize = 0)
+           cpq_semantics semantics = CPQ_SEM_REFERENCE, int device = 0, int partitionSize = 0,
+           cpq_schedule schedule = CPQ_SCHED_UNIFORM)
     {
         cpq_engine_desc d{};
         d.struct_size = static_cast<int32_t>(sizeof(d));
@@ -47,6 +48,7 @@ public:
         d.mac_tile = 0;
         d.sample_rate = sampleRate;
         d.partition_size = partitionSize;
+        d.schedule = schedule;
         cpq_engine* raw = nullptr;
         const int rc = cpq_engine_create(&d, &raw);
         if (rc != CPQ_OK) throw std::runtime_error(std::string("cpq_engine_create: ") + cpq_last_error(nullptr));

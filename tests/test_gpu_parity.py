@@ -751,3 +751,30 @@ def test_filter_spec_tails_shared_ir_in_place_whole_path(amd, oracle):
         el, er, _ = O.eq_process_stereo(w[0], w[1], po)
         assert rms(y[2 * s] - el) <= 1e-13 and rms(y[2 * s + 1] - er) <= 1e-13, (s, rms(y[2 * s] - el))
     eng.close()
+
+
+@pytest.mark.parametrize("ir_len,block,T,S", [(131072, 512, 8, 2), (131072, 512, 64, 2), (524288, 512, 16, 1),
+                                              (131072, 1024, 4, 1), (20000, 128, 12, 2), (3000, 512, 4, 1)])
+def test_native_non_uniform_schedule(amd, oracle, ir_len, block, T, S):
+    """CPQ_SCHED_REFERENCE_NUC (BASELINE.json configs[3]): the reference's own non-uniform partition schedule run
+    natively -- layer 0 at the block size, tail layers at 8x / 64x on their own FFT grids, merged through the replayed
+    delay-line reader -- against the stateful NUC emulation (filterSpec = nullptr), LTI and time-varying plans, and
+    against the uniform-schedule engine (same reference semantics, different partitioning) where that one applies."""
+    O = oracle
+    irs = [O.gen_ir(ir_len, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    n_calls = max(3, (ir_len + 30000) // (T * block))
+    x = make_inputs(O, S, n_calls * T * block)
+    ref = np.empty_like(x)
+    for c in range(2 * S):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], block)
+        ref[c] = nuc.run(x[c], block)
+    eng = amd.BatchedEngine(S, block_size=block, max_ir_len=ir_len, max_blocks_per_call=T,
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    y = np.concatenate([eng.conv_process(x[:, o:o + T * block]) for o in range(0, x.shape[1], T * block)], axis=1)
+    err = rms(y - ref)
+    print("native nuc", ir_len, block, T, "layers", eng.plan().num_layers, "rms err", err, "signal", rms(ref))
+    assert err <= 1e-13 and rms(ref) > 1e-3
+    eng.close()
