@@ -778,3 +778,46 @@ def test_native_non_uniform_schedule(amd, oracle, ir_len, block, T, S):
     print("native nuc", ir_len, block, T, "layers", eng.plan().num_layers, "rms err", err, "signal", rms(ref))
     assert err <= 1e-13 and rms(ref) > 1e-3
     eng.close()
+
+
+@pytest.mark.parametrize("ir_len,block", [(4096, 512), (8192, 512), (16384, 512), (8192, 1024), (4096, 256)] +
+                         [(n, 512) for n in (1024, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193)])
+def test_reference_mt_nupc_measurement_scenarios(amd, oracle, ir_len, block):
+    """The scenarios of the reference's own NUC test (src/tests/MT-NUPC-Measurement.cpp:116-122 MT-NUPC-01 configs,
+    :196-199 MT-NUPC-03 partition-boundary lengths; IR = sign(sin(0.1 i)) :49-51, Dirac in the first block then
+    silence, one block per Add/Get, 2 x irLen output samples :73-85).  The reference asserts SetImpulse success and
+    output energy > 1e-20 (:183); here additionally the whole response must equal the stateful emulation's."""
+    O = oracle
+    i = np.arange(ir_len)
+    ir = np.where(np.sin(i * 0.1) > 0.0, 1.0, -1.0)
+    total = ((ir_len * 2 + block - 1) // block) * block
+    x = np.zeros((2, total))
+    x[:, 0] = 1.0
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=1)
+    eng.set_impulse(0, ir, ir)                                # SetImpulse(ir, irLen, blockSize, 1.0, false, nullptr)
+    assert eng.is_ready() and eng.latency() == max(block, 64)
+    y = np.concatenate([eng.conv_process(x[:, o:o + block]) for o in range(0, total, block)], axis=1)
+    assert float(np.sum(y[0] ** 2)) > 1e-20                   # the reference's own assertion
+    nuc = O.Nuc()
+    assert nuc.set_impulse(ir, block)
+    ref = nuc.run(x[0], block)
+    assert np.abs(y[0] - ref).max() <= 1e-12 and np.array_equal(y[0], y[1])
+    eng.close()
+
+
+def test_reference_mt_nupc_02_dirac_response(amd, oracle):
+    """MT-NUPC-02 (src/tests/MT-NUPC-Measurement.cpp:143-190): IR = sin(0.5 i), 8192 taps, blk 512, Dirac then
+    Add(nullptr) = silence for 16384 output samples; assertion: energy > 1e-20."""
+    O = oracle
+    ir = np.sin(np.arange(8192) * 0.5)
+    x = np.zeros((2, 16384))
+    x[:, 0] = 1.0
+    eng = amd.BatchedEngine(1, block_size=512, max_ir_len=8192, max_blocks_per_call=1)
+    eng.set_impulse(0, ir, ir)
+    y = np.concatenate([eng.conv_process(x[:, o:o + 512]) for o in range(0, 16384, 512)], axis=1)
+    energy = float(np.sum(y[0] ** 2))
+    assert energy > 1e-20
+    nuc = O.Nuc()
+    assert nuc.set_impulse(ir, 512)
+    assert np.abs(y[0] - nuc.run(x[0], 512)).max() <= 1e-12
+    eng.close()

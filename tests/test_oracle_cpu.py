@@ -244,3 +244,26 @@ def test_mid_side_bands_properties(oracle):
     p.bands[10].enabled = 0
     b, _, _ = O.eq_process_stereo(x, x, p)
     assert np.abs(a - b).max() > 1e-6
+
+
+@pytest.mark.parametrize("ir_len,block", [(4096, 512), (8192, 512), (16384, 512), (8192, 1024), (4096, 256)] +
+                         [(n, 512) for n in (1024, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193)])
+def test_oracle_passes_the_references_own_nuc_test(oracle, ir_len, block):
+    """The only checks the reference's tests make on convolver output (src/tests/MT-NUPC-Measurement.cpp:116-122,
+    :183, :196-199): SetImpulse succeeds and the Dirac response has energy > 1e-20, for these (irLen, blockSize) pairs
+    with IR = sign(sin(0.1 i)).  They hold no values, so they cannot pin the oracle's numbers (parity unpinned); on top of
+    them the response of an LTI plan must equal the closed-form h_eff of SURVEY.md A6."""
+    i = np.arange(ir_len)
+    ir = np.where(np.sin(i * 0.1) > 0.0, 1.0, -1.0)
+    total = ((ir_len * 2 + block - 1) // block) * block
+    x = np.zeros(total)
+    x[0] = 1.0
+    nuc = oracle.Nuc()
+    assert nuc.set_impulse(ir, block)
+    y = nuc.run(x, block)
+    assert float(np.sum(y * y)) > 1e-20
+    pl = nuc.plan()
+    if pl.ltiValid:
+        h = oracle.heff(ir, block)
+        m = min(len(h), total)
+        assert np.abs(y[:m] - h[:m]).max() <= 1e-12
