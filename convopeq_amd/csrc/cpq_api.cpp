@@ -408,7 +408,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
                                      tables(e), e->P, e->nCh, T, e->head, e->ringSlots);
         }
         for (int l = 0; l < pl.num_layers; ++l) {
-            const int kTile = (e->macTile == 0 && T >= 32) ? 8 : (e->macTile ? e->macTile : 16);
+            const int kTile = cpq::fdl_mac_kpad_align(e->macTile, T);
             const int kPad = (int)alignUp(e->layerK[l], kTile);
             double* dst = (l == 0) ? dOut : e->layerOut + (int64_t)(l - 1) * e->nCh * stride;
             {
@@ -449,7 +449,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     {
         ProfScope p(e, CPQ_K_FDL_MAC);
         cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh,
-                            (int)alignUp(e->kMaxReal, (e->macTile == 0 && T >= 32) ? 8 : (e->macTile ? e->macTile : 16)), e->ringSlots,
+                            (int)alignUp(e->kMaxReal, cpq::fdl_mac_kpad_align(e->macTile, T)), e->ringSlots,
                             e->head, T, (int64_t)e->hRows * e->P);
     }
     {

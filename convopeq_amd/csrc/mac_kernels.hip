@@ -231,10 +231,29 @@ void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const 
 
 }  // namespace
 
+// Variant for `tile` (0 = automatic) and T output rows per channel: 0 = the workgroup-cooperative kernel (64 outputs
+// per workgroup: worth it from ~48 rows on), else the register tile -- sized so that short calls do not spend most
+// of their FMAs on rows that are not there (T = 1, the reference's own call pattern, is HBM-bound at any tile).
+int fdl_mac_variant(int tile, int T)
+{
+    if (tile) return tile;
+    if (T >= 48) return 0;
+    if (T >= 12) return 16;
+    if (T >= 6) return 8;
+    return 4;
+}
+
+int fdl_mac_kpad_align(int tile, int T)
+{
+    const int v = fdl_mac_variant(tile, T);
+    return v == 0 ? kWgTile : v;
+}
+
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot, double2* Y,
                     int P, int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride)
 {
-    if (tile == 0 && T >= 32) {      // default for long calls: workgroup-cooperative kernel
+    tile = fdl_mac_variant(tile, T);
+    if (tile == 0) {      // long calls: workgroup-cooperative kernel
         const int nGroups = (T + kWgWaves * kWgTile - 1) / (kWgWaves * kWgTile);
         const int nCols = P / 64;
         const int nWork = nCh * nCols * nGroups;
