@@ -120,9 +120,14 @@ def load_pmc_traffic(path, kernel):
     try:
         with open(path) as f:
             d = json.load(f)
+        # the profiler id k_fdl_mac covers the workgroup-cooperative variant of long calls (k_fdl_mac_wg in rocprof
+        # names) and the register-tile variants of short ones (k_fdl_mac<TT, PF>, summarised as "k_fdl_mac")
+        if kernel == "k_fdl_mac" and "k_fdl_mac_wg" in d:
+            return d["k_fdl_mac_wg"].get("hbm_bytes_per_launch")
+        if kernel == "k_fdl_mac:tile":
+            kernel = "k_fdl_mac"
         if kernel in d:
             return d[kernel].get("hbm_bytes_per_launch")
-        # kernel ids group template / variant names (k_fdl_mac covers k_fdl_mac_wg): take the variant that ran
         cands = [v for k, v in d.items() if k.startswith(kernel) and isinstance(v, dict)]
         return max((v.get("hbm_bytes_per_launch") for v in cands), default=None)
     except Exception:
@@ -151,7 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="diagnostic: host-pointer entry point (PCIe-inclusive rate)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json"))
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
@@ -316,7 +321,8 @@ def main():
             gbs1 = b1 / (ms1 / cnt1 * 1e-3) / 1e9
             hbm_regime = {"kernel": "k_fdl_mac", "blocks_per_call": P // B, "algorithmic_bytes_per_launch": b1,
                           "avg_launch_ms": round(ms1 / cnt1, 4), "achieved": round(gbs1, 1),
-                          "frac": round(gbs1 / HBM_PEAK_GBS, 4), "launches": cnt1}
+                          "frac": round(gbs1 / HBM_PEAK_GBS, 4), "launches": cnt1,
+                          "traffic": load_pmc_traffic(args.pmc_json, "k_fdl_mac:tile")}
         flop_per_byte = alg_flops["k_fdl_mac"] / alg_bytes["k_fdl_mac"]
         out = {
             "metric": "Mega stereo-samples/s convolved (131072-tap IR, blk=512)",
