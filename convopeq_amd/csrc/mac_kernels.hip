@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
 constexpr int kWgWaves = 8;
 constexpr int kWgTile = 8;                       // outputs per lane
 constexpr int kWgRingBlocks = kWgWaves + 1;      // blocks of 8 rows
+static_assert(kWgWaves == kWgTile, "k_fdl_mac_wg fetches block -1 one row per wave: waves per workgroup == rows per block");
 
 template <int PFH>
 __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* __restrict__ X,

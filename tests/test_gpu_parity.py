@@ -821,3 +821,36 @@ def test_reference_mt_nupc_02_dirac_response(amd, oracle):
     assert nuc.set_impulse(ir, 512)
     assert np.abs(y[0] - nuc.run(x[0], 512)).max() <= 1e-12
     eng.close()
+
+
+@pytest.mark.parametrize("schedule", ["uniform", "nuc"])
+def test_ragged_call_lengths_across_ring_wraps(amd, oracle, schedule):
+    """Calls of varying length (1 ... T_max blocks, every MAC kernel variant) for long enough that the FDL ring
+    (512 slots at 131072 taps), the tail-layer rings and the delay lines wrap several times."""
+    O = oracle
+    rng = np.random.default_rng(7)
+    T_max, ir_len = 112, 131072
+    sizes = []
+    while sum(sizes) < 1500:
+        sizes.append(int(rng.choice([1, 2, 3, 5, 8, 13, 31, 40, 47, 48, 64, 100, 112])))
+    total = sum(sizes) * B
+    irs = [O.gen_ir(ir_len, channel=ch) for ch in range(2)]
+    x = make_inputs(O, 1, total)
+    ref = np.empty_like(x)
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], B)
+        ref[c] = nuc.run(x[c], B)
+    eng = amd.BatchedEngine(1, max_ir_len=ir_len, max_blocks_per_call=T_max,
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if schedule == "nuc" else amd.CPQ_SCHED_UNIFORM)
+    eng.set_impulse(0, irs[0], irs[1])
+    outs, o = [], 0
+    for t in sizes:
+        outs.append(eng.conv_process(x[:, o:o + t * B]))
+        o += t * B
+    y = np.concatenate(outs, axis=1)
+    err = rms(y - ref)
+    tail_err = rms(y[:, -100 * B:] - ref[:, -100 * B:])
+    print("ragged", schedule, len(sizes), "calls", sum(sizes), "blocks, rms err", err, "last 100 blocks", tail_err)
+    assert err <= 1e-13 and tail_err <= 1e-13
+    eng.close()
