@@ -342,6 +342,10 @@ namespace {
 // ONE P-complex LDS buffer: every thread reads its 8 inputs, barrier, butterflies in registers, writes its 8
 // outputs, barrier.  Stage with radix R and Ns = product of earlier radices, butterfly j in [0, P/R):
 //   k = j mod Ns,  in[j + q P/R] * exp(-2 pi i q k / (R Ns))  ->  out[(j - k) R + k + q Ns].
+// LDS element index with one pad element per 8: the first radix-8 stage writes elements 8 j + q from consecutive lanes j
+// (stride 128 B: an 8-way bank conflict unpadded, conflict-free at stride 9), the second one 64 a + b
+__device__ __forceinline__ int wgp(int i) { return i + (i >> 3); }
+
 template <bool INV>
 __device__ __forceinline__ void wg_stage8(double2* lds, int M, int ns, const double2* __restrict__ twM)
 {
@@ -350,7 +354,7 @@ __device__ __forceinline__ void wg_stage8(double2* lds, int M, int ns, const dou
     const int k = j & (ns - 1);
     double2 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = lds[j + q * stride];
+    for (int q = 0; q < 8; ++q) v[q] = lds[wgp(j + q * stride)];
     if (ns > 1) {
         const int tstep = M / (8 * ns);
 #pragma unroll
@@ -360,7 +364,7 @@ __device__ __forceinline__ void wg_stage8(double2* lds, int M, int ns, const dou
     __syncthreads();
     const int o = ((j - k) << 3) + k;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) lds[o + q * ns] = v[q];
+    for (int q = 0; q < 8; ++q) lds[wgp(o + q * ns)] = v[q];
     __syncthreads();
 }
 
@@ -380,7 +384,7 @@ __device__ __forceinline__ void wg_stage_small(double2* lds, int M, int ns, cons
         outBase[b] = (j - k) * R + k;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            v[b][q] = lds[j + q * stride];
+            v[b][q] = lds[wgp(j + q * stride)];
             if (q > 0) v[b][q] = cmulw<INV>(v[b][q], twM[q * k * tstep]);
         }
         if (R == 4) dft4<INV>(v[b][0], v[b][1], v[b][2], v[b][3]);
@@ -390,7 +394,7 @@ __device__ __forceinline__ void wg_stage_small(double2* lds, int M, int ns, cons
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int q = 0; q < R; ++q) lds[outBase[b] + q * ns] = v[b][q];
+        for (int q = 0; q < R; ++q) lds[wgp(outBase[b] + q * ns)] = v[b][q];
     __syncthreads();
 }
 
@@ -401,6 +405,26 @@ __device__ __forceinline__ void wg_cfft(double2* lds, int M, const double2* __re
     while (ns * 8 <= M) { wg_stage8<INV>(lds, M, ns, twM); ns *= 8; }
     if (ns * 4 == M) wg_stage_small<INV, 4>(lds, M, ns, twM);
     else if (ns * 2 == M) wg_stage_small<INV, 2>(lds, M, ns, twM);
+}
+
+// real-FFT split of the padded LDS buffer (same arithmetic as split_store_generic)
+__device__ __forceinline__ void split_store_wg(const double2* Z, int M, const double2* __restrict__ tw2M,
+                                               double2* __restrict__ spec, double2* __restrict__ dcnyq)
+{
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        const double2 zk = Z[wgp(k)];
+        const double2 zm = Z[wgp((M - k) & (M - 1))];
+        const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+        const double2 o = make_double2(d.y, -d.x);
+        const double2 w = tw2M[k];
+        double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
+        if (k == 0) {
+            xk = make_double2(zk.x + zk.y, zk.x - zk.y);
+            *dcnyq = xk;
+        }
+        spec[k] = xk;
+    }
 }
 
 __global__ __launch_bounds__(512) void k_rfft_fwd_ols_wg(const double* __restrict__ in, int64_t chStride,
@@ -418,14 +442,14 @@ __global__ __launch_bounds__(512) void k_rfft_fwd_ols_wg(const double* __restric
     for (int n = threadIdx.x; n < P; n += blockDim.x) {
         const double* src = (n < halfP) ? (prev + 2 * n) : (cur + 2 * (n - halfP));
         const double2 v = *reinterpret_cast<const double2*>(src);
-        dyn[n] = v;
+        dyn[wgp(n)] = v;
         if (t == T - 1 && n >= halfP) *reinterpret_cast<double2*>(histNew + (int64_t)c * P + 2 * (n - halfP)) = v;
     }
     __syncthreads();
     wg_cfft<false>(dyn, P, tw.tw512);
     const int slot = (head + t) & ringMask;
     const int64_t row = (int64_t)c * (ringMask + 1) + slot;
-    split_store_generic(dyn, P, tw.tw1024, X + row * P, XDN + row);
+    split_store_wg(dyn, P, tw.tw1024, X + row * P, XDN + row);
 }
 
 __global__ __launch_bounds__(512) void k_ir_spectra_wg(const double* __restrict__ heff, int heffLen,
@@ -441,11 +465,11 @@ __global__ __launch_bounds__(512) void k_ir_spectra_wg(const double* __restrict_
             const int i = k * P + 2 * n;
             v = make_double2(i < heffLen ? heff[i] : 0.0, (i + 1) < heffLen ? heff[i + 1] : 0.0);
         }
-        dyn[n] = v;
+        dyn[wgp(n)] = v;
     }
     __syncthreads();
     wg_cfft<false>(dyn, P, tw.tw512);
-    split_store_generic(dyn, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
+    split_store_wg(dyn, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
 }
 
 __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restrict__ Y, double* __restrict__ out,
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
         const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
         double2 z = make_double2(e.x - o.y, e.y + o.x);
         if (k == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
-        dyn[k] = z;
+        dyn[wgp(k)] = z;
     }
     __syncthreads();
     wg_cfft<true>(dyn, P, tw.tw512);
@@ -473,7 +497,7 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
     const double s = 1.0 / (double)P;
     const int halfP = P >> 1;
     for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)
-        *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(dyn[n].x * s, dyn[n].y * s);
+        *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(dyn[wgp(n)].x * s, dyn[wgp(n)].y * s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -743,6 +767,7 @@ void allowLargeLds(K kernel, size_t bytes)
 
 }  // namespace
 
+static size_t wgLdsBytes(int P) { return (size_t)(P + (P >> 3)) * sizeof(double2); }   // padded buffer of the *_wg kernels
 static int genericThreads(int P) { return P / 2 < 64 ? 64 : (P / 2 > 256 ? 256 : P / 2); }
 
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
@@ -761,8 +786,8 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
         hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
                            tw, T, head, ringSlots - 1);
     else if (P >= 1024) {
-        allowLargeLds(k_rfft_fwd_ols_wg, P * sizeof(double2));
-        hipLaunchKernelGGL(k_rfft_fwd_ols_wg, dim3(nCh * T), dim3(P / 8), P * sizeof(double2), stream, in, chStride,
+        allowLargeLds(k_rfft_fwd_ols_wg, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_fwd_ols_wg, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, in, chStride,
                            histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
     } else
         hipLaunchKernelGGL(k_rfft_fwd_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
@@ -783,8 +808,8 @@ void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, doub
     if (P == kP)
         hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
     else if (P >= 1024) {
-        allowLargeLds(k_ir_spectra_wg, P * sizeof(double2));
-        hipLaunchKernelGGL(k_ir_spectra_wg, dim3(nParts), dim3(P / 8), P * sizeof(double2), stream, heff, heffLen, H, HDN,
+        allowLargeLds(k_ir_spectra_wg, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_ir_spectra_wg, dim3(nParts), dim3(P / 8), wgLdsBytes(P), stream, heff, heffLen, H, HDN,
                            tw, P);
     } else
         hipLaunchKernelGGL(k_ir_spectra_generic, dim3(nParts), dim3(genericThreads(P)), 2 * P * sizeof(double2), stream,
@@ -809,8 +834,8 @@ void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int6
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
     else if (P >= 1024) {
-        allowLargeLds(k_rfft_inv_ols_wg, P * sizeof(double2));
-        hipLaunchKernelGGL(k_rfft_inv_ols_wg, dim3(nCh * T), dim3(P / 8), P * sizeof(double2), stream, Y, out, chStride,
+        allowLargeLds(k_rfft_inv_ols_wg, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_inv_ols_wg, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, Y, out, chStride,
                            tw, P, T);
     } else
         hipLaunchKernelGGL(k_rfft_inv_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
