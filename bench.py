@@ -292,7 +292,9 @@ def main():
             "k_convproc_mix": n_ch * n * 16 * max(0, len(layers) - 1),      # delay-line write / read-add of the tail layers
         }
         # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF ~35 fp64 instructions per band-sample
-        alg_flops = {"k_fdl_mac": sum(8.0 * n_ch * nb * kl * pl for pl, kl, nb in layers),
+        # the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex MAC (Gauss), the tile kernels 4
+        mac_flop = lambda nb: 6.0 if nb >= 48 else 8.0
+        alg_flops = {"k_fdl_mac": sum(mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb in layers),
                      "k_svf_cascade_tp": 2.0 * 35 * 20 * n_ch * n}
         per_kernel = {}
         for name, (cnt, ms) in prof.items():
@@ -363,8 +365,8 @@ def main():
                          "sample (~35 fp64 instructions per band-sample) against 16 B of HBM traffic per sample"
                          if dominant.startswith("k_svf") else "HBM stream of FDL and IR spectra"),
                 "fp64_vector": {"achieved_tflops": dk.get("fp64_tflops"), "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
-                # k_fdl_mac at T partitions per call does 8 K T flop per 16 (2K + T) bytes: past the fp64 ridge
-                # (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) from T ~ 45 at K = 259, where the FMA rate binds instead of HBM
+                # k_fdl_mac at T partitions per call executes 6 K T flop (3 FMAs per complex MAC) per 16 (2K + T) bytes:
+                # at the fp64 ridge (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) around T = 64 at K = 259
                 "mac_flop_per_byte": round(flop_per_byte, 2),
                 "ridge_flop_per_byte": round(FP64_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 2),
                 "hbm_regime": hbm_regime,

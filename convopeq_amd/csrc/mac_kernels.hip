@@ -83,7 +83,14 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Workgroup-cooperative variant for calls of >= 32 blocks.
+// Workgroup-cooperative variant for calls of >= 48 blocks.
+//
+// At that batching the kernel is bound by the fp64 FMA rate, not by HBM (8 K T flop per 16 (2K + T) bytes), so the
+// complex MAC is done with THREE real FMAs (Gauss): M1 += a c, M2 += b d, M3 += (a + b)(c + d), Re = M1 - M2,
+// Im = M3 - M1 - M2 at the end.  The X-side sum a + b is formed once when a row enters the register window, the
+// H-side sum c + d once per IR row for the lane's 8 outputs: 26 VALU operations per partition step instead of 32.
+// Rounding differs from the 4-multiply form by the usual Gauss bound (normwise the same order; measured RMS error
+// against the oracle unchanged at 4.9e-16).  The register-tile kernel above (short, HBM-bound calls) keeps 4 FMAs.
 //
 // fp64 FMA needs >= 4 waves per SIMD to approach its issue rate on gfx950 (measured: 1 wave 25-45, 2 waves
 // ~50, 4 waves ~60 TFLOP/s), i.e. <= 128 VGPRs per lane, which caps the register tile at 8 outputs per lane;
@@ -129,11 +136,16 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     auto xrow = [&](int slot) { return Xu + (int64_t)(slot & ringMask) * P; };
     auto hrow = [&](int k) { return Hu + (int64_t)k * P; };
 
-    double2 acc[kWgTile], xw[kWgTile], hn[PFH];
+    // three real products per complex MAC (Gauss): M1 += a c, M2 += b d, M3 += (a + b)(c + d);
+    // Re = M1 - M2, Im = M3 - M1 - M2.  The X-side sums live next to the register window, the H-side sum is formed
+    // once per IR row and serves the 8 outputs of the lane.
+    double m1[kWgTile], m2[kWgTile], m3[kWgTile], xsum[kWgTile];
+    double2 xw[kWgTile], hn[PFH];
 #pragma unroll
     for (int u = 0; u < kWgTile; ++u) {
-        acc[u] = make_double2(0.0, 0.0);
+        m1[u] = 0.0; m2[u] = 0.0; m3[u] = 0.0;
         xw[u] = xrow(base + kWgTile * w + u)[bin];
+        xsum[u] = xw[u].x + xw[u].y;
     }
     // ring prologue: block b (rows base+8b .. base+8b+7) for b = 0..6 is the register window of wave b;
     // block -1 is fetched one row per wave
@@ -158,20 +170,26 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         for (int r = 0; r < kWgTile; ++r) {
             const int k = j * kWgTile + r;
             const double2 h = hn[r % PFH];
+            const double hs = h.x + h.y;
+            // the slot refilled in the previous step (window slot 8-r, first used now): its sum
+            if (r > 0) xsum[kWgTile - r] = xw[kWgTile - r].x + xw[kWgTile - r].y;
             // output 7 is the last user of window slot 7-r: retire it first, then refill the slot straight from
             // the LDS ring (X[t0w - k - 1]); the read's latency hides behind the other seven MACs
             {
                 const double2 x = xw[kWgTile - 1 - r];
-                acc[kWgTile - 1].x = fma(x.x, h.x, fma(-x.y, h.y, acc[kWgTile - 1].x));
-                acc[kWgTile - 1].y = fma(x.x, h.y, fma(x.y, h.x, acc[kWgTile - 1].y));
+                m1[kWgTile - 1] = fma(x.x, h.x, m1[kWgTile - 1]);
+                m2[kWgTile - 1] = fma(x.y, h.y, m2[kWgTile - 1]);
+                m3[kWgTile - 1] = fma(xsum[kWgTile - 1 - r], hs, m3[kWgTile - 1]);
             }
             xw[kWgTile - 1 - r] = blk[(kWgTile - 1 - r) * 64];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < kWgTile - 1; ++i) {
-                const double2 x = xw[(i - r + kWgTile) % kWgTile];
-                acc[i].x = fma(x.x, h.x, fma(-x.y, h.y, acc[i].x));
-                acc[i].y = fma(x.x, h.y, fma(x.y, h.x, acc[i].y));
+                const int sl = (i - r + kWgTile) % kWgTile;
+                const double2 x = xw[sl];
+                m1[i] = fma(x.x, h.x, m1[i]);
+                m2[i] = fma(x.y, h.y, m2[i]);
+                m3[i] = fma(xsum[sl], hs, m3[i]);
             }
             hn[r % PFH] = hrow(k + PFH)[bin];        // IR row k+PFH (zero rows past K), into the slot just consumed
             __builtin_amdgcn_sched_barrier(0);
@@ -179,11 +197,13 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         // slot of block (-j-2) == slot of block (7-j), last read by wave 7 in chunk j-1: free since the barrier
         // that ended that chunk
         ring[(slotOf(-j - 2) * kWgTile + w) * 64 + lane] = xs;
+        // slot 0 was refilled in the last step of this chunk
+        xsum[0] = xw[0].x + xw[0].y;
         __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < kWgTile; ++i)
-        if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * P + bin] = acc[i];
+        if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * P + bin] = make_double2(m1[i] - m2[i], (m3[i] - m1[i]) - m2[i]);
 }
 
 // Packed bin 0 holds (DC, Nyquist): two independent real MACs per (channel, block).  One wave per (channel,
