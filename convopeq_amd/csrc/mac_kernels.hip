@@ -203,7 +203,12 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     }
 #pragma unroll
     for (int i = 0; i < kWgTile; ++i)
-        if (t0w + i < T) Y[((int64_t)c * T + t0w + i) * P + bin] = make_double2(m1[i] - m2[i], (m3[i] - m1[i]) - m2[i]);
+        if (t0w + i < T) {
+            // element 0 packs (DC, Nyquist), two independent REAL MACs: exactly M1 and M2 of the Gauss form, so this
+            // kernel needs no separate DC/Nyquist pass
+            const double2 y = (bin == 0) ? make_double2(m1[i], m2[i]) : make_double2(m1[i] - m2[i], (m3[i] - m1[i]) - m2[i]);
+            Y[((int64_t)c * T + t0w + i) * P + bin] = y;
+        }
 }
 
 // Packed bin 0 holds (DC, Nyquist): two independent real MACs per (channel, block).  One wave per (channel,
