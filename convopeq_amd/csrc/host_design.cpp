@@ -261,7 +261,7 @@ double totalGainLinear(float db)
 //   A = [[2 a1 - 1, -2 a2], [2 a2, 1 - 2 a3]],  Bv = [2 a2, 2 a3],  C = [m1 a1 + m2 a2, -m1 a2 + m2 (1 - a3)]
 namespace {
 typedef long double ld;
-bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double* out);
+bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, ld D, double* out);
 }  // namespace
 
 bool buildSvfTpTables(const cpq_svf_coeffs& c, double* out)
@@ -270,7 +270,8 @@ bool buildSvfTpTables(const cpq_svf_coeffs& c, double* out)
     const ld A[4] = { 2 * a1 - 1, -2 * a2, 2 * a2, 1 - 2 * a3 };
     const ld C[2] = { m1 * a1 + m2 * a2, -m1 * a2 + m2 * (1 - a3) };
     const ld Bv[2] = { 2 * a2, 2 * a3 };
-    return buildTpTablesFromStateSpace(A, C, Bv, out);
+    const ld D = (ld)c.m0 + m1 * a2 + m2 * a3;          // coefficient of v0 in y = m0 v0 + m1 v1 + m2 v2
+    return buildTpTablesFromStateSpace(A, C, Bv, D, out);
 }
 
 // DF-II-T biquad (src/OutputFilter.h:33-68): y = b0 x + w1; w1' = b1 x - a1 y + w2; w2' = b2 x - a2 y
@@ -280,11 +281,11 @@ bool buildBiquadTpTables(const cpq_biquad_coeffs& q, double* out)
     const ld A[4] = { -(ld)q.a1, 1, -(ld)q.a2, 0 };
     const ld C[2] = { 1, 0 };
     const ld Bv[2] = { (ld)q.b1 - (ld)q.a1 * q.b0, (ld)q.b2 - (ld)q.a2 * q.b0 };
-    return buildTpTablesFromStateSpace(A, C, Bv, out);
+    return buildTpTablesFromStateSpace(A, C, Bv, (ld)q.b0, out);
 }
 
 namespace {
-bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double* out)
+bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, ld D, double* out)
 {
     auto mul = [](const ld* x, const ld* y, ld* z) {
         const ld r[4] = { x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3],
@@ -324,7 +325,24 @@ bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, double*
             mul(A, P, P);
         }
     }
-    for (int i = 0; i < 2 * kPerLc; ++i) if (!std::isfinite(out[i])) return false;
+    // matrix form of a 16-sample chunk (MFMA path of the time-parallel kernel): zero-state impulse response
+    // h[0] = D, h[n] = C A^(n-1) B behind 15 zeros, and the chunk's end-state map e[:, k] = A^(15-k) B
+    {
+        double* o = out + 2 * kPerLc;
+        for (int i = 0; i < kSvfTpMfmaDoubles; ++i) o[i] = 0.0;
+        ld v[2] = { Bv[0], Bv[1] };                     // A^n B
+        o[15] = (double)D;
+        for (int n = 1; n < 16; ++n) {
+            o[15 + n] = (double)(C[0] * v[0] + C[1] * v[1]);
+            o[32 + (16 - n)] = (double)v[0];            // e[0][15 - (n-1)] = (A^(n-1) B)_0
+            o[48 + (16 - n)] = (double)v[1];
+            const ld t0 = A[0] * v[0] + A[1] * v[1], t1 = A[2] * v[0] + A[3] * v[1];
+            v[0] = t0; v[1] = t1;
+        }
+        o[32 + 0] = (double)v[0];                       // A^15 B
+        o[48 + 0] = (double)v[1];
+    }
+    for (int i = 0; i < kSvfTpTableDoubles; ++i) if (!std::isfinite(out[i])) return false;
 
     // guard-freedom proof: sup_n |A^n|_inf (carried state) and the l1 gain input -> state must keep every
     // state below 1e15 for |input|, |carried state| < 1e9 (one decade of margin)

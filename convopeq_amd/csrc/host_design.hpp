@@ -14,7 +14,10 @@ namespace cpq {
 constexpr int kSvfTpWaves = CPQ_TP_WAVES;
 constexpr int kSvfTpLc[2] = { 4096 / (64 * kSvfTpWaves), 512 / (64 * kSvfTpWaves) };
 constexpr int kSvfTpLcDoubles = 6 * 4 + 4 + 64 * 4 + 16 * 2;
-constexpr int kSvfTpTableDoubles = 2 * kSvfTpLcDoubles;
+// after the two per-chunk-length blocks: the matrix form of one 16-sample chunk for the MFMA path (chunk length 16 only):
+// ht[32] = 15 zeros, h[0..15], 0 (zero-state impulse response; T[m][k] = ht[15 + m - k]),  e[2][16] = A^(15-k) B
+constexpr int kSvfTpMfmaDoubles = 32 + 2 * 16;
+constexpr int kSvfTpTableDoubles = 2 * kSvfTpLcDoubles + kSvfTpMfmaDoubles;
 
 int    computeNucPlan(int irLen, int blockSize, bool enableDirectHead, const cpq_filter_spec* spec,
                       cpq_nuc_plan* out);

@@ -227,7 +227,13 @@ struct TpLcTables {
     double P[64][4];     // A^(LC*(c+1)): carries the wave's start state to the end of chunk c
     double G[16][2];     // C*A^i, i < LC
 };
-struct TpBandTables { TpLcTables t[2]; };
+// matrix form of one 16-sample chunk for the MFMA path: T[m][k] = ht[15 + m - k] (zero-state response, lower triangular
+// Toeplitz), e[:, k] = A^(15-k) B (end state of the chunk)
+struct TpMfmaTables {
+    double ht[32];
+    double e[2][16];
+};
+struct TpBandTables { TpLcTables t[2]; TpMfmaTables mm; };
 
 // num / den for the fastTanh Pade: den in [27, 209.25], |num| <= 212.7, so the range scaling and special-case
 // fix-up of the generic fp64 division (v_div_scale / v_div_fmas / v_div_fixup, which serialise on VCC) are
@@ -368,20 +374,31 @@ constexpr int kDppRowBcast31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
 // the powers A^(LC 2^k)), then lane 15 of a row carries into the next row and lane 31 into the upper half
 // (row_bcast 15/31) with per-lane powers A^(LC (n+1)), n = lane mod 16 / mod 32; across the W waves the totals are
 // chained through LDS as before.
-__device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const TpLds* L, int b,
-                                        const double* __restrict__ Pglob, double* wtot, double* sState, int tid)
+// per-lane powers A^(LC (n+1)) for n = lane mod 16, lane mod 32, lane: global (L2) loads, to be issued well before the scan
+struct TpLanePowers { double2 pa01, pa23, pb01, pb23, pc01, pc23; };
+__device__ __forceinline__ TpLanePowers tp_load_powers(const double* __restrict__ Pglob, int lane)
+{
+    const double2* Pv = reinterpret_cast<const double2*>(Pglob);
+    TpLanePowers p;
+    p.pa01 = Pv[(lane & 15) * 2]; p.pa23 = Pv[(lane & 15) * 2 + 1];
+    p.pb01 = Pv[(lane & 31) * 2]; p.pb23 = Pv[(lane & 31) * 2 + 1];
+    p.pc01 = Pv[lane * 2];        p.pc23 = Pv[lane * 2 + 1];
+    return p;
+}
+
+// ONE workgroup barrier per band: the wave totals go through wtot[parity] (the caller flips the parity per band, so a
+// wave that is already in the next band writes the other half while slow waves still read this one) and the span's
+// end state goes to sNext while every wave reads the start state from sCur (the caller swaps the two per span).
+__device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const double* Mall, int b,
+                                        const TpLanePowers& pw, double* wtot, const double* sCur, double* sNext, int tid)
 {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the chain below branches on it
-    // per-lane powers, issued now and consumed after the row scan
-    const double2* Pv = reinterpret_cast<const double2*>(Pglob);
-    const double2 pa01 = Pv[(lane & 15) * 2], pa23 = Pv[(lane & 15) * 2 + 1];
-    const double2 pb01 = Pv[(lane & 31) * 2], pb23 = Pv[(lane & 31) * 2 + 1];
-    const double2 pc01 = Pv[lane * 2], pc23 = Pv[lane * 2 + 1];
+    const double2 pa01 = pw.pa01, pa23 = pw.pa23, pb01 = pw.pb01, pb23 = pw.pb23, pc01 = pw.pc01, pc23 = pw.pc23;
     // band row of the LDS tables through a VGPR base, so that every read below is base + immediate offset
-    uint32_t mOff = (uint32_t)b * (uint32_t)sizeof(L->M[0]);
+    uint32_t mOff = (uint32_t)b * (uint32_t)(28 * sizeof(double));      // Mall = [band][28]
     asm volatile("" : "+v"(mOff));
-    const double* Mb = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&L->M[0][0]) + mOff);
+    const double* Mb = reinterpret_cast<const double*>(reinterpret_cast<const char*>(Mall) + mOff);
     double sx = ic1, sy = ic2;
 #define CPQ_ROW_STEP(k)                                                                                       \
     {                                                                                                         \
@@ -417,7 +434,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
     __syncthreads();
     // state at the start of this wave's segment: the span's start state carried through the totals of the waves before it
-    double bx = sState[2 * b], by = sState[2 * b + 1];
+    double bx = sCur[2 * b], by = sCur[2 * b + 1];
     const double mw0 = Mb[24], mw1 = Mb[25], mw2 = Mb[26], mw3 = Mb[27];
     for (int w = 0; w < wave; ++w) {
         const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
@@ -431,8 +448,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     s0x = dpp_f64<kDppWaveShr1, 0xF>(sx);
     s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
     if (lane == 0) { s0x = bx; s0y = by; }
-    __syncthreads();                          // every thread has read sState[b] and wtot
-    if (tid == kTpChunks - 1) { sState[2 * b] = sx; sState[2 * b + 1] = sy; }     // end of the span
+    if (tid == kTpChunks - 1) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }     // end of the span
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
@@ -491,8 +507,8 @@ __device__ __forceinline__ void tp_row_store(const double (&v)[U], double* p)
 // totals of the state scan.  The output stage of band b and the zero-state run of the next active band are
 // fused over the same registers (the next band consumes what the output stage just produced).
 template <int LC, bool SAT>
-__device__ __forceinline__ void tp_span(const double* in, double* out, double* buf, double* wtot, double* sState,
-                                        int* sFlag, const TpLds* L, int tid, const int* __restrict__ fl,
+__device__ __forceinline__ void tp_span(const double* in, double* out, double* buf, double* wtot, double*& sState,
+                                        double*& sNext, int* sFlag, const TpLds* L, int tid, const int* __restrict__ fl,
                                         const TpBandTables* __restrict__ tb, double sat, double gain)
 {
     constexpr int LCI = (LC == kTpLcMain) ? 0 : 1;
@@ -529,6 +545,7 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
         }
     } else {
         double* row = buf + tid * kTpStride;
+        int par = 0;
         int b = 0;
         while (b < kBands && !(fl[b] & 1)) ++b;              // first active band (uniform)
         if (b < kBands) {
@@ -552,7 +569,9 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
                 int nb = b + 1;
                 while (nb < kBands && !(fl[nb] & 1)) ++nb;     // next active band (uniform)
                 double s0x, s0y;
-                tp_scan(ic1, ic2, s0x, s0y, L, b, &tb[b].t[LCI].P[0][0], wtot, sState, tid);
+                tp_scan(ic1, ic2, s0x, s0y, &L->M[0][0], b, tp_load_powers(&tb[b].t[LCI].P[0][0], tid & 63),
+                        wtot + par * 2 * kTpWaves, sState, sNext, tid);
+                par ^= 1;
                 // response table row of band b through a VGPR base: reads below are base + immediate offset
                 uint32_t gOff = (uint32_t)b * (uint32_t)sizeof(L->G[0]);
                 asm volatile("" : "+v"(gOff));
@@ -593,6 +612,199 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
             }
         }
         __syncthreads();
+        { double* t = sState; sState = sNext; sNext = t; }      // the span's end states become the next span's start states
+    }
+#pragma unroll 4
+    for (int it = 0; it < LC; ++it) {
+        const int j = it * kTpChunks + tid;
+        out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA form of the main path (chunk length 16).  Inside one band everything between the input and the output stage
+// is linear, and over a chunk of 16 samples it is a small dense product shared by all chunks of the span:
+//     y_lin (16 x chunks) = [ T | G ] (16 x 18)  .  [ x ; s0 ] (18 x chunks),     e (2 x chunks) = E (2 x 16) . x
+// with T the lower-triangular Toeplitz matrix of the band's zero-state impulse response, G = C A^i the state
+// response and s0 the chunk start states from the scan of the end states e.  That product runs on the matrix cores
+// (v_mfma_f64_16x16x4_f64: 5 per tile of 16 chunks), which are idle otherwise and issue beside the VALU.
+// Register layout = the instruction's own: lane (m = lane & 15, g = lane >> 4) holds of tile tau (16 chunks) the
+// samples g + 4 j (j = register) of chunk 16 tau + m.  The D registers of one band ARE the B operands of the next
+// (k-step s = register s), so the span stays in registers across the 20 bands; the output stage is element-wise.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct TpLdsM {
+    double cf[kBands][6];        // a1 a2 a3 m0 m1 m2 (guarded fallback)
+    double M[kBands][28];        // Mk[6][4], Mw[4] (scan)
+    double Gq[kBands][16][4];    // (C A^i)_x, (C A^i)_y, 0, 0: A-operand rows of the state response
+    double ht[kBands][32];
+    double e[kBands][2][16];
+};
+
+// LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the compiler
+// from moving them across each other
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void tp_load_tables_m(TpLdsM* L, const double* __restrict__ cf,
+                                                 const TpBandTables* __restrict__ tb, int tid)
+{
+    for (int i = tid; i < kBands * 6; i += kTpChunks) L->cf[i / 6][i % 6] = cf[i];
+    for (int i = tid; i < kBands * 28; i += kTpChunks) {
+        const int b = i / 28, q = i % 28;
+        L->M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
+    }
+    for (int i = tid; i < kBands * 64; i += kTpChunks) {
+        const int b = i / 64, r = (i % 64) / 4, q = i % 4;
+        L->Gq[b][r][q] = (q < 2) ? tb[b].t[0].G[r][q] : 0.0;
+    }
+    for (int i = tid; i < kBands * 32; i += kTpChunks) {
+        L->ht[i / 32][i % 32] = tb[i / 32].mm.ht[i % 32];
+        L->e[i / 32][(i % 32) / 16][i % 16] = tb[i / 32].mm.e[(i % 32) / 16][i % 16];
+    }
+    __syncthreads();
+}
+
+template <bool SAT>
+__device__ __forceinline__ void tp_span_mfma(const double* in, double* out, double* buf, double* wtot, double*& sState,
+                                             double*& sNext, int* sFlag, const TpLdsM* L, int tid, const int* __restrict__ fl,
+                                             const TpBandTables* __restrict__ tb, double sat, double gain)
+{
+    constexpr int LC = 16;
+    static_assert(kTpLcMain == LC && kTpWaves == 4, "MFMA path: 4 waves x 64 chunks of 16 samples");
+    const double oneMinusSat = 1.0 - sat;
+    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
+    const double smallC1 = 9.0 - 8.0 * sat;
+    // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
+    bool bad = false;
+#pragma unroll 4
+    for (int it = 0; it < LC; ++it) {
+        const int j = it * kTpChunks + tid;
+        const double x = in[j];
+        bad |= !(fabs(x) < kTpInputBound);
+        buf[(j / LC) * kTpStride + (j % LC)] = x;
+    }
+    if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
+    if (tid == 0) *sFlag = 0;
+    __syncthreads();
+    if (__any(bad) && (tid & 63) == 0) atomicOr(sFlag, 1);
+    __syncthreads();
+    const bool unsafe = (*sFlag != 0);
+    if (unsafe) {
+        for (int b = 0; b < kBands; ++b) {
+            const int flag = fl[b];
+            if (!(flag & 1)) continue;
+            if (tid == 0) {
+                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b);
+            }
+            __syncthreads();
+        }
+    } else {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int m = lane & 15, g = lane >> 4;
+        // registers <- LDS in the MFMA layout
+        v4d x[4];
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) {
+            const double* row = buf + (wave * 64 + tau * 16 + m) * kTpStride + g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[tau][j] = row[4 * j];
+        }
+        __syncthreads();                                  // buf is scratch from here to the write-back
+        double2* red = reinterpret_cast<double2*>(buf) + wave * 256;      // [tau * 4 + g][m]: partial end states
+        double* s0q = buf + 2048 + wave * 256;                            // [chunk of the wave][4]: s0x, s0y, 0, 0
+        int par = 0;
+        for (int b = 0; b < kBands; ++b) {
+            const int flag = fl[b];
+            if (!(flag & 1)) continue;                    // uniform
+            const int kind = (flag >> 1) & 3;
+            // every table read of the band up front (global / LDS latency behind the arithmetic below)
+            const TpLanePowers pw = tp_load_powers(&tb[b].t[0].P[0][0], lane);
+            double a[5];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
+            a[4] = L->Gq[b][m][g];
+            // (1) end state of every chunk's zero-state run: e = E x, partial over this lane's four samples per tile ...
+            double e0[4], e1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e0[j] = L->e[b][0][g + 4 * j]; e1[j] = L->e[b][1][g + 4 * j]; }
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                double px = e0[0] * x[tau][0], py = e1[0] * x[tau][0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) { px = fma(e0[j], x[tau][j], px); py = fma(e1[j], x[tau][j], py); }
+                red[(tau * 4 + g) * 16 + m] = make_double2(px, py);
+            }
+            wave_lds_sync();
+            // ... then over the four lane groups; lane l ends up with chunk l of the wave (tile g, column m)
+            double ic1, ic2;
+#if defined(CPQ_ABL) && (CPQ_ABL & 1)
+            ic1 = x[0][0]; ic2 = x[1][0];
+#else
+            {
+                const double2 p0 = red[(g * 4 + 0) * 16 + m], p1 = red[(g * 4 + 1) * 16 + m];
+                const double2 p2 = red[(g * 4 + 2) * 16 + m], p3 = red[(g * 4 + 3) * 16 + m];
+                ic1 = (p0.x + p1.x) + (p2.x + p3.x);
+                ic2 = (p0.y + p1.y) + (p2.y + p3.y);
+            }
+#endif
+            // (2) chunk start states
+            double s0x, s0y;
+#if defined(CPQ_ABL) && (CPQ_ABL & 2)
+            s0x = ic1 * pw.pa01.x; s0y = ic2 * pw.pc23.y;
+#else
+            tp_scan(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * kTpWaves, sState, sNext, tid);
+            par ^= 1;
+#endif
+            // (3) start states where the MFMA B operand takes them from: row 16 + g of [x ; s0]
+            *reinterpret_cast<double2*>(s0q + lane * 4) = make_double2(s0x, s0y);
+            *reinterpret_cast<double2*>(s0q + lane * 4 + 2) = make_double2(0.0, 0.0);
+            wave_lds_sync();
+            // (4) y_lin = [T | G] [x ; s0] on the matrix cores and (5) the element-wise output stage, software-pipelined:
+            // the five MFMAs of tile tau+1 are issued before the output stage of tile tau, so they run beside it
+            double sb[4];
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) sb[tau] = s0q[(tau * 16 + m) * 4 + g];
+            auto product = [&](int tau) {
+                v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[tau][s4], acc, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f64_16x16x4f64(a[4], sb[tau], acc, 0, 0, 0);
+            };
+            v4d cur = product(0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                v4d nxt = cur;
+                if (tau < 3) nxt = product(tau + 1);
+                if (kind != 2) {          // kind 2 (OutputFilter biquad): linear section, no output stage
+                    double v[4] = { cur[0], cur[1], cur[2], cur[3] };
+                    const double big = fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3])));
+                    if (smallOk && __all(big < 4.5)) {
+                        if (SAT) tp_nonlinear_small<4>(v, smallC1);
+                    } else if (kind == 1) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
+                    else                  tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
+                    cur = v4d{ v[0], v[1], v[2], v[3] };
+                }
+                x[tau] = cur;
+                cur = nxt;
+            }
+        }
+        __syncthreads();                                  // every wave is done with the scratch view of buf
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) {
+            double* row = buf + (wave * 64 + tau * 16 + m) * kTpStride + g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) row[4 * j] = x[tau][j];
+        }
+        __syncthreads();
+        { double* t = sState; sState = sNext; sNext = t; }      // the span's end states become the next span's start states
     }
 #pragma unroll 4
     for (int it = 0; it < LC; ++it) {
@@ -622,9 +834,13 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
                                                               const TpBandTables* __restrict__ tables)
 {
     __shared__ double buf[kTpChunks * kTpStride];
-    __shared__ TpLds L;
-    __shared__ double sState[kBands * 2];
-    __shared__ double wtot[2 * kTpWaves];
+    __shared__ __align__(16) unsigned char ltab[sizeof(TpLdsM) > sizeof(TpLds) ? sizeof(TpLdsM) : sizeof(TpLds)];
+    TpLds& L = *reinterpret_cast<TpLds*>(ltab);             // tables of the 512-sample remainder path
+    TpLdsM& LM = *reinterpret_cast<TpLdsM*>(ltab);          // tables of the MFMA main path (one at a time)
+    __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];     // start / end states of the current span (swapped per span)
+    __shared__ double wtot[2 * 2 * kTpWaves];                        // wave totals, two parities
+    double* sState = sStateA;
+    double* sNext = sStateB;
     __shared__ int sFlag;
     const int tid = threadIdx.x;
     const int c = blockIdx.x;
@@ -632,16 +848,16 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     const int* fl = flags + c * kBands;
     const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;     // tables are per stream
     const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
-    if (tid < kBands * 2) sState[tid] = state[(int64_t)c * kBands * 2 + tid];
+    if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
 
     const double* src = in + (int64_t)c * chStride;
     double* dst = out + (int64_t)c * chStride;
     int done = 0;
     if (nSamples >= kTpChunks * kTpLcMain) {
-        tp_load_tables(&L, cf, tb, 0, tid);
+        tp_load_tables_m(&LM, cf, tb, tid);
         while (nSamples - done >= kTpChunks * kTpLcMain) {
-            if (sat > 0.0) tp_span<kTpLcMain, true>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
-            else           tp_span<kTpLcMain, false>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
+            if (sat > 0.0) tp_span_mfma<true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &LM, tid, fl, tb, sat, gain);
+            else           tp_span_mfma<false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &LM, tid, fl, tb, sat, gain);
             done += kTpChunks * kTpLcMain;
         }
     }
@@ -649,8 +865,8 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
         __syncthreads();
         tp_load_tables(&L, cf, tb, 1, tid);
         while (nSamples - done >= kTpChunks * kTpLcTail) {
-            if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
-            else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, &sFlag, &L, tid, fl, tb, sat, gain);
+            if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
+            else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
             done += kTpChunks * kTpLcTail;
         }
     }
