@@ -389,12 +389,17 @@ __device__ __forceinline__ TpLanePowers tp_load_powers(const double* __restrict_
 // ONE workgroup barrier per band: the wave totals go through wtot[parity] (the caller flips the parity per band, so a
 // wave that is already in the next band writes the other half while slow waves still read this one) and the span's
 // end state goes to sNext while every wave reads the start state from sCur (the caller swaps the two per span).
+// Plate != nullptr: the per-lane powers are loaded from there right where they are used (register-tight callers: the
+// loads then wait on L2 behind the other waves of the SIMD) and pw is ignored.
+template <int NTHREADS = kTpChunks>
 __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const double* Mall, int b,
-                                        const TpLanePowers& pw, double* wtot, const double* sCur, double* sNext, int tid)
+                                        const TpLanePowers& pw, double* wtot, const double* sCur, double* sNext, int tid,
+                                        const double* __restrict__ Plate = nullptr)
 {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the chain below branches on it
-    const double2 pa01 = pw.pa01, pa23 = pw.pa23, pb01 = pw.pb01, pb23 = pw.pb23, pc01 = pw.pc01, pc23 = pw.pc23;
+    const double2* Pl = reinterpret_cast<const double2*>(Plate);
+    double2 pa01 = pw.pa01, pa23 = pw.pa23, pb01 = pw.pb01, pb23 = pw.pb23, pc01 = pw.pc01, pc23 = pw.pc23;
     // band row of the LDS tables through a VGPR base, so that every read below is base + immediate offset
     uint32_t mOff = (uint32_t)b * (uint32_t)(28 * sizeof(double));      // Mall = [band][28]
     asm volatile("" : "+v"(mOff));
@@ -415,6 +420,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     CPQ_ROW_STEP(2)
     CPQ_ROW_STEP(3)
 #undef CPQ_ROW_STEP
+    if (Plate) { pa01 = Pl[(lane & 15) * 2]; pa23 = Pl[(lane & 15) * 2 + 1]; pb01 = Pl[(lane & 31) * 2]; pb23 = Pl[(lane & 31) * 2 + 1]; }
     {   // rows 1 and 3 <- total of the row below
         const double px = dpp_f64<kDppRowBcast15, 0xA>(sx);
         const double py = dpp_f64<kDppRowBcast15, 0xA>(sy);
@@ -432,6 +438,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
         sy = ny;
     }
     if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
+    if (Plate) { pc01 = Pl[lane * 2]; pc23 = Pl[lane * 2 + 1]; }
     __syncthreads();
     // state at the start of this wave's segment: the span's start state carried through the totals of the waves before it
     double bx = sCur[2 * b], by = sCur[2 * b + 1];
@@ -448,7 +455,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     s0x = dpp_f64<kDppWaveShr1, 0xF>(sx);
     s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
     if (lane == 0) { s0x = bx; s0y = by; }
-    if (tid == kTpChunks - 1) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }     // end of the span
+    if (tid == NTHREADS - 1) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }     // end of the span
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
@@ -670,6 +677,110 @@ __device__ __forceinline__ void tp_load_tables_m(TpLdsM* L, const double* __rest
     __syncthreads();
 }
 
+// The band loop of the matrix form: x = the wave's 64 chunks in the MFMA layout (in and out); red / s0q = the wave's LDS
+// scratch (256 double2 / 256 doubles); NTHREADS = threads of the workgroup (64 per wave of the span).
+// wtot: two parities of [2 * waves] wave totals (one workgroup barrier per band, see tp_scan).  A barrier-free variant
+// (totals published with per-band flags, waves polling only their predecessors) measured slower: 0.59 vs 0.58 ms.
+template <bool SAT, int NTHREADS>
+__device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double* s0q, double* wtot, const double* sState,
+                                              double* sNext, const TpLdsM* L, int tid, const int* __restrict__ fl,
+                                              const TpBandTables* __restrict__ tb, double sat)
+{
+    const int lane = tid & 63;
+    const int m = lane & 15, g = lane >> 4;
+    const double oneMinusSat = 1.0 - sat;
+    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
+    const double smallC1 = 9.0 - 8.0 * sat;
+        int par = 0;
+        for (int b = 0; b < kBands; ++b) {
+            const int flag = fl[b];
+            if (!(flag & 1)) continue;                    // uniform
+            const int kind = (flag >> 1) & 3;
+            // four waves per channel (256 registers available): every table read of the band up front; eight waves (128
+            // registers): each table is read where it is used
+            constexpr bool kEarly = (NTHREADS == 256);
+            TpLanePowers pw = {};
+            double a[5];
+            if (kEarly) {
+                pw = tp_load_powers(&tb[b].t[0].P[0][0], lane);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
+                a[4] = L->Gq[b][m][g];
+            }
+            // (1) end state of every chunk's zero-state run: e = E x, partial over this lane's four samples per tile ...
+            double e0[4], e1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e0[j] = L->e[b][0][g + 4 * j]; e1[j] = L->e[b][1][g + 4 * j]; }
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                double px = e0[0] * x[tau][0], py = e1[0] * x[tau][0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) { px = fma(e0[j], x[tau][j], px); py = fma(e1[j], x[tau][j], py); }
+                red[(tau * 4 + g) * 16 + m] = make_double2(px, py);
+            }
+            wave_lds_sync();
+            // ... then over the four lane groups; lane l ends up with chunk l of the wave (tile g, column m)
+            double ic1, ic2;
+#if defined(CPQ_ABL) && (CPQ_ABL & 1)
+            ic1 = x[0][0]; ic2 = x[1][0];
+#else
+            {
+                const double2 p0 = red[(g * 4 + 0) * 16 + m], p1 = red[(g * 4 + 1) * 16 + m];
+                const double2 p2 = red[(g * 4 + 2) * 16 + m], p3 = red[(g * 4 + 3) * 16 + m];
+                ic1 = (p0.x + p1.x) + (p2.x + p3.x);
+                ic2 = (p0.y + p1.y) + (p2.y + p3.y);
+            }
+#endif
+            // (2) chunk start states
+            double s0x, s0y;
+#if defined(CPQ_ABL) && (CPQ_ABL & 2)
+            s0x = ic1 * pw.pa01.x; s0y = ic2 * pw.pc23.y;
+#else
+            tp_scan<NTHREADS>(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * (NTHREADS / 64), sState, sNext, tid,
+                              kEarly ? nullptr : &tb[b].t[0].P[0][0]);
+            par ^= 1;
+#endif
+            // (3) start states where the MFMA B operand takes them from: row 16 + g of [x ; s0]
+            *reinterpret_cast<double2*>(s0q + lane * 4) = make_double2(s0x, s0y);
+            *reinterpret_cast<double2*>(s0q + lane * 4 + 2) = make_double2(0.0, 0.0);
+            wave_lds_sync();
+            // (4) y_lin = [T | G] [x ; s0] on the matrix cores and (5) the element-wise output stage, software-pipelined:
+            // the five MFMAs of tile tau+1 are issued before the output stage of tile tau, so they run beside it
+            if (!kEarly) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
+                a[4] = L->Gq[b][m][g];
+            }
+            double sb[4];
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) sb[tau] = s0q[(tau * 16 + m) * 4 + g];
+            auto product = [&](int tau) {
+                v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[tau][s4], acc, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f64_16x16x4f64(a[4], sb[tau], acc, 0, 0, 0);
+            };
+            v4d cur = product(0);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                v4d nxt = cur;
+                if (kEarly && tau < 3) nxt = product(tau + 1);
+                if (kind != 2) {          // kind 2 (OutputFilter biquad): linear section, no output stage
+                    double v[4] = { cur[0], cur[1], cur[2], cur[3] };
+                    const double big = fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3])));
+                    if (smallOk && __all(big < 4.5)) {
+                        if (SAT) tp_nonlinear_small<4>(v, smallC1);
+                    } else if (kind == 1) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
+                    else                  tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
+                    cur = v4d{ v[0], v[1], v[2], v[3] };
+                }
+                x[tau] = cur;
+                if (!kEarly && tau < 3) nxt = product(tau + 1);
+                cur = nxt;
+            }
+        }
+}
+
 template <bool SAT>
 __device__ __forceinline__ void tp_span_mfma(const double* in, double* out, double* buf, double* wtot, double*& sState,
                                              double*& sNext, int* sFlag, const TpLdsM* L, int tid, const int* __restrict__ fl,
@@ -677,9 +788,6 @@ __device__ __forceinline__ void tp_span_mfma(const double* in, double* out, doub
 {
     constexpr int LC = 16;
     static_assert(kTpLcMain == LC && kTpWaves == 4, "MFMA path: 4 waves x 64 chunks of 16 samples");
-    const double oneMinusSat = 1.0 - sat;
-    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
-    const double smallC1 = 9.0 - 8.0 * sat;
     // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
     bool bad = false;
 #pragma unroll 4
@@ -720,82 +828,7 @@ __device__ __forceinline__ void tp_span_mfma(const double* in, double* out, doub
         __syncthreads();                                  // buf is scratch from here to the write-back
         double2* red = reinterpret_cast<double2*>(buf) + wave * 256;      // [tau * 4 + g][m]: partial end states
         double* s0q = buf + 2048 + wave * 256;                            // [chunk of the wave][4]: s0x, s0y, 0, 0
-        int par = 0;
-        for (int b = 0; b < kBands; ++b) {
-            const int flag = fl[b];
-            if (!(flag & 1)) continue;                    // uniform
-            const int kind = (flag >> 1) & 3;
-            // every table read of the band up front (global / LDS latency behind the arithmetic below)
-            const TpLanePowers pw = tp_load_powers(&tb[b].t[0].P[0][0], lane);
-            double a[5];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
-            a[4] = L->Gq[b][m][g];
-            // (1) end state of every chunk's zero-state run: e = E x, partial over this lane's four samples per tile ...
-            double e0[4], e1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { e0[j] = L->e[b][0][g + 4 * j]; e1[j] = L->e[b][1][g + 4 * j]; }
-#pragma unroll
-            for (int tau = 0; tau < 4; ++tau) {
-                double px = e0[0] * x[tau][0], py = e1[0] * x[tau][0];
-#pragma unroll
-                for (int j = 1; j < 4; ++j) { px = fma(e0[j], x[tau][j], px); py = fma(e1[j], x[tau][j], py); }
-                red[(tau * 4 + g) * 16 + m] = make_double2(px, py);
-            }
-            wave_lds_sync();
-            // ... then over the four lane groups; lane l ends up with chunk l of the wave (tile g, column m)
-            double ic1, ic2;
-#if defined(CPQ_ABL) && (CPQ_ABL & 1)
-            ic1 = x[0][0]; ic2 = x[1][0];
-#else
-            {
-                const double2 p0 = red[(g * 4 + 0) * 16 + m], p1 = red[(g * 4 + 1) * 16 + m];
-                const double2 p2 = red[(g * 4 + 2) * 16 + m], p3 = red[(g * 4 + 3) * 16 + m];
-                ic1 = (p0.x + p1.x) + (p2.x + p3.x);
-                ic2 = (p0.y + p1.y) + (p2.y + p3.y);
-            }
-#endif
-            // (2) chunk start states
-            double s0x, s0y;
-#if defined(CPQ_ABL) && (CPQ_ABL & 2)
-            s0x = ic1 * pw.pa01.x; s0y = ic2 * pw.pc23.y;
-#else
-            tp_scan(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * kTpWaves, sState, sNext, tid);
-            par ^= 1;
-#endif
-            // (3) start states where the MFMA B operand takes them from: row 16 + g of [x ; s0]
-            *reinterpret_cast<double2*>(s0q + lane * 4) = make_double2(s0x, s0y);
-            *reinterpret_cast<double2*>(s0q + lane * 4 + 2) = make_double2(0.0, 0.0);
-            wave_lds_sync();
-            // (4) y_lin = [T | G] [x ; s0] on the matrix cores and (5) the element-wise output stage, software-pipelined:
-            // the five MFMAs of tile tau+1 are issued before the output stage of tile tau, so they run beside it
-            double sb[4];
-#pragma unroll
-            for (int tau = 0; tau < 4; ++tau) sb[tau] = s0q[(tau * 16 + m) * 4 + g];
-            auto product = [&](int tau) {
-                v4d acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[tau][s4], acc, 0, 0, 0);
-                return __builtin_amdgcn_mfma_f64_16x16x4f64(a[4], sb[tau], acc, 0, 0, 0);
-            };
-            v4d cur = product(0);
-#pragma unroll
-            for (int tau = 0; tau < 4; ++tau) {
-                v4d nxt = cur;
-                if (tau < 3) nxt = product(tau + 1);
-                if (kind != 2) {          // kind 2 (OutputFilter biquad): linear section, no output stage
-                    double v[4] = { cur[0], cur[1], cur[2], cur[3] };
-                    const double big = fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3])));
-                    if (smallOk && __all(big < 4.5)) {
-                        if (SAT) tp_nonlinear_small<4>(v, smallC1);
-                    } else if (kind == 1) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
-                    else                  tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
-                    cur = v4d{ v[0], v[1], v[2], v[3] };
-                }
-                x[tau] = cur;
-                cur = nxt;
-            }
-        }
+        tp_bands_mfma<SAT, kTpChunks>(x, red, s0q, wtot, sState, sNext, L, tid, fl, tb, sat);
         __syncthreads();                                  // every wave is done with the scratch view of buf
 #pragma unroll
         for (int tau = 0; tau < 4; ++tau) {
@@ -874,6 +907,122 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Eight waves per channel: spans of 8192 samples (512 chunks of 16).  The band loop is a dependent chain (end states ->
+// reduction -> scan -> product -> output stage) that two waves per SIMD do not hide; with twice the waves per channel
+// four waves share a SIMD.  No LDS staging of the span (it would not fit twice per CU beside the tables): every lane
+// loads and stores its 16 samples straight in the MFMA layout (4 x 8 B per 128-byte line and instruction, the four
+// registers of a tile cover the line).  Spans with non-finite / out-of-range input go through the guarded sequential
+// code in two 4096-sample halves staged in the scratch area.  Handles whole 8192-sample spans only; the launcher runs
+// k_svf_cascade_tp on what is left.
+constexpr int kTp8Threads = 512;
+constexpr int kTp8Span = kTp8Threads * 16;
+constexpr int kTp8ScratchDoubles = 8 * (512 + 256);        // per wave: red (256 double2) + s0q (256 doubles) = 48 KB
+
+__global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double* in, double* out, int64_t chStride,
+                                                                int nSpans, const double* __restrict__ coef,
+                                                                const int* __restrict__ flags,
+                                                                const double* __restrict__ satGain,
+                                                                double* __restrict__ state,
+                                                                const TpBandTables* __restrict__ tables)
+{
+    static_assert(kTp8ScratchDoubles >= 256 * kTpStride, "the guarded path stages 4096 samples in the scratch area");
+    __shared__ __align__(16) double scratch[kTp8ScratchDoubles];
+    __shared__ TpLdsM LM;
+    __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];
+    __shared__ double wtot[2 * 2 * 8];
+    __shared__ int sFlag;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int c = blockIdx.x;
+    const double* cf = coef + (int64_t)c * kBands * 6;
+    const int* fl = flags + c * kBands;
+    const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;
+    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
+    double* sState = sStateA;
+    double* sNext = sStateB;
+    if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
+    // tables (same content as tp_load_tables_m, 512 threads)
+    for (int i = tid; i < kBands * 6; i += kTp8Threads) LM.cf[i / 6][i % 6] = cf[i];
+    for (int i = tid; i < kBands * 28; i += kTp8Threads) {
+        const int b = i / 28, q = i % 28;
+        LM.M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
+    }
+    for (int i = tid; i < kBands * 64; i += kTp8Threads) {
+        const int b = i / 64, r = (i % 64) / 4, q = i % 4;
+        LM.Gq[b][r][q] = (q < 2) ? tb[b].t[0].G[r][q] : 0.0;
+    }
+    for (int i = tid; i < kBands * 32; i += kTp8Threads) {
+        LM.ht[i / 32][i % 32] = tb[i / 32].mm.ht[i % 32];
+        LM.e[i / 32][(i % 32) / 16][i % 16] = tb[i / 32].mm.e[(i % 32) / 16][i % 16];
+    }
+    __syncthreads();
+
+    for (int sp = 0; sp < nSpans; ++sp) {
+        const double* src = in + (int64_t)c * chStride + (int64_t)sp * kTp8Span;
+        double* dst = out + (int64_t)c * chStride + (int64_t)sp * kTp8Span;
+        v4d x[4];
+        bool bad = false;
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) {
+            const double* p = src + (wave * 64 + tau * 16 + m) * 16 + g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[tau][j] = p[4 * j];
+                bad |= !(fabs(x[tau][j]) < kTpInputBound);
+            }
+        }
+        if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
+        if (tid == 0) sFlag = 0;
+        __syncthreads();
+        if (__any(bad) && lane == 0) atomicOr(&sFlag, 1);
+        __syncthreads();
+        if (sFlag != 0) {
+            // guarded path: two halves of 4096 samples through the one-thread reference recurrence, staged in the scratch
+            // area in the [chunk][sample] layout of the four-wave kernel; in and out may alias, every sample is read
+            // before the half is written
+            for (int half = 0; half < 2; ++half) {
+                for (int it = 0; it < 8; ++it) {
+                    const int j = it * kTp8Threads + tid;
+                    scratch[(j / 16) * kTpStride + (j % 16)] = src[half * 4096 + j];
+                }
+                __syncthreads();
+                for (int b = 0; b < kBands; ++b) {
+                    const int flag = fl[b];
+                    if (!(flag & 1)) continue;
+                    if (tid == 0) {
+                        if (flag & 4)      tp_band_guarded<2>(scratch, 16, LM.cf[b], sat, sState + 2 * b);
+                        else if (flag & 2) tp_band_guarded<1>(scratch, 16, LM.cf[b], sat, sState + 2 * b);
+                        else               tp_band_guarded<0>(scratch, 16, LM.cf[b], sat, sState + 2 * b);
+                    }
+                    __syncthreads();
+                }
+                for (int it = 0; it < 8; ++it) {
+                    const int j = it * kTp8Threads + tid;
+                    dst[half * 4096 + j] = scratch[(j / 16) * kTpStride + (j % 16)] * gain;
+                }
+                __syncthreads();
+            }
+            continue;
+        }
+        double2* red = reinterpret_cast<double2*>(scratch) + wave * 256;
+        double* s0q = scratch + 8 * 512 + wave * 256;
+        if (sat > 0.0) tp_bands_mfma<true, kTp8Threads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
+        else           tp_bands_mfma<false, kTp8Threads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
+#pragma unroll
+        for (int tau = 0; tau < 4; ++tau) {
+            double* p = dst + (wave * 64 + tau * 16 + m) * 16 + g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[4 * j] = x[tau][j] * gain;
+        }
+        __syncthreads();                      // the last thread's end states are in sNext
+        { double* t = sState; sState = sNext; sNext = t; }
+    }
+    __syncthreads();
+    if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
+}
+
 }  // namespace
 
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
@@ -895,7 +1044,14 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
                            const void* tables)
 {
     static_assert(sizeof(TpBandTables) == kSvfTpTableDoubles * sizeof(double), "host/device table layout");
-    hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in, out, chStride, nSamples, coef, flags,
-                       satGain, state, reinterpret_cast<const TpBandTables*>(tables));
+    // whole 8192-sample spans on the eight-wave kernel, the rest (multiples of 512) on the four-wave one
+    const int nSpans8 = (kTpLcMain == 16 && kTpWaves == 4) ? nSamples / kTp8Span : 0;
+    if (nSpans8 > 0)
+        hipLaunchKernelGGL(k_svf_cascade_tp8, dim3(nCh), dim3(kTp8Threads), 0, stream, in, out, chStride, nSpans8, coef, flags,
+                           satGain, state, reinterpret_cast<const TpBandTables*>(tables));
+    const int done = nSpans8 * kTp8Span;
+    if (nSamples > done)
+        hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in + done, out + done, chStride,
+                           nSamples - done, coef, flags, satGain, state, reinterpret_cast<const TpBandTables*>(tables));
 }
 }  // namespace cpq

@@ -854,3 +854,29 @@ def test_ragged_call_lengths_across_ring_wraps(amd, oracle, schedule):
     print("ragged", schedule, len(sizes), "calls", sum(sizes), "blocks, rms err", err, "last 100 blocks", tail_err)
     assert err <= 1e-13 and tail_err <= 1e-13
     eng.close()
+
+
+@pytest.mark.parametrize("sat", [0.0, 0.2])
+def test_eq_time_parallel_kernels_hand_over_state(amd, oracle, sat):
+    """One call of 43 blocks = two 8192-sample spans (eight-wave matrix-form kernel) + one 4096-sample span (four-wave
+    matrix form) + three 512-sample spans (VALU form, chunk length 2); band states pass between the three through the
+    state array.  A later call injects a NaN into the second 8192-sample span (guarded path in two staged halves)."""
+    O = oracle
+    S, T = 2, 43
+    x = make_inputs(O, S, 3 * T * B)
+    x[1, 2 * T * B + 8192 + 5000] = np.nan
+    po = O.eq_params_bench(sat)
+    po.bands[6].channelMode = 1
+    po.totalGainDb = 0.75
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.profile_enable(True)
+    y = np.concatenate([eng.eq_process(x[:, o:o + T * B]) for o in range(0, x.shape[1], T * B)], axis=1)
+    assert eng.profile_read()["k_svf_cascade_tp"][0] == 3 and eng.profile_read()["k_svf_cascade"][0] == 0
+    worst = 0.0
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po)
+        worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+    print("tp hand-over sat", sat, "max abs diff", worst)
+    assert np.all(np.isfinite(y)) and worst <= 1e-13
+    eng.close()
