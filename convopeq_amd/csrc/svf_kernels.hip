@@ -696,17 +696,13 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
             const int flag = fl[b];
             if (!(flag & 1)) continue;                    // uniform
             const int kind = (flag >> 1) & 3;
-            // four waves per channel (256 registers available): every table read of the band up front; eight waves (128
-            // registers): each table is read where it is used
-            constexpr bool kEarly = (NTHREADS == 256);
+            // tables of the band
+            constexpr bool kEarly = (NTHREADS == 256);        // four waves per channel: 256 registers, per-lane powers hoisted
             TpLanePowers pw = {};
-            double a[5];
-            if (kEarly) {
-                pw = tp_load_powers(&tb[b].t[0].P[0][0], lane);
+            if (kEarly) pw = tp_load_powers(&tb[b].t[0].P[0][0], lane);
+            double a[4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
-                a[4] = L->Gq[b][m][g];
-            }
+            for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
             // (1) end state of every chunk's zero-state run: e = E x, partial over this lane's four samples per tile ...
             double e0[4], e1[4];
 #pragma unroll
@@ -718,11 +714,28 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
                 for (int j = 1; j < 4; ++j) { px = fma(e0[j], x[tau][j], px); py = fma(e1[j], x[tau][j], py); }
                 red[(tau * 4 + g) * 16 + m] = make_double2(px, py);
             }
+            // (2) the zero-state part of the product, T x, does not wait for the start states: its 16 MFMAs go to the
+            // matrix pipe now and run beside the reduction and the scan below (x is dead from here: acc takes its place)
+#if !(defined(CPQ_ABL) && (CPQ_ABL & 4))
+            {
+                v4d acc[4];
+#pragma unroll
+                for (int tau = 0; tau < 4; ++tau) acc[tau] = v4d{ 0.0, 0.0, 0.0, 0.0 };
+                // k-step major: consecutive MFMAs belong to different tiles, so none waits for its own accumulator
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int tau = 0; tau < 4; ++tau)
+                        acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[tau][s4], acc[tau], 0, 0, 0);
+#pragma unroll
+                for (int tau = 0; tau < 4; ++tau) x[tau] = acc[tau];
+            }
+#endif
             wave_lds_sync();
-            // ... then over the four lane groups; lane l ends up with chunk l of the wave (tile g, column m)
+            // ... the partial end states summed over the four lane groups; lane l ends up with chunk l of the wave
             double ic1, ic2;
 #if defined(CPQ_ABL) && (CPQ_ABL & 1)
-            ic1 = x[0][0]; ic2 = x[1][0];
+            ic1 = e0[0]; ic2 = e1[1];
 #else
             {
                 const double2 p0 = red[(g * 4 + 0) * 16 + m], p1 = red[(g * 4 + 1) * 16 + m];
@@ -731,52 +744,41 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
                 ic2 = (p0.y + p1.y) + (p2.y + p3.y);
             }
 #endif
-            // (2) chunk start states
+            // (3) chunk start states
             double s0x, s0y;
 #if defined(CPQ_ABL) && (CPQ_ABL & 2)
-            s0x = ic1 * pw.pa01.x; s0y = ic2 * pw.pc23.y;
+            s0x = ic1 * e0[1]; s0y = ic2 * e1[0];
 #else
             tp_scan<NTHREADS>(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * (NTHREADS / 64), sState, sNext, tid,
                               kEarly ? nullptr : &tb[b].t[0].P[0][0]);
             par ^= 1;
 #endif
-            // (3) start states where the MFMA B operand takes them from: row 16 + g of [x ; s0]
+            // (4) the state response G s0 completes the product (k-step 4: rows 16 + g of [x ; s0], staged through the
+            // wave's LDS scratch), tile by tile, followed by (5) the element-wise output stage of that tile
             *reinterpret_cast<double2*>(s0q + lane * 4) = make_double2(s0x, s0y);
             *reinterpret_cast<double2*>(s0q + lane * 4 + 2) = make_double2(0.0, 0.0);
             wave_lds_sync();
-            // (4) y_lin = [T | G] [x ; s0] on the matrix cores and (5) the element-wise output stage, software-pipelined:
-            // the five MFMAs of tile tau+1 are issued before the output stage of tile tau, so they run beside it
-            if (!kEarly) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
-                a[4] = L->Gq[b][m][g];
-            }
+            const double ag = L->Gq[b][m][g];
             double sb[4];
 #pragma unroll
             for (int tau = 0; tau < 4; ++tau) sb[tau] = s0q[(tau * 16 + m) * 4 + g];
-            auto product = [&](int tau) {
-                v4d acc = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[tau][s4], acc, 0, 0, 0);
-                return __builtin_amdgcn_mfma_f64_16x16x4f64(a[4], sb[tau], acc, 0, 0, 0);
-            };
-            v4d cur = product(0);
+            for (int tau = 0; tau < 4; ++tau) x[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, sb[tau], x[tau], 0, 0, 0);
+#if defined(CPQ_ABL) && (CPQ_ABL & 8)
+            if (false) {
+#else
+            if (kind != 2) {          // kind 2 (OutputFilter biquad): linear section, no output stage
+#endif
 #pragma unroll
-            for (int tau = 0; tau < 4; ++tau) {
-                v4d nxt = cur;
-                if (kEarly && tau < 3) nxt = product(tau + 1);
-                if (kind != 2) {          // kind 2 (OutputFilter biquad): linear section, no output stage
-                    double v[4] = { cur[0], cur[1], cur[2], cur[3] };
+                for (int tau = 0; tau < 4; ++tau) {
+                    double v[4] = { x[tau][0], x[tau][1], x[tau][2], x[tau][3] };
                     const double big = fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3])));
                     if (smallOk && __all(big < 4.5)) {
                         if (SAT) tp_nonlinear_small<4>(v, smallC1);
                     } else if (kind == 1) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
                     else                  tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
-                    cur = v4d{ v[0], v[1], v[2], v[3] };
+                    x[tau] = v4d{ v[0], v[1], v[2], v[3] };
                 }
-                x[tau] = cur;
-                if (!kEarly && tau < 3) nxt = product(tau + 1);
-                cur = nxt;
             }
         }
 }
