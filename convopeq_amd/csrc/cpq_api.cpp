@@ -83,6 +83,14 @@ struct cpq_engine {
     double* heffDev = nullptr;  // staging for one h_eff upload
     double* gainDev = nullptr;  // [P+1] spectral gains of a FilterSpec
     bool directHead = false;    // last set_impulse enabled the direct head (affects the processor-level dry delay)
+    // direct head (allocated on first use): reversed, scaled head taps and tap count per IR slot, input history, output
+    double* directIr = nullptr;         // [nCh slots][32]
+    int* directTaps = nullptr;          // [nCh slots]
+    double* directHist[2] = { nullptr, nullptr };   // [nCh][32] last input samples, ping-pong
+    double* directOut = nullptr;        // [nCh][tMax * P]
+    int directSel = 0;
+    std::vector<int> directTapsHost;    // per IR slot
+    bool anyDirect = false;
     int64_t heffCap = 0;
     double2* tw512 = nullptr;
     double2* tw1024 = nullptr;
@@ -399,6 +407,17 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     if (!cpq_conv_is_ready(e)) return fail(e, CPQ_ERR_NOT_READY, "set_impulse has not covered every stream");
     const int64_t stride = (int64_t)T * e->P;
     if (!e->specTails.empty()) specTailsAppend(e, dIn, (int)stride);
+    if (e->anyDirect) {       // before anything writes dOut, which may alias dIn
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_direct_head(e->stream, dIn, stride, (int)stride, e->directIr, e->directTaps, e->irSlot,
+                                e->directHist[e->directSel], e->directHist[e->directSel ^ 1], e->directOut, e->nCh);
+        e->directSel ^= 1;
+    }
+    auto addDirect = [&]() {
+        if (!e->anyDirect) return;
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_rows_add(e->stream, dOut, stride, e->directOut, (int)stride, e->nCh);
+    };
     if (e->layered) {
         const cpq_nuc_plan& pl = e->layerPlan;
         const int nTail = pl.num_layers - 1;
@@ -436,6 +455,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
                                     nTail > 1 ? pl.part_size[2] : e->B, nTail > 1 ? pl.output_delay[2] : 0, d2,
                                     pl.gain[1], nTail > 1 ? pl.gain[2] : 0.0);
         }
+        addDirect();
         CPQ_HIP(e, hipGetLastError());
         e->head = (e->head + T) & (e->ringSlots - 1);
         e->histSel ^= 1;
@@ -464,7 +484,9 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     CPQ_HIP(e, hipGetLastError());
     e->head = (e->head + T) & (e->ringSlots - 1);
     e->histSel ^= 1;
+    addDirect();          // Get(): direct output first, then the tail layers (src/MKLNonUniformConvolver.cpp:1606-1633)
     if (!e->specTails.empty()) return specTailsRun(e, dOut, (int)stride);
+    CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
 }
 
@@ -615,6 +637,8 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         e->head = 0;
         e->histSel = 0;
         { const int rc = resetSpecTails(e); if (rc != CPQ_OK) return rc; }
+        for (double* p : { e->directHist[0], e->directHist[1] })
+            if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, sizeof(double) * 32 * e->nCh, e->stream));
         if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 3 * sizeof(long long), e->stream));
         if (e->tailRing) CPQ_HIP(e, hipMemsetAsync(e->tailRing, 0, sizeof(double) * (size_t)(e->layerPlan.num_layers - 1) * e->nCh * e->tailRingSlots, e->stream));
         for (double* p : { e->dryHist[0], e->dryHist[1] })
@@ -862,6 +886,8 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
     if (e->procDelay) (void)hipFree(e->procDelay);
+    for (double* p : { e->directIr, e->directHist[0], e->directHist[1], e->directOut }) if (p) (void)hipFree(p);
+    if (e->directTaps) (void)hipFree(e->directTaps);
     delete e;
 }
 
@@ -928,7 +954,6 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
         if (e->P != sp.part_size[0])
             return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec needs partition_size == the reference layer-0 partition (%d)", sp.part_size[0]);
-        if (direct && spec) return fail(e, CPQ_ERR_UNSUPPORTED, "FilterSpec together with the direct head is not implemented");
         if (e->desc.semantics != CPQ_SEM_REFERENCE) return fail(e, CPQ_ERR_INVALID_ARG, "FilterSpec requires reference semantics");
         if (sp.num_layers > 1) {
             if (e->layered) return fail(e, CPQ_ERR_UNSUPPORTED, "engine is in time-varying (layered) mode");
@@ -951,6 +976,23 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     }
 
     CPQ_HIP(e, hipSetDevice(e->device));
+    // Direct head (src/MKLNonUniformConvolver.cpp:689-731): the first min(irLen, partSize0, 32) taps leave the FFT path
+    // (zeroed there, :730-731, before the spectra and any FilterSpec gains are formed) and run as a time-domain FIR.
+    const int headTaps = direct ? std::min(irLen, std::min(nextPow2(std::max(e->desc.block_size, 64)), 32)) : 0;
+    if (direct && !e->directIr) {
+        const size_t callSamples = (size_t)e->tMax * e->P;
+        if (hipMalloc((void**)&e->directIr, sizeof(double) * 32 * e->nCh) != hipSuccess ||
+            hipMalloc((void**)&e->directTaps, sizeof(int) * e->nCh) != hipSuccess ||
+            hipMalloc((void**)&e->directHist[0], sizeof(double) * 32 * e->nCh) != hipSuccess ||
+            hipMalloc((void**)&e->directHist[1], sizeof(double) * 32 * e->nCh) != hipSuccess ||
+            hipMalloc((void**)&e->directOut, sizeof(double) * e->nCh * callSamples) != hipSuccess)
+            return fail(e, CPQ_ERR_OOM, "direct-head buffers could not be allocated");
+        CPQ_HIP(e, hipMemset(e->directIr, 0, sizeof(double) * 32 * e->nCh));
+        CPQ_HIP(e, hipMemset(e->directTaps, 0, sizeof(int) * e->nCh));
+        CPQ_HIP(e, hipMemset(e->directHist[0], 0, sizeof(double) * 32 * e->nCh));
+        CPQ_HIP(e, hipMemset(e->directHist[1], 0, sizeof(double) * 32 * e->nCh));
+        e->directTapsHost.assign(e->nCh, 0);
+    }
     const double* irs[2] = { irL, irR };
     // IR slots: stream s owns slots 2s, 2s+1; CPQ_ALL_STREAMS shares slots 0 and 1 between all streams
     const int slotBase = (stream == CPQ_ALL_STREAMS) ? 0 : 2 * stream;
@@ -1013,6 +1055,17 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             for (int l = 0; l < pl.num_layers; ++l) {
                 heff.assign(irs[ch] + pl.offset[l], irs[ch] + pl.offset[l] + pl.len[l]);
                 if (scaled) for (double& v : heff) v *= scale;
+                if (l == 0 && e->directIr) {
+                    double rev[32] = { 0 };
+                    for (int i = 0; i < headTaps; ++i) {
+                        rev[i] = irs[ch][headTaps - 1 - i] * scale;
+                        if (i < (int)heff.size()) heff[(size_t)i] = 0.0;
+                    }
+                    CPQ_HIP(e, hipMemcpyAsync(e->directIr + slot * 32, rev, sizeof(rev), hipMemcpyHostToDevice, e->stream));
+                    CPQ_HIP(e, hipMemcpyAsync(e->directTaps + slot, &headTaps, sizeof(int), hipMemcpyHostToDevice, e->stream));
+                    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+                    e->directTapsHost[slot] = headTaps;
+                }
                 CPQ_HIP(e, hipMemcpyAsync(e->heffDev, heff.data(), heff.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
                 cpq::launch_ir_spectra(e->stream, e->heffDev, (int)heff.size(), Hs + (int64_t)e->layerRow[l] * e->P,
                                        HDNs + e->layerRow[l], tables(e), e->P, e->layerK[l]);
@@ -1048,6 +1101,17 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             if (rc != CPQ_OK) return fail(e, rc, "layer plan failed");
             heff.assign(irs[ch], irs[ch] + irLen);
             if (std::abs(scale - 1.0) > 1e-12) for (double& v : heff) v *= scale;
+        }
+        if (e->directIr) {
+            double rev[32] = { 0 };
+            for (int i = 0; i < headTaps; ++i) {
+                rev[i] = irs[ch][headTaps - 1 - i] * scale;                  // m_directIRRev (:716-718)
+                if (i < (int)heff.size()) heff[(size_t)i] = 0.0;            // the head leaves the FFT path
+            }
+            CPQ_HIP(e, hipMemcpyAsync(e->directIr + slot * 32, rev, sizeof(rev), hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipMemcpyAsync(e->directTaps + slot, &headTaps, sizeof(int), hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipStreamSynchronize(e->stream));                     // rev / headTaps are stack storage
+            e->directTapsHost[slot] = headTaps;
         }
         const int parts = ((int)heff.size() + e->P - 1) / e->P;
         if (parts > e->kCap) return fail(e, CPQ_ERR_INVALID_ARG, "h_eff needs %d partitions, capacity %d", parts, e->kCap);
@@ -1102,6 +1166,9 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         for (int ch = 0; ch < 2; ++ch) { e->irSlotHost[2 * stream + ch] = 2 * stream + ch; e->irLoaded[2 * stream + ch] = 1; }
     }
     CPQ_HIP(e, hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice));
+    e->anyDirect = false;
+    if (e->directIr)
+        for (int c = 0; c < e->nCh; ++c) if (e->irLoaded[c] && e->directTapsHost[e->irSlotHost[c]] > 0) e->anyDirect = true;
     int kMax = 0;
     for (int c = 0; c < e->nCh; ++c) if (e->irLoaded[c]) kMax = std::max(kMax, e->irParts[e->irSlotHost[c]]);
     e->kMaxReal = kMax;

@@ -105,4 +105,9 @@ void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, 
 void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,
                           int pl2, int ol2, int d2);
 
+// direct head: time-domain FIR of the first <= 32 taps over [history | block] into dout ([nCh][n]); then out += dout
+void launch_direct_head(hipStream_t stream, const double* in, int64_t inStride, int n, const double* irRev, const int* taps,
+                        const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh);
+void launch_rows_add(hipStream_t stream, double* out, int64_t outStride, const double* add, int n, int nCh);
+
 }  // namespace cpq

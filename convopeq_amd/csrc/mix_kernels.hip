@@ -251,6 +251,63 @@ __global__ __launch_bounds__(256) void k_ring_add(double* out, int64_t outStride
     }
 }
 
+
+// ---- direct head (processDirectBlock, src/MKLNonUniformConvolver.cpp:1169-1232): the first <= 32 taps run as a
+// time-domain FIR over [history | block]; same accumulation pattern as the AVX2 loop (two 4-lane FMA accumulators over
+// blocks of 8 taps, lanes summed as (0+2)+(1+3), scalar tail), result flushed to 0 when non-finite or below 1e-20.
+// hist: the last 32 input samples of the previous call per channel (ping-pong: histOld read, histNew written).
+__global__ __launch_bounds__(256) void k_direct_head(const double* __restrict__ in, int64_t inStride, int n,
+                                                     const double* __restrict__ irRev, const int* __restrict__ taps,
+                                                     const int* __restrict__ irSlot, const double* __restrict__ histOld,
+                                                     double* __restrict__ histNew, double* __restrict__ dout)
+{
+    const int c = blockIdx.y;
+    const int slot = irSlot[c];
+    const int nt = taps[slot];
+    const double* h = irRev + slot * 32;
+    const double* x = in + (int64_t)c * inStride;
+    const double* ho = histOld + c * 32;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        double y = 0.0;
+        if (nt > 0) {
+            auto win = [&](int k) {                       // window[s + k], window = [last nt-1 samples | block]
+                const int p = s + k - (nt - 1);
+                return p >= 0 ? x[p] : ho[32 + p];
+            };
+            double a0[4] = { 0, 0, 0, 0 }, a1[4] = { 0, 0, 0, 0 };
+            const int v8 = (nt / 8) * 8;
+            int k = 0;
+            for (; k < v8; k += 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0[j] = fma(h[k + j], win(k + j), a0[j]);
+                    a1[j] = fma(h[k + 4 + j], win(k + 4 + j), a1[j]);
+                }
+            }
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a0[j] + a1[j];
+            y = (v[0] + v[2]) + (v[1] + v[3]);
+            for (; k < nt; ++k) y += h[k] * win(k);
+            if (!(fabs(y) >= 1.0e-20 && fabs(y) <= 1.79769313486231570815e308)) y = 0.0;    // non-finite or below the threshold
+        }
+        dout[(int64_t)c * n + s] = y;
+    }
+    // next history = last 32 samples of (history ++ block)
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int p = n - 32 + (int)threadIdx.x;
+        histNew[c * 32 + threadIdx.x] = p >= 0 ? x[p] : ho[32 + p];
+    }
+}
+
+// out[c][i] += add[c][i]  (Get(): direct output added to the ring output, :1609-1618)
+__global__ __launch_bounds__(256) void k_rows_add(double* out, int64_t outStride, const double* __restrict__ add, int n)
+{
+    double* o = out + (int64_t)blockIdx.y * outStride;
+    const double* a = add + (int64_t)blockIdx.y * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] += a[i];
+}
+
 }  // namespace
 
 void launch_agc_block_rms(hipStream_t stream, const double* x, int64_t chStride, int nCh, int B, int T, double* rms)
@@ -332,6 +389,18 @@ void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int
 {
     hipLaunchKernelGGL(k_tail_schedule, dim3(1), dim3(64), 0, stream, reinterpret_cast<TailState*>(state), sched, T, B, nTail,
                        make_int2(pl1, ol1), make_int2(pl2, ol2), d1, d2);
+}
+
+void launch_direct_head(hipStream_t stream, const double* in, int64_t inStride, int n, const double* irRev, const int* taps,
+                        const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh)
+{
+    hipLaunchKernelGGL(k_direct_head, rowsGrid(n, nCh), dim3(256), 0, stream, in, inStride, n, irRev, taps, irSlot, histOld,
+                       histNew, dout);
+}
+
+void launch_rows_add(hipStream_t stream, double* out, int64_t outStride, const double* add, int n, int nCh)
+{
+    hipLaunchKernelGGL(k_rows_add, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, add, n);
 }
 
 }  // namespace cpq

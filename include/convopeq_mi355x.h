@@ -197,8 +197,10 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
  * Tail partitions up to 32768 samples are supported (above 4096 through a four-step FFT); plans that are time-varying
  * in the reference (cpq_nuc_plan.lti_valid == 0) follow the replayed delay-line reader.
  * Limits (CPQ_ERR_UNSUPPORTED): tail partitions that are not a power of two or exceed 32768, FilterSpec IRs with
- * different layer plans in one engine, partition_size != block_size, FilterSpec together with the direct head.
- * enable_direct_head: accepted; the <= 32 head taps stay in the FFT path (same h_eff, rounding-level difference). */
+ * different layer plans in one engine, partition_size != block_size.
+ * enable_direct_head: the first min(ir_len, 32) taps leave the FFT path before the spectra (and any FilterSpec gains)
+ * are formed and run as a time-domain FIR over [history | block], flushed below 1e-20, added before the tail layers
+ * (src/MKLNonUniformConvolver.cpp:689-731, 1169-1232, 1606-1618). */
 int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* ir_l, const double* ir_r,
                              int32_t ir_len, double scale, int32_t enable_direct_head,
                              const cpq_filter_spec* spec);

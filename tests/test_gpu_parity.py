@@ -287,9 +287,6 @@ def test_prepare_resets_state_and_unsupported_features_fail_loudly(amd, oracle):
     eng.conv_process(x)
     eng.prepare_to_play(48000.0, 4 * B)
     assert np.array_equal(eng.conv_process(x), y1)
-    with pytest.raises(amd.CpqError) as e2:
-        eng.set_impulse(0, ir, ir, direct_head=True, spec=amd.FilterSpec.defaults())
-    assert e2.value.status == -5
     with pytest.raises(amd.CpqError):
         eng.conv_process(x[:, :100])                    # not a multiple of the block size
     p = amd.eq_params_default()
@@ -473,7 +470,8 @@ def test_whole_chain_conv_eq_output_filter(amd, oracle):
 
 
 def test_direct_head_is_accepted(amd, oracle):
-    """enableDirectHead only moves <= 32 taps to a time-domain FIR in the reference: same h_eff."""
+    """enableDirectHead moves the first <= 32 taps to a time-domain FIR (processDirectBlock); without a FilterSpec the
+    sum is the same convolution."""
     O = oracle
     irs = [O.gen_ir(3000, channel=ch) for ch in range(2)]
     x = make_inputs(O, 1, 16 * B)
@@ -879,4 +877,44 @@ def test_eq_time_parallel_kernels_hand_over_state(amd, oracle, sat):
         worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
     print("tp hand-over sat", sat, "max abs diff", worst)
     assert np.all(np.isfinite(y)) and worst <= 1e-13
+    eng.close()
+
+
+@pytest.mark.parametrize("kw,ir_len,block,T,schedule", [(dict(), 3000, 512, 4, "uniform"), (dict(hc_mode=0), 131072, 512, 8, "uniform"),
+                                                       (dict(tail_mode=0), 100000, 256, 12, "uniform"),
+                                                       (None, 131072, 512, 16, "nuc"), (None, 20, 64, 3, "uniform"),
+                                                       (None, 131072, 1024, 4, "uniform")])
+def test_direct_head_time_domain_path(amd, oracle, kw, ir_len, block, T, schedule):
+    """The direct head as the reference runs it (src/MKLNonUniformConvolver.cpp:689-731, 1169-1232): the first
+    min(irLen, 32) taps leave the FFT path BEFORE the partition spectra and any FilterSpec gains are formed, and run as a
+    time-domain FIR over [history | block] whose output is flushed below 1e-20.  With a FilterSpec the head is therefore
+    NOT spectrally shaped -- the case the 'taps stay in the FFT path' shortcut could not represent.  kw = None: no spec
+    (incl. the native non-uniform schedule, an IR shorter than 32 taps, and a time-varying plan at block 1024)."""
+    O = oracle
+    names = {"hc_mode": "hcMode", "lc_mode": "lcMode", "tail_mode": "tailMode"}
+    sa = amd.FilterSpec.defaults(**kw) if kw is not None else None
+    so = O.FilterSpec.defaults(applySpectrumFilter=1, **{names[k]: v for k, v in kw.items()}) if kw is not None else None
+    irs = [O.gen_ir(ir_len, channel=ch) for ch in range(2)]
+    n_calls = max(4, (ir_len + 20000) // (T * block))
+    x = make_inputs(O, 1, n_calls * T * block)
+    ref = np.empty_like(x)
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], block, scale=0.9, direct=True, spec=so)
+        assert nuc.plan().directTaps == min(ir_len, 32)
+        ref[c] = nuc.run(x[c], block)
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=T,
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if schedule == "nuc" else amd.CPQ_SCHED_UNIFORM)
+    eng.set_impulse(0, irs[0], irs[1], scale=0.9, direct_head=True, spec=sa)
+    y = np.concatenate([eng.conv_process(x[:, o:o + T * block]) for o in range(0, x.shape[1], T * block)], axis=1)
+    err = rms(y - ref)
+    print("direct head", kw, ir_len, block, T, schedule, "rms err", err, "signal", rms(ref))
+    assert err <= 1e-13 and rms(ref) > 1e-4
+    # a later IR without the direct head switches the FIR off again for that stream
+    eng.conv_reset()
+    eng.set_impulse(0, irs[0], irs[1], scale=0.9, spec=sa)
+    nuc = O.Nuc()
+    assert nuc.set_impulse(irs[0], block, scale=0.9, spec=so)
+    y2 = eng.conv_process(x[:, :T * block])
+    assert rms(y2[0] - nuc.run(x[0, :T * block], block)) <= 1e-13
     eng.close()
