@@ -162,10 +162,13 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     __syncthreads();
 
     const int nChunks = kPad / kWgTile;
+    const bool active = t0w < T;                  // wave-uniform
     for (int j = 0; j < nChunks; ++j) {
         // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
         const double2 xs = xrow(base + kWgTile * (-j - 2) + w)[bin];
         const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
+        // a wave whose 8 outputs lie beyond T only feeds the ring (partial last group: T mod 64 != 0)
+        if (active)
 #pragma unroll
         for (int r = 0; r < kWgTile; ++r) {
             const int k = j * kWgTile + r;
@@ -258,7 +261,7 @@ void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const 
 }  // namespace
 
 // Variant for `tile` (0 = automatic) and T output rows per channel: 0 = the workgroup-cooperative kernel (64 outputs
-// per workgroup: worth it from ~48 rows on), else the register tile -- sized so that short calls do not spend most
+// per workgroup: waves past the last row only feed the LDS ring; worth it from ~48 rows on (below, the register tiles measured faster)), else the register tile -- sized so that short calls do not spend most
 // of their FMAs on rows that are not there (T = 1, the reference's own call pattern, is HBM-bound at any tile).
 int fdl_mac_variant(int tile, int T)
 {
