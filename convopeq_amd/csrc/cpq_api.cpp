@@ -122,6 +122,13 @@ struct cpq_engine {
     bool eqSet = false;
     std::vector<char> eqTpSafe; // per stream: time-parallel kernel proven guard-free
     std::vector<char> eqMidSide; // per stream: some active band filters the Mid or Side component
+    // last parameters per stream, re-designed when prepare() changes the sample rate (EQProcessor::prepareToPlay rebuilds
+    // its band nodes on a rate change, src/eqprocessor/EQProcessor.Core.cpp:679-826; OutputFilter::prepare likewise)
+    std::vector<cpq_eq_params> eqParamsHost;
+    std::vector<char> eqParamsSet;
+    struct OfModes { int convIsLast, hc, lc, lp; };
+    std::vector<OfModes> ofModesHost;
+    std::vector<char> ofModesSet;
     int eqMode = CPQ_EQ_MODE_AUTO;
     int order = CPQ_ORDER_CONV_THEN_EQ;
     double sampleRate = 48000.0;
@@ -856,6 +863,10 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->slotSpecTail.assign(e->nCh, 0);
     e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
     e->eqMidSide.assign(d->n_streams, 0);
+    e->eqParamsHost.assign(d->n_streams, cpq_eq_params{});
+    e->eqParamsSet.assign(d->n_streams, 0);
+    e->ofModesHost.assign(d->n_streams, cpq_engine::OfModes{ 0, 1, 0, 1 });
+    e->ofModesSet.assign(d->n_streams, 0);
     e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0 });
     e->agcOnHost.assign(d->n_streams, 0);
     e->gainRamp.assign(d->n_streams, cpq_engine::GainRamp{});
@@ -914,7 +925,33 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
     if (sampleRate <= 0.0) return fail(e, CPQ_ERR_INVALID_ARG, "sample rate must be positive");
     if (maxBlock <= 0 || maxBlock > e->P * e->tMax)
         return fail(e, CPQ_ERR_INVALID_ARG, "max_block %d exceeds block_size*max_blocks_per_call", maxBlock);
+    const bool rateChanged = sampleRate != e->sampleRate;
     e->sampleRate = sampleRate;
+    if (rateChanged) {
+        // coefficients follow the rate: re-design what was set (one call when every stream shares the parameters)
+        const int S = e->desc.n_streams;
+        bool same = S > 0 && e->eqParamsSet[0];
+        for (int s = 1; s < S && same; ++s)
+            same = e->eqParamsSet[s] && std::memcmp(&e->eqParamsHost[s], &e->eqParamsHost[0], sizeof(cpq_eq_params)) == 0;
+        if (same) {
+            const cpq_eq_params p = e->eqParamsHost[0];
+            const int rc = cpq_eq_set_params(e, CPQ_ALL_STREAMS, &p);
+            if (rc != CPQ_OK) return rc;
+        } else {
+            for (int s = 0; s < S; ++s)
+                if (e->eqParamsSet[s]) {
+                    const cpq_eq_params p = e->eqParamsHost[s];
+                    const int rc = cpq_eq_set_params(e, s, &p);
+                    if (rc != CPQ_OK) return rc;
+                }
+        }
+        for (int s = 0; s < S; ++s)
+            if (e->ofModesSet[s]) {
+                const auto m = e->ofModesHost[s];
+                const int rc = cpq_outfilter_set_params(e, s, m.convIsLast, m.hc, m.lc, m.lp);
+                if (rc != CPQ_OK) return rc;
+            }
+    }
     e->eqProcessed = false;
     for (auto& r : e->gainRamp) { r.current = r.target = r.wanted; r.step = 0.0; r.remaining = 0; }   // setCurrentAndTargetValue (Core.cpp:765)
     return zeroRuntimeState(e, true, true);
@@ -936,13 +973,9 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
     if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
         return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
     if (irLen > e->desc.max_ir_len) return fail(e, CPQ_ERR_INVALID_ARG, "ir_len %d > max_ir_len %d", irLen, e->desc.max_ir_len);
-    // Direct head (<= 32 taps computed in the time domain, src/MKLNonUniformConvolver.cpp:689-731,1169-1232): the taps
-    // are only MOVED from the FFT path to a direct FIR, so h_eff is unchanged and the engine convolves them in the
-    // FFT path (difference: rounding, and the reference's flush of |direct output| < 1e-20).
-    // FilterSpec: the HC/LC gains multiply every partition spectrum of every layer at that layer's FFT size
-    // (:336-443), which this engine reproduces exactly only for a single-layer plan at P == block size.
-    // With tail layers every layer keeps the reference's own partition size: layer 0 in the main path, each tail layer in
-    // a SpecTail (partition sizes up to 4096, LTI-valid plans; all such IRs of an engine share one plan).
+    // FilterSpec: the HC/LC gains (and the air-absorption damping) multiply every partition spectrum of every layer at
+    // that layer's FFT size (:336-443, :1060-1097), so every layer keeps the reference's own partition size: layer 0 in
+    // the main path, each tail layer in a SpecTail (partitions up to 32768; all such IRs of an engine share one plan).
     // CPQ_SCHED_REFERENCE_NUC runs every IR that way (spec or not): the reference's own partition schedule.
     std::vector<double> gains;
     cpq_nuc_plan sp{};
@@ -1420,6 +1453,7 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     CPQ_HIP(e, hipMemcpy(e->svfSatGain + c0 * 2, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->svfTp + (size_t)s0 * tp.size(), ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
     e->eqSet = true;   // streams never given parameters keep all bands inactive (pass-through)
+    for (int s = s0; s < s1; ++s) { e->eqParamsHost[s] = *p; e->eqParamsSet[s] = 1; }
     for (int s = s0; s < s1; ++s) {
         auto& r = e->gainRamp[s];
         r.wanted = cpq::totalGainLinear(p->total_gain_db);
@@ -1503,6 +1537,7 @@ int32_t cpq_outfilter_set_params(cpq_engine* e, int32_t stream, int32_t convIsLa
     const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
     const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
     const double sg[2] = { 0.0, 1.0 };
+    for (int s = s0; s < s1; ++s) { e->ofModesHost[s] = cpq_engine::OfModes{ convIsLast, hcMode, lcMode, lpMode }; e->ofModesSet[s] = 1; }
     for (int s = s0; s < s1; ++s) {
         for (int ch = 0; ch < 2; ++ch) {
             const size_t c = (size_t)2 * s + ch;

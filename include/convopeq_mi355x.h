@@ -180,8 +180,10 @@ int64_t cpq_engine_arena_bytes(const cpq_engine* e);
 
 /* replaces ConvolverProcessor::prepareToPlay(double,int) (src/convolver/ConvolverProcessor.Lifecycle.cpp:211-402)
  * and EQProcessor::prepareToPlay(double,int) (src/eqprocessor/EQProcessor.Core.cpp:679-826):
- * publishes the rate, zeroes all run-time state (FDL, overlap history, SVF state). max_block must
- * not exceed block_size * max_blocks_per_call. */
+ * publishes the rate, zeroes all run-time state (FDL, overlap history, SVF state) and, when the rate changed, re-designs
+ * the EQ and OutputFilter coefficients from the parameters set so far (the reference rebuilds its band nodes on a rate
+ * change).  IR spectra are not touched: an IR belongs to a rate, load it again if needed.  max_block must not exceed
+ * block_size * max_blocks_per_call. */
 int32_t cpq_engine_prepare(cpq_engine* e, double sample_rate, int32_t max_block);
 int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
 

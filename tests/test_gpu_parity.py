@@ -918,3 +918,27 @@ def test_direct_head_time_domain_path(amd, oracle, kw, ir_len, block, T, schedul
     y2 = eng.conv_process(x[:, :T * block])
     assert rms(y2[0] - nuc.run(x[0, :T * block], block)) <= 1e-13
     eng.close()
+
+
+def test_prepare_with_a_new_sample_rate_redesigns_the_filters(amd, oracle):
+    """EQProcessor::prepareToPlay / OutputFilter::prepare rebuild their coefficients when the rate changes
+    (src/eqprocessor/EQProcessor.Core.cpp:679-826): parameters set at 48 kHz, then prepare(96 kHz)."""
+    O = oracle
+    S, T = 2, 16
+    x = make_inputs(O, S, T * B)
+    po = [O.eq_params_bench(0.2), O.eq_params_bench(0.0)]
+    po[1].bands[3].gain = 5.5
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_eq_params(s, _copy_params(po[s], amd.eq_params_default()))
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    eng.prepare_to_play(96000.0, T * B)
+    y = eng.eq_process(x)
+    z = eng.outfilter_process(x)
+    q = O.outfilter_design(0, 1, 0, 1, 96000.0)
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po[s], sr=96000.0)
+        assert max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max()) <= 1e-13
+        fl, fr, _ = O.outfilter_process_stereo(x[2 * s], x[2 * s + 1], q)
+        assert rms(z[2 * s] - fl) <= 1e-12 and rms(z[2 * s + 1] - fr) <= 1e-12
+    eng.close()
