@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="diagnostic: host-pointer entry point (PCIe-inclusive rate)")
+    ap.add_argument("--pinned", action="store_true", help="with --host-buffers: pin the host buffers (cpq_host_register)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json"))
     args = ap.parse_args()
@@ -217,6 +218,9 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     host_out = np.empty_like(host) if args.host_buffers else None
+    if args.host_buffers and args.pinned:
+        for a in (host, host_out):
+            assert eng._lib.cpq_host_register(a.ctypes.data, a.nbytes) == 0
 
     def step():
         if args.host_buffers:

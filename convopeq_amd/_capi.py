@@ -101,6 +101,8 @@ SYMBOLS = {
     "cpq_engine_arena_bytes": (C.c_int64, [_E]),
     "cpq_engine_prepare": (C.c_int32, [_E, C.c_double, C.c_int32]),
     "cpq_engine_set_order": (C.c_int32, [_E, C.c_int32]),
+    "cpq_host_register": (C.c_int32, [C.c_void_p, C.c_size_t]),
+    "cpq_host_unregister": (C.c_int32, [C.c_void_p]),
     "cpq_conv_set_impulse": (C.c_int32, [_E, C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_int32, C.POINTER(FilterSpec)]),
     "cpq_conv_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_conv_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -56,6 +56,8 @@ struct cpq_engine {
     cpq_engine_desc desc{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copyIn = nullptr, copyOut = nullptr;      // host-pointer entry points: upload / download beside the kernels
+    hipEvent_t evIn[4] = {}, evDone[4] = {};
     std::string lastError;
 
     // geometry
@@ -617,18 +619,66 @@ int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T)
                           e->ofState, e->ofTp);
 }
 
+// Host-pointer entry points: H2D, the kernel sequence and D2H.  Long calls are cut into four time chunks (each a complete
+// engine call: the state carries over on the engine's stream) so that the upload of chunk i+1 and the download of chunk
+// i-1 run on two copy streams beside the kernels of chunk i.  With pinned caller buffers (cpq_host_register) the three
+// overlap; pageable buffers take the plain upload / kernels / download sequence.
 template <typename F>
 int viaStaging(cpq_engine* e, const double* in, double* out, int nSamples, F&& body)
 {
     int T = 0;
     int rc = checkCall(e, in, out, nSamples, &T);
     if (rc != CPQ_OK) return rc;
-    const size_t bytes = (size_t)e->nCh * nSamples * sizeof(double);
     CPQ_HIP(e, hipSetDevice(e->device));
-    CPQ_HIP(e, hipMemcpyAsync(e->stageIn, in, bytes, hipMemcpyHostToDevice, e->stream));
-    rc = body(e->stageIn, e->stageOut, T);
+    constexpr int kChunks = 4;
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory
+        return a.type == hipMemoryTypeHost;
+    };
+    // pageable buffers: the runtime stages every copy and blocks the host, so chunking only adds strided copies
+    // (measured 1157 vs 1230 M samples/s); one upload, one download
+    if (T < 32 || T % kChunks != 0 || !pinned(in) || !pinned(out)) {
+        const size_t bytes = (size_t)e->nCh * nSamples * sizeof(double);
+        CPQ_HIP(e, hipMemcpyAsync(e->stageIn, in, bytes, hipMemcpyHostToDevice, e->stream));
+        rc = body(e->stageIn, e->stageOut, T);
+        if (rc != CPQ_OK) return rc;
+        CPQ_HIP(e, hipMemcpyAsync(out, e->stageOut, bytes, hipMemcpyDeviceToHost, e->stream));
+        CPQ_HIP(e, hipStreamSynchronize(e->stream));
+        return CPQ_OK;
+    }
+    if (!e->copyIn) {
+        CPQ_HIP(e, hipStreamCreateWithFlags(&e->copyIn, hipStreamNonBlocking));
+        CPQ_HIP(e, hipStreamCreateWithFlags(&e->copyOut, hipStreamNonBlocking));
+        for (int i = 0; i < kChunks; ++i) {
+            CPQ_HIP(e, hipEventCreateWithFlags(&e->evIn[i], hipEventDisableTiming));
+            CPQ_HIP(e, hipEventCreateWithFlags(&e->evDone[i], hipEventDisableTiming));
+        }
+    }
+    const int chunkT = T / kChunks;
+    const size_t chunkLen = (size_t)chunkT * e->P;                       // samples per channel and chunk
+    const size_t hostPitch = (size_t)nSamples * sizeof(double), devPitch = chunkLen * sizeof(double);
+    auto download = [&](int i) -> int {
+        CPQ_HIP(e, hipStreamWaitEvent(e->copyOut, e->evDone[i], 0));
+        CPQ_HIP(e, hipMemcpy2DAsync(out + i * chunkLen, hostPitch, e->stageOut + (size_t)i * e->nCh * chunkLen, devPitch, devPitch,
+                                    (size_t)e->nCh, hipMemcpyDeviceToHost, e->copyOut));
+        return CPQ_OK;
+    };
+    for (int i = 0; i < kChunks; ++i) {
+        double* dIn = e->stageIn + (size_t)i * e->nCh * chunkLen;
+        double* dOut = e->stageOut + (size_t)i * e->nCh * chunkLen;
+        CPQ_HIP(e, hipMemcpy2DAsync(dIn, devPitch, in + i * chunkLen, hostPitch, devPitch, (size_t)e->nCh, hipMemcpyHostToDevice,
+                                    e->copyIn));
+        CPQ_HIP(e, hipEventRecord(e->evIn[i], e->copyIn));
+        CPQ_HIP(e, hipStreamWaitEvent(e->stream, e->evIn[i], 0));
+        rc = body(dIn, dOut, chunkT);
+        if (rc != CPQ_OK) { (void)hipDeviceSynchronize(); return rc; }
+        CPQ_HIP(e, hipEventRecord(e->evDone[i], e->stream));
+        if (i > 0) { rc = download(i - 1); if (rc != CPQ_OK) return rc; }
+    }
+    rc = download(kChunks - 1);
     if (rc != CPQ_OK) return rc;
-    CPQ_HIP(e, hipMemcpyAsync(out, e->stageOut, bytes, hipMemcpyDeviceToHost, e->stream));
+    CPQ_HIP(e, hipStreamSynchronize(e->copyOut));
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     return CPQ_OK;
 }
@@ -888,6 +938,11 @@ void cpq_engine_destroy(cpq_engine* e)
         for (auto& ev : s.freeList) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     }
     freeSpecTails(e);
+    if (e->copyIn) {
+        (void)hipStreamDestroy(e->copyIn);
+        (void)hipStreamDestroy(e->copyOut);
+        for (int i = 0; i < 4; ++i) { (void)hipEventDestroy(e->evIn[i]); (void)hipEventDestroy(e->evDone[i]); }
+    }
     if (e->arena) (void)hipFree(e->arena);
     for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
     if (e->agcOn) (void)hipFree(e->agcOn);
@@ -955,6 +1010,18 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
     e->eqProcessed = false;
     for (auto& r : e->gainRamp) { r.current = r.target = r.wanted; r.step = 0.0; r.remaining = 0; }   // setCurrentAndTargetValue (Core.cpp:765)
     return zeroRuntimeState(e, true, true);
+}
+
+int32_t cpq_host_register(void* ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) return CPQ_ERR_INVALID_ARG;
+    return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? CPQ_OK : CPQ_ERR_DEVICE;
+}
+
+int32_t cpq_host_unregister(void* ptr)
+{
+    if (!ptr) return CPQ_ERR_INVALID_ARG;
+    return hipHostUnregister(ptr) == hipSuccess ? CPQ_OK : CPQ_ERR_DEVICE;
 }
 
 int32_t cpq_engine_set_order(cpq_engine* e, int32_t order)

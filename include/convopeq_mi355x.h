@@ -21,6 +21,7 @@
 #ifndef CONVOPEQ_MI355X_H
 #define CONVOPEQ_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -186,6 +187,10 @@ int64_t cpq_engine_arena_bytes(const cpq_engine* e);
  * block_size * max_blocks_per_call. */
 int32_t cpq_engine_prepare(cpq_engine* e, double sample_rate, int32_t max_block);
 int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
+/* Pin / unpin a caller buffer that is passed to the host-pointer entry points (cpq_*_process, cpq_engine_process_block):
+ * those calls pipeline upload, kernels and download over time chunks, which overlaps fully only for pinned memory. */
+int32_t cpq_host_register(void* ptr, size_t bytes);
+int32_t cpq_host_unregister(void* ptr);
 
 /* ---------------------------------------------------------------- convolver */
 /* replaces StereoConvolver::init (src/ConvolverProcessor.h:741-814) -> 2 x

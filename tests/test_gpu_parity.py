@@ -942,3 +942,44 @@ def test_prepare_with_a_new_sample_rate_redesigns_the_filters(amd, oracle):
         fl, fr, _ = O.outfilter_process_stereo(x[2 * s], x[2 * s + 1], q)
         assert rms(z[2 * s] - fl) <= 1e-12 and rms(z[2 * s + 1] - fr) <= 1e-12
     eng.close()
+
+
+def test_host_pointer_path_pipelines_pinned_buffers(amd, oracle):
+    """cpq_engine_process_block on PINNED caller buffers (cpq_host_register) runs upload / kernels / download pipelined
+    over four time chunks; the result must equal the plain single-shot path used for pageable buffers (in place too)."""
+    O = oracle
+    S, T = 3, 64
+    irs = [O.gen_ir(9000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, S, 2 * T * B)
+    po = O.eq_params_bench(0.2)
+
+    def run(pin):
+        eng = amd.BatchedEngine(S, max_ir_len=9000, max_blocks_per_call=T)
+        for s in range(S):
+            eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+        eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+        outs = []
+        for o in range(0, x.shape[1], T * B):
+            buf = np.ascontiguousarray(x[:, o:o + T * B])
+            if pin:
+                assert eng._lib.cpq_host_register(buf.ctypes.data, buf.nbytes) == 0
+            rc = eng._lib.cpq_engine_process_block(eng._h, buf.ctypes.data_as(amd._capi.c_double_p),
+                                                   buf.ctypes.data_as(amd._capi.c_double_p), T * B)      # in place
+            assert rc == 0
+            if pin:
+                assert eng._lib.cpq_host_unregister(buf.ctypes.data) == 0
+            outs.append(buf)
+        eng.close()
+        return np.concatenate(outs, axis=1)
+
+    y_pageable, y_pinned = run(False), run(True)
+    assert np.abs(y_pinned - y_pageable).max() <= 1e-13
+    ref = np.empty_like(x)
+    for s in range(S):
+        w = []
+        for ch in range(2):
+            nuc = O.Nuc()
+            assert nuc.set_impulse(irs[2 * s + ch], B)
+            w.append(nuc.run(x[2 * s + ch], B))
+        ref[2 * s], ref[2 * s + 1], _ = O.eq_process_stereo(w[0], w[1], po)
+    assert rms(y_pinned - ref) <= 1e-13
