@@ -80,6 +80,7 @@ def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
     po = O.eq_params_bench(saturation)
     done = [0] * cores
     stop_at = [0.0]
+    first = {}                            # thread 0's first 64 blocks of output: the parity sample
 
     def work(tid):
         irs = [O.gen_ir(ir_len, stream=tid, channel=ch) for ch in range(2)]
@@ -92,7 +93,9 @@ def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
         while True:
             y = [nucs[ch].run(x[ch], B) for ch in range(2)]
             if use_eq:
-                O.eq_process_stereo(y[0], y[1], po, state=state)
+                y[0], y[1], _ = O.eq_process_stereo(y[0], y[1], po, state=state)
+            if tid == 0 and not first:
+                first["y"] = np.stack([y[0][:64 * B].copy(), y[1][:64 * B].copy()])
             done[tid] += n_blocks * B
             if time.perf_counter() >= stop_at[0]:
                 break
@@ -112,7 +115,26 @@ def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
     return {"value": round(total / dt / 1e6, 3), "unit": "Mega stereo-samples/s", "cores": cores, "kind": "port",
             "sample": f"{cores} stereo streams (one per thread), {ir_len}-tap IR each, blk {B}, "
                       f"{total // cores} samples per stream, conv{'+EQ' if use_eq else ''}, {dt:.1f} s wall; "
-                      "oracle = C restatement of the reference NUC schedule (own radix-2 FFT, not IPP)"}
+                      "oracle = C restatement of the reference NUC schedule (own radix-2 FFT, not IPP)"}, first.get("y")
+
+
+def parity_against(amd, ref, ir_len, use_eq, saturation, device):
+    """fp64 RMS / max-abs difference between the HIP path and the CPU baseline's own output for stream 0 (first 64 blocks
+    from reset, same IR / PCM / EQ preset): the oracle here is the checker, nothing of it is timed or shipped."""
+    n = ref.shape[1]
+    eng = amd.BatchedEngine(1, block_size=B, max_ir_len=ir_len, max_blocks_per_call=n // B, device=device)
+    eng.set_impulse(0, gen_ir(ir_len, 0, 0), gen_ir(ir_len, 0, 1))
+    x = np.stack([gen_pcm(n, 0, 0), gen_pcm(n, 0, 1)])
+    if use_eq:
+        eng.set_eq_params(amd.CPQ_ALL_STREAMS, bench_eq_params(amd, saturation))
+        y = eng.process(x)
+    else:
+        y = eng.conv_process(x)
+    eng.close()
+    d = y - ref
+    return {"rms_err": float(np.sqrt(np.mean(d * d))), "max_abs_err": float(np.abs(d).max()),
+            "signal_rms": float(np.sqrt(np.mean(ref * ref))), "target_rms_err": 1e-12,
+            "sample": f"stream 0, {n} samples per channel from reset, conv{'+EQ' if use_eq else ''}, GPU vs the CPU baseline's output"}
 
 
 def load_pmc_traffic(path, kernel):
@@ -380,7 +402,9 @@ def main():
             "setup_s": round(setup_s, 2),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, use_eq, args.saturation)
+            out["cpu_baseline"], ref = cpu_baseline(L, use_eq, args.saturation)
+            if ref is not None and B == 512 and not (args.exact or args.partition):
+                out["cpu_baseline"]["parity"] = parity_against(amd, ref, L, use_eq, args.saturation, dev_index)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
