@@ -99,14 +99,15 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
 // through LDS: wave w needs FDL row (t0 + 8w - k - 1) at partition step k, which wave w-1 needs eight steps
 // later, so each row is fetched from HBM once, parked in a 9-block LDS ring (72 KB, lane-linear rows: every
 // ds_read/ds_write_b128 is conflict-free) and read by the eight waves at eight different times.  One barrier per
-// 8 steps.  IR rows are read by all eight waves at the same step straight from global memory (one L2/HBM fetch,
-// seven L1 hits).  HBM traffic per launch = every needed FDL row, IR row and output row exactly once.
+// 8 steps (plus one for the IR rows, which are staged the same way: each wave fetches one IR row of the next chunk).
+// HBM traffic per launch = every needed FDL row, IR row and output row exactly once.
 constexpr int kWgWaves = 8;
 constexpr int kWgTile = 8;                       // outputs per lane
 constexpr int kWgRingBlocks = kWgWaves + 1;      // blocks of 8 rows
 static_assert(kWgWaves == kWgTile, "k_fdl_mac_wg fetches block -1 one row per wave: waves per workgroup == rows per block");
 
-template <int PFH>
+// The IR rows of a chunk are staged through LDS one chunk ahead (one row per wave, like the FDL rows): a prefetch distance
+// of 8+ partition steps without holding them in registers (a 4-deep register prefetch measured 7 % slower, 2-deep 35 %).
 __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* __restrict__ X,
                                                                   const double2* __restrict__ H,
                                                                   const int* __restrict__ irSlot,
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
                                                                   int P, int nCols, int nWork)
 {
     __shared__ double2 ring[kWgRingBlocks * kWgTile * 64];
+    __shared__ double2 hst[kWgTile * 64];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     // workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8): give each XCD a contiguous range of logical ids so
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     // Re = M1 - M2, Im = M3 - M1 - M2.  The X-side sums live next to the register window, the H-side sum is formed
     // once per IR row and serves the 8 outputs of the lane.
     double m1[kWgTile], m2[kWgTile], m3[kWgTile], xsum[kWgTile];
-    double2 xw[kWgTile], hn[PFH];
+    double2 xw[kWgTile];
 #pragma unroll
     for (int u = 0; u < kWgTile; ++u) {
         m1[u] = 0.0; m2[u] = 0.0; m3[u] = 0.0;
@@ -157,8 +159,7 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         const double2 xs = xrow(base - kWgTile + w)[bin];
         ring[(slotOf(-1) * kWgTile + w) * 64 + lane] = xs;
     }
-#pragma unroll
-    for (int r = 0; r < PFH; ++r) hn[r] = hrow(r)[bin];
+    hst[w * 64 + lane] = hrow(w)[bin];            // IR rows of chunk 0
     __syncthreads();
 
     const int nChunks = kPad / kWgTile;
@@ -166,13 +167,13 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     for (int j = 0; j < nChunks; ++j) {
         // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
         const double2 xs = xrow(base + kWgTile * (-j - 2) + w)[bin];
+        const double2 hsn = hrow((j + 1) * kWgTile + w)[bin];     // IR row w of the next chunk (zero rows past K)
         const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
         // a wave whose 8 outputs lie beyond T only feeds the ring (partial last group: T mod 64 != 0)
         if (active)
 #pragma unroll
         for (int r = 0; r < kWgTile; ++r) {
-            const int k = j * kWgTile + r;
-            const double2 h = hn[r % PFH];
+            const double2 h = hst[r * 64 + lane];
             const double hs = h.x + h.y;
             // the slot refilled in the previous step (window slot 8-r, first used now): its sum
             if (r > 0) xsum[kWgTile - r] = xw[kWgTile - r].x + xw[kWgTile - r].y;
@@ -194,7 +195,6 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
                 m2[i] = fma(x.y, h.y, m2[i]);
                 m3[i] = fma(xsum[sl], hs, m3[i]);
             }
-            hn[r % PFH] = hrow(k + PFH)[bin];        // IR row k+PFH (zero rows past K), into the slot just consumed
             __builtin_amdgcn_sched_barrier(0);
         }
         // slot of block (-j-2) == slot of block (7-j), last read by wave 7 in chunk j-1: free since the barrier
@@ -202,6 +202,8 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
         ring[(slotOf(-j - 2) * kWgTile + w) * 64 + lane] = xs;
         // slot 0 was refilled in the last step of this chunk
         xsum[0] = xw[0].x + xw[0].y;
+        __syncthreads();                      // every wave is done with this chunk's IR rows
+        hst[w * 64 + lane] = hsn;
         __syncthreads();
     }
 #pragma unroll
@@ -286,7 +288,7 @@ void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double
         const int nGroups = (T + kWgWaves * kWgTile - 1) / (kWgWaves * kWgTile);
         const int nCols = P / 64;
         const int nWork = nCh * nCols * nGroups;
-        hipLaunchKernelGGL((k_fdl_mac_wg<4>), dim3((nWork + 7) / 8 * 8), dim3(64 * kWgWaves), 0, stream, X, H,
+        hipLaunchKernelGGL(k_fdl_mac_wg, dim3((nWork + 7) / 8 * 8), dim3(64 * kWgWaves), 0, stream, X, H,
                            irSlot, Y, kPad, ringSlots - 1, head, T, nGroups, hSlotStride, P, nCols, nWork);
         return;
     }
