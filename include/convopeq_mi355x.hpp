@@ -31,6 +31,19 @@ struct AudioBlockBatch {
     int numSamples;
 };
 
+// RAII pin of a caller-owned PCM buffer (cpq_host_register): the host-pointer entry points pipeline upload, kernels and
+// download only for pinned memory.
+class PinnedRegion {
+public:
+    PinnedRegion(void* ptr, size_t bytes) : ptr_(cpq_host_register(ptr, bytes) == CPQ_OK ? ptr : nullptr) {}
+    ~PinnedRegion() { if (ptr_) (void)cpq_host_unregister(ptr_); }
+    PinnedRegion(const PinnedRegion&) = delete;
+    PinnedRegion& operator=(const PinnedRegion&) = delete;
+    bool ok() const { return ptr_ != nullptr; }
+private:
+    void* ptr_;
+};
+
 class Engine {
 public:
     Engine(int streams, int blockSize, int maxIrLen, int maxBlocksPerCall, double sampleRate = 48000.0,
