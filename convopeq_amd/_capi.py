@@ -74,7 +74,7 @@ class BiquadCoeffs(C.Structure):
 
 
 class ConvProcParams(C.Structure):
-    _fields_ = [("mix", C.c_float), ("bypassed", C.c_int32), ("ir_peak_latency", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("mix", C.c_float), ("bypassed", C.c_int32), ("ir_peak_latency", C.c_int32), ("smoothing_time_sec", C.c_float)]
 
 
 class EngineDesc(C.Structure):

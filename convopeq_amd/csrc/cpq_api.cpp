@@ -172,6 +172,12 @@ struct cpq_engine {
     int convLevel = CPQ_LEVEL_NUC;
     std::vector<cpq_convproc_params> procParams;   // per stream
     bool procBypassed = false, procDryOnly = false;
+    // mix smoothing (LinearRamp mixSmoother, src/ConvolverProcessor.h:945; Runtime.cpp:340-375, 591-607): per stream
+    struct MixRamp { double current = 1.0, target = 1.0, step = 0.0; int remaining = 0, totalSteps = 4800; };
+    std::vector<MixRamp> mixRamp;
+    bool procProcessed = false;         // a processor-level call has run since create / prepare: parameter changes ramp
+    int* mixRampLen = nullptr;             // [streams] device: leading samples of the call with per-sample gains
+    double* mixRampGains = nullptr;     // [streams][tMax * P][2] device (allocated when a ramp first runs)
     double* procGains = nullptr;    // [streams][2] device
     int* procDelay = nullptr;       // [streams] device
     double* dryHist[2] = { nullptr, nullptr };   // [nCh][dryHistCap] device, allocated on first use
@@ -917,7 +923,8 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->eqParamsSet.assign(d->n_streams, 0);
     e->ofModesHost.assign(d->n_streams, cpq_engine::OfModes{ 0, 1, 0, 1 });
     e->ofModesSet.assign(d->n_streams, 0);
-    e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0 });
+    e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0.0f });
+    e->mixRamp.assign(d->n_streams, cpq_engine::MixRamp{});
     e->agcOnHost.assign(d->n_streams, 0);
     e->gainRamp.assign(d->n_streams, cpq_engine::GainRamp{});
     if (hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice) != hipSuccess) {
@@ -952,6 +959,8 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
     if (e->procDelay) (void)hipFree(e->procDelay);
+    if (e->mixRampLen) (void)hipFree(e->mixRampLen);
+    if (e->mixRampGains) (void)hipFree(e->mixRampGains);
     for (double* p : { e->directIr, e->directHist[0], e->directHist[1], e->directOut }) if (p) (void)hipFree(p);
     if (e->directTaps) (void)hipFree(e->directTaps);
     delete e;
@@ -1008,6 +1017,13 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
             }
     }
     e->eqProcessed = false;
+    e->procProcessed = false;
+    for (size_t s = 0; s < e->mixRamp.size(); ++s) {      // mixSmoother.setCurrentAndTargetValue(mix) (Lifecycle.cpp:370-371)
+        auto& r = e->mixRamp[s];
+        r.current = r.target = (double)e->procParams[s].mix;
+        r.step = 0.0;
+        r.remaining = 0;
+    }
     for (auto& r : e->gainRamp) { r.current = r.target = r.wanted; r.step = 0.0; r.remaining = 0; }   // setCurrentAndTargetValue (Core.cpp:765)
     return zeroRuntimeState(e, true, true);
 }
@@ -1340,6 +1356,9 @@ int uploadProcParams(cpq_engine* e)
         const double mix = (double)e->procParams[s].mix;                 // targetMixValue (float widened, :366)
         g[2 * s] = equalPowerSin(mix) * 1.0;                             // * CONVOLUTION_HEADROOM_GAIN
         g[2 * s + 1] = (mix < 0.999) ? equalPowerSin(1.0 - mix) : 0.0;   // needsDrySignal, :375, :676
+        // !needsConvolution (:374, :573-585): the delayed dry signal is copied as it is -- matters when the convolver
+        // still runs because a mix ramp is finishing in the same call
+        if (!(mix > 0.001)) { g[2 * s] = 0.0; g[2 * s + 1] = 1.0; }
         d[s] = procDelayOf(e, s);
         maxDelay = std::max(maxDelay, d[s]);
     }
@@ -1369,7 +1388,49 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!e->procGains) { const int rc = uploadProcParams(e); if (rc != CPQ_OK) return rc; }
     const int n = T * e->P;
-    const bool skipConv = e->procBypassed || e->procDryOnly;
+    // mix smoothing: per callback the reference moves the ramp's target to the current mix (:366-371) and, while the ramp
+    // is running at the START of a callback, mixes that whole callback with per-sample gains equalPowerSin(getNextValue())
+    // (:591-607).  Parameters only change between calls, so the smoothed region is a prefix of the call.
+    const int S = e->desc.n_streams;
+    std::vector<int> mixRampLenHost;
+    std::vector<double> rampHost;
+    bool anyRamp = false;
+    if (!e->procBypassed) {
+        for (int s = 0; s < S; ++s) {
+            auto& r = e->mixRamp[s];
+            const double tgt = (double)e->procParams[s].mix;
+            if (std::fabs(r.target - tgt) > 1.0e-5 && tgt != r.target) {                 // setTargetValue
+                r.target = tgt;
+                const int steps = r.remaining > 0 ? r.remaining : r.totalSteps;
+                r.step = (r.target - r.current) / (double)steps;
+                r.remaining = steps;
+            }
+            if (r.remaining <= 0) continue;
+            if (!anyRamp) { mixRampLenHost.assign(S, 0); rampHost.assign((size_t)S * n * 2, 0.0); anyRamp = true; }
+            const int nSm = (int)std::min<int64_t>(n, ((int64_t)r.remaining + e->B - 1) / e->B * e->B);
+            for (int i = 0; i < nSm; ++i) {
+                if (r.remaining > 0) {                                                  // getNextValue
+                    r.current += r.step;
+                    if (--r.remaining <= 0) r.current = r.target;
+                }
+                rampHost[((size_t)s * n + i) * 2] = equalPowerSin(r.current) * 1.0;
+                rampHost[((size_t)s * n + i) * 2 + 1] = equalPowerSin(1.0 - r.current);
+            }
+            mixRampLenHost[s] = nSm;
+        }
+    }
+    if (anyRamp) {
+        if (!e->mixRampGains) {
+            if (hipMalloc((void**)&e->mixRampLen, sizeof(int) * S) != hipSuccess ||
+                hipMalloc((void**)&e->mixRampGains, sizeof(double) * 2 * (size_t)S * e->tMax * e->P) != hipSuccess)
+                return fail(e, CPQ_ERR_OOM, "mix-ramp buffers could not be allocated");
+        }
+        CPQ_HIP(e, hipMemcpyAsync(e->mixRampLen, mixRampLenHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+        CPQ_HIP(e, hipMemcpyAsync(e->mixRampGains, rampHost.data(), sizeof(double) * rampHost.size(), hipMemcpyHostToDevice, e->stream));
+        CPQ_HIP(e, hipStreamSynchronize(e->stream));         // the host vectors go out of scope
+    }
+    e->procProcessed = true;
+    const bool skipConv = e->procBypassed || (e->procDryOnly && !anyRamp);      // needsConvolution = isSmoothing || mix > 0.001
     const double* dry = dIn;
     if (dIn == dOut && !skipConv) {
         // in place: the convolver overwrites the block, keep a copy for the dry path
@@ -1393,7 +1454,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_convproc_mix(e->stream, wet, dry, dOut, (int64_t)n, e->nCh, n, e->procGains, e->procDelay,
                                  e->dryHist[e->dryHistSel], e->dryHist[e->dryHistSel ^ 1], e->dryHistCap,
-                                 skipConv ? 0 : 1);
+                                 skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, n);
     }
     CPQ_HIP(e, hipGetLastError());
     e->dryHistSel ^= 1;
@@ -1416,7 +1477,18 @@ int32_t cpq_convproc_set_params(cpq_engine* e, int32_t stream, const cpq_convpro
         return fail(e, CPQ_ERR_UNSUPPORTED, "bypass / dry-only freeze the convolver state and must be set for CPQ_ALL_STREAMS");
     const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
     const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
-    for (int s = s0; s < s1; ++s) e->procParams[s] = *p;
+    if (p->smoothing_time_sec != 0.0f && !(p->smoothing_time_sec >= 0.01f && p->smoothing_time_sec <= 0.5f))
+        return fail(e, CPQ_ERR_INVALID_ARG, "smoothing_time_sec must be 0 (default 0.1 s) or in [0.01, 0.5]");
+    for (int s = s0; s < s1; ++s) {
+        e->procParams[s] = *p;
+        auto& r = e->mixRamp[s];
+        const double t = p->smoothing_time_sec != 0.0f ? (double)p->smoothing_time_sec : 0.1;     // SMOOTHING_TIME_DEFAULT_SEC
+        const int steps = (int)(e->sampleRate * t + 0.5);
+        r.totalSteps = steps > 0 ? steps : 1;
+        // before the first processor-level call (the reference's prepareToPlay: setCurrentAndTargetValue, Lifecycle.cpp:370)
+        // the mix applies at once; afterwards it is the ramp's new target
+        if (!e->procProcessed) { r.current = r.target = (double)p->mix; r.step = 0.0; r.remaining = 0; }
+    }
     if (stream == CPQ_ALL_STREAMS) { e->procBypassed = p->bypassed != 0; e->procDryOnly = dryOnly; }
     return uploadProcParams(e);
 }

@@ -73,7 +73,8 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
 // gains: [streams][2] = {wetG, dryG}; histOld/histNew: [nCh][histCap] ping-pong.
 void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dryIn, double* out, int64_t chStride,
                          int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
-                         double* histNew, int histCap, int wetValid);
+                         double* histNew, int histCap, int wetValid, const int* rampLen = nullptr, const double* rampGains = nullptr,
+                         int rampCap = 0);
 
 // EQ AGC (EQProcessor::processAGC): per-callback-block RMS in the reference's accumulation order, then envelopes /
 // gain per block (one thread per stream) and the linear gain ramp with the reference's incremental-add pattern.

@@ -20,11 +20,17 @@ __global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, const d
                                                       const double* __restrict__ gains,
                                                       const int* __restrict__ delay,
                                                       const double* __restrict__ histOld,
-                                                      double* __restrict__ histNew, int histCap, int wetValid)
+                                                      double* __restrict__ histNew, int histCap, int wetValid,
+                                                      const int* __restrict__ rampLen,
+                                                      const double* __restrict__ rampGains, int rampCap)
 {
     const int c = blockIdx.y;
     const int s = c >> 1;
     const double wetG = gains[2 * s], dryG = gains[2 * s + 1];
+    // mix smoothing (:591-607, mixSmoothingSmall :611-632): the first rampLen[s] samples of the call carry per-sample
+    // gains (equalPowerSin of the LinearRamp's values, formed on the host)
+    const int nRamp = rampLen ? rampLen[s] : 0;
+    const double* rg = rampGains + (int64_t)s * rampCap * 2;
     const int d = delay[s];
     const double* w = wet + (int64_t)c * chStride;
     const double* x = dryIn + (int64_t)c * chStride;
@@ -38,7 +44,8 @@ __global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, const d
             double wv = w[n];
             // isFiniteAndAbsBelowNoLibm(x, 1e300): false for NaN / Inf
             wv = (fabs(wv) < 1.0e300) ? wv : 0.0;
-            o[n] = (wv * wetG) + (dry * dryG);
+            if (n < nRamp) o[n] = (wv * rg[2 * n]) + (dry * rg[2 * n + 1]);
+            else           o[n] = (wv * wetG) + (dry * dryG);
         } else {
             o[n] = dry;           // dry-only fast path (:573-585) and bypass (:123-186): plain copy of the delayed input
         }
@@ -352,13 +359,14 @@ void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const
 
 void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dryIn, double* out, int64_t chStride,
                          int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
-                         double* histNew, int histCap, int wetValid)
+                         double* histNew, int histCap, int wetValid, const int* rampLen, const double* rampGains,
+                         int rampCap)
 {
     const int work = nSamples > histCap ? nSamples : histCap;
     int bx = (work + 255) / 256;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(k_convproc_mix, dim3(bx, nCh), dim3(256), 0, stream, wet, dryIn, out, chStride, nSamples, gains,
-                       delay, histOld, histNew, histCap, wetValid);
+                       delay, histOld, histNew, histCap, wetValid, rampLen, rampGains, rampCap);
 }
 
 static dim3 rowsGrid(int n, int nCh) { int bx = (n + 255) / 256; if (bx > 64) bx = 64; if (bx < 1) bx = 1; return dim3(bx, nCh); }

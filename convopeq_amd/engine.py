@@ -120,8 +120,8 @@ class BatchedEngine:
     def set_eq_params(self, stream, params):
         self._ck(self._lib.cpq_eq_set_params(self._h, stream, C.byref(params)))
 
-    def set_convproc_params(self, stream, mix=1.0, bypassed=False, ir_peak_latency=0):
-        p = K.ConvProcParams(mix, int(bypassed), ir_peak_latency, 0)
+    def set_convproc_params(self, stream, mix=1.0, bypassed=False, ir_peak_latency=0, smoothing_time_sec=0.0):
+        p = K.ConvProcParams(mix, int(bypassed), ir_peak_latency, smoothing_time_sec)
         self._ck(self._lib.cpq_convproc_set_params(self._h, stream, C.byref(p)))
 
     def convproc_delay(self, stream):

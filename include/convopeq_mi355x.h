@@ -233,14 +233,16 @@ int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan);
  *   dryG = mix < 0.999 ? equalPowerSin(1 - mix) : 0, equalPowerSin = the 9th-order Taylor form (:26-31),
  *   so mix = 1 scales the wet signal by 1.0000035... (:373-375, :675-676, :611-657);
  *   mix <= 0.001: dry only, the convolver is not run (:573-585); bypassed: pure delay, convolver not run (:123-186).
- * Parameter changes apply immediately: the reference's mix smoothing ramp (:591-607) and latency crossfade
- * (:393-547) are transition effects of a live stream and are not reproduced.
+ * A mix change after the first processor-level call is smoothed like the reference's mixSmoother (LinearRamp over
+ * smoothing_time_sec, per-sample gains equalPowerSin(mix_i) / equalPowerSin(1 - mix_i) for every callback that starts
+ * while the ramp runs, :340-375, :591-607); before it (and after cpq_engine_prepare) the mix applies at once, as
+ * prepareToPlay sets it.  The latency crossfade (:393-547) of a live IR swap is not reproduced.
  * mix / ir_peak_latency may differ per stream; bypassed and mix <= 0.001 must be set for CPQ_ALL_STREAMS. */
 typedef struct {
     float   mix;                 /* 0..1, default 1 (src/ConvolverProcessor.h:950) */
     int32_t bypassed;
     int32_t ir_peak_latency;     /* StereoConvolver::irLatency (peak delay of the loaded IR), samples */
-    int32_t reserved;
+    float   smoothing_time_sec;  /* mix ramp length; 0 = default 0.1 s (SMOOTHING_TIME_DEFAULT_SEC), else 0.01 .. 0.5 */
 } cpq_convproc_params;
 int32_t cpq_convproc_set_params(cpq_engine* e, int32_t stream, const cpq_convproc_params* p);
 int32_t cpq_convproc_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);

@@ -292,6 +292,57 @@ def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0):
     return (wet * wet_g) + (dry * dry_g)
 
 
+def convproc_mix_schedule(ir, x, block, mix_per_callback, sr=48000.0, smoothing_time=0.1, ir_peak_latency=0,
+                          initial_mix=None):
+    """ConvolverProcessor::process for ONE channel with a mix value per callback (block): the LinearRamp mixSmoother
+    (src/DspNumericPolicy.h:319-421; 100 ms default) moves to a new mix over smoothing_time, and every callback that
+    STARTS while it runs is mixed with per-sample gains equalPowerSin(mix_i) / equalPowerSin(1 - mix_i)
+    (src/convolver/ConvolverProcessor.Runtime.cpp:366-375, 591-607, 727-735); other callbacks use the steady gains, or
+    copy the delayed dry signal when mix <= 0.001 (:573-585).  The convolver is run on every callback here (callers keep
+    mix > 0.001 until a final dry-only stretch whose wet signal is not used)."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(x)
+    assert n == block * len(mix_per_callback)
+    delay = min(block, 524288) + min(max(0, ir_peak_latency), 2097152)
+    dry = np.zeros(n)
+    if delay < n:
+        dry[delay:] = x[:n - delay]
+    nuc = Nuc()
+    assert nuc.set_impulse(ir, block)
+    wet = nuc.run(x, block)
+    nuc.close()
+    wet = np.where(~(np.abs(wet) < 1.0e300), 0.0, wet)
+    total = max(1, int(sr * smoothing_time + 0.5))
+    m0 = float(np.float32(mix_per_callback[0] if initial_mix is None else initial_mix))
+    cur, tgt, step, rem = m0, m0, 0.0, 0
+    out = np.empty(n)
+    eps = L.orc_equal_power_sin
+    for cb, mix in enumerate(mix_per_callback):
+        mixd = float(np.float32(mix))
+        if abs(tgt - mixd) > 1.0e-5 and mixd != tgt:          # setTargetValue
+            tgt = mixd
+            steps = rem if rem > 0 else total
+            step = (tgt - cur) / float(steps)
+            rem = steps
+        lo, hi = cb * block, (cb + 1) * block
+        if rem > 0:                                           # isSmoothing at the start of the callback
+            for i in range(lo, hi):
+                if rem > 0:
+                    cur += step
+                    rem -= 1
+                    if rem <= 0:
+                        cur = tgt
+                out[i] = (wet[i] * (eps(cur) * 1.0)) + (dry[i] * eps(1.0 - cur))
+        elif not (mixd > 0.001):
+            out[lo:hi] = dry[lo:hi]
+        else:
+            wg = eps(mixd) * 1.0
+            dg = eps(1.0 - mixd) if mixd < 0.999 else 0.0
+            out[lo:hi] = (wet[lo:hi] * wg) + (dry[lo:hi] * dg)
+    return out
+
+
 def outfilter_design(conv_is_last, hc_mode=1, lc_mode=0, lp_mode=1, sr=48000.0):
     out = (Biquad * 3)()
     lib().orc_outfilter_design(int(conv_is_last), hc_mode, lc_mode, lp_mode, sr, out)

@@ -983,3 +983,49 @@ def test_host_pointer_path_pipelines_pinned_buffers(amd, oracle):
             w.append(nuc.run(x[2 * s + ch], B))
         ref[2 * s], ref[2 * s + 1], _ = O.eq_process_stereo(w[0], w[1], po)
     assert rms(y_pinned - ref) <= 1e-13
+
+
+def test_processor_level_mix_ramp(amd, oracle):
+    """SURVEY N1 transitions: a mix change after processing has started is smoothed by the LinearRamp mixSmoother
+    (4800 samples at 48 kHz): per-sample equal-power gains for every callback that starts while it runs, a retarget in
+    the middle of a ramp keeps the remaining step count, a different ramp time on the second stream, and a final change
+    to dry-only lets the convolver run until the ramp has finished and then copies the delayed dry signal."""
+    O = oracle
+    S, T = 2, 6
+    irs = [O.gen_ir(6000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    calls = 12
+    x = make_inputs(O, S, calls * T * B)
+    # mix per call and stream (a call = 6 callbacks); stream 1 uses a 30 ms ramp
+    sched = [[1.0, 1.0, 0.35, 0.8, 0.8, 0.8, 0.2, 0.2, 0.9, 0.9, 0.9, 0.9],
+             [0.5, 0.5, 0.5, 0.95, 0.95, 0.1, 0.1, 0.1, 0.1, 0.6, 0.6, 0.6]]
+    times = [0.0, 0.03]
+    eng = amd.BatchedEngine(S, max_ir_len=6000, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    outs = []
+    for k in range(calls):
+        for s in range(S):
+            eng.set_convproc_params(s, mix=sched[s][k], smoothing_time_sec=times[s])
+        outs.append(eng.convproc_process(x[:, k * T * B:(k + 1) * T * B]))
+    y = np.concatenate(outs, axis=1)
+    for s in range(S):
+        per_cb = [m for m in sched[s] for _ in range(T)]
+        for ch in range(2):
+            ref = O.convproc_mix_schedule(irs[2 * s + ch], x[2 * s + ch], B, per_cb, smoothing_time=times[s] or 0.1)
+            err = np.abs(y[2 * s + ch] - ref).max()
+            assert err <= 1e-13, (s, ch, err)
+    eng.close()
+    # all streams to dry-only: the ramp still needs the wet signal, afterwards the output is the delayed input
+    eng = amd.BatchedEngine(1, max_ir_len=6000, max_blocks_per_call=T)
+    eng.set_impulse(0, irs[0], irs[1])
+    mixes = [0.7, 0.7, 0.0, 0.0, 0.0, 0.0]
+    outs = []
+    for k, m in enumerate(mixes):
+        eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=m)
+        outs.append(eng.convproc_process(x[:2, k * T * B:(k + 1) * T * B]))
+    y = np.concatenate(outs, axis=1)
+    per_cb = [m for m in mixes for _ in range(T)]
+    ref = O.convproc_mix_schedule(irs[0], x[0, :len(per_cb) * B], B, per_cb)
+    assert np.abs(y[0] - ref).max() <= 1e-13
+    assert np.array_equal(y[0, 5 * T * B:], ref[5 * T * B:])           # plain copy of the delayed dry signal
+    eng.close()
