@@ -77,6 +77,19 @@ class ConvProcParams(C.Structure):
     _fields_ = [("mix", C.c_float), ("bypassed", C.c_int32), ("ir_peak_latency", C.c_int32), ("smoothing_time_sec", C.c_float)]
 
 
+class IrBuffer(C.Structure):
+    _fields_ = [("n_channels", C.c_int32), ("n_samples", C.c_int32), ("sample_rate", C.c_double), ("data", c_double_p)]
+
+
+class IrScale(C.Structure):
+    _fields_ = [("scale_factor", C.c_double), ("has_scale_factor", C.c_int32), ("additional_attenuation_db", C.c_float),
+                ("peak_value", C.c_double), ("rms_value", C.c_double), ("frequency_peak_gain", C.c_double)]
+
+
+class IrPrepared(C.Structure):
+    _fields_ = [("ir", IrBuffer), ("scale", IrScale), ("ir_peak_latency", C.c_int32), ("reserved", C.c_int32)]
+
+
 class EngineDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_streams", C.c_int32),
                 ("block_size", C.c_int32), ("max_ir_len", C.c_int32), ("max_blocks_per_call", C.c_int32),
@@ -128,6 +141,13 @@ SYMBOLS = {
     "cpq_engine_enable_output_filter": (C.c_int32, [_E, C.c_int32]),
     "cpq_engine_process_block": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_engine_process_block_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_ir_load_wav": (C.c_int32, [C.c_char_p, C.POINTER(IrBuffer)]),
+    "cpq_ir_buffer_free": (None, [C.POINTER(IrBuffer)]),
+    "cpq_ir_prepare": (C.c_int32, [C.POINTER(IrBuffer), C.c_double, C.c_float, C.POINTER(IrBuffer), C.c_double, C.POINTER(IrPrepared)]),
+    "cpq_ir_prepared_free": (None, [C.POINTER(IrPrepared)]),
+    "cpq_ir_compute_scale_factor": (C.c_int32, [C.POINTER(c_double_p), C.c_int32, C.c_int32, C.POINTER(c_double_p), C.c_int32, C.c_int32, C.c_double, C.POINTER(IrScale)]),
+    "cpq_ir_estimate_max_frequency_response_gain": (C.c_double, [C.POINTER(c_double_p), C.c_int32, C.c_int32]),
+    "cpq_ir_estimate_peak_latency": (C.c_int32, [C.POINTER(c_double_p), C.c_int32, C.c_int32]),
     "cpq_profile_enable": (C.c_int32, [_E, C.c_int32]),
     "cpq_profile_reset": (C.c_int32, [_E]),
     "cpq_profile_read": (C.c_int32, [_E, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -8,6 +8,7 @@
 All numerical work happens in libconvopeq_mi355x.so on the GPU; numpy is only the host buffer type.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -65,6 +66,78 @@ def eq_params_default():
     p = K.EqParams()
     K.load().cpq_eq_params_default(C.byref(p))
     return p
+
+
+def _planes(a):
+    a = np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64)
+    ptrs = (K.c_double_p * a.shape[0])(*[a[c].ctypes.data_as(K.c_double_p) for c in range(a.shape[0])])
+    return a, ptrs
+
+
+def _ir_buffer(a, rate):
+    a = np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64)
+    return a, K.IrBuffer(a.shape[0], a.shape[1], float(rate), a.ctypes.data_as(K.c_double_p))
+
+
+def _scale_dict(s):
+    return {"scale_factor": s.scale_factor, "has_scale_factor": bool(s.has_scale_factor),
+            "additional_attenuation_db": s.additional_attenuation_db, "peak_value": s.peak_value,
+            "rms_value": s.rms_value, "frequency_peak_gain": s.frequency_peak_gain}
+
+
+def ir_load_wav(path):
+    """cpq_ir_load_wav: (planes [channels][samples] float64, sample rate)."""
+    b = K.IrBuffer()
+    rc = K.load().cpq_ir_load_wav(os.fsencode(path), C.byref(b))
+    if rc != 0:
+        raise CpqError(rc, f"cpq_ir_load_wav({path})")
+    try:
+        out = np.ctypeslib.as_array(b.data, shape=(b.n_channels, b.n_samples)).copy()
+        return out, b.sample_rate
+    finally:
+        K.load().cpq_ir_buffer_free(C.byref(b))
+
+
+def ir_prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=None, current_scale=1.0):
+    """cpq_ir_prepare: dict(ir=[channels][target] float64, scale=..., ir_peak_latency=...)."""
+    keep, b = _ir_buffer(ir, ir_rate)
+    cur = None
+    if current_ir is not None:
+        keep2, cur = _ir_buffer(current_ir, sample_rate)
+    out = K.IrPrepared()
+    rc = K.load().cpq_ir_prepare(C.byref(b), sample_rate, target_ir_length_sec, C.byref(cur) if cur is not None else None,
+                                 current_scale, C.byref(out))
+    if rc != 0:
+        raise CpqError(rc, "cpq_ir_prepare")
+    try:
+        data = np.ctypeslib.as_array(out.ir.data, shape=(out.ir.n_channels, out.ir.n_samples)).copy()
+        return {"ir": data, "sample_rate": out.ir.sample_rate, "scale": _scale_dict(out.scale),
+                "ir_peak_latency": out.ir_peak_latency}
+    finally:
+        K.load().cpq_ir_prepared_free(C.byref(out))
+
+
+def ir_compute_scale_factor(ir, current_ir=None, current_scale=1.0):
+    a, pa = _planes(ir)
+    cur_ptrs, cc, cn = None, 0, 0
+    if current_ir is not None:
+        c, cur_ptrs = _planes(current_ir)
+        cc, cn = c.shape
+    out = K.IrScale()
+    rc = K.load().cpq_ir_compute_scale_factor(pa, a.shape[0], a.shape[1], cur_ptrs, cc, cn, current_scale, C.byref(out))
+    if rc != 0:
+        raise CpqError(rc, "cpq_ir_compute_scale_factor")
+    return _scale_dict(out)
+
+
+def ir_estimate_max_frequency_response_gain(ir):
+    a, pa = _planes(ir)
+    return K.load().cpq_ir_estimate_max_frequency_response_gain(pa, a.shape[0], a.shape[1])
+
+
+def ir_estimate_peak_latency(ir):
+    a, pa = _planes(ir)
+    return K.load().cpq_ir_estimate_peak_latency(pa, a.shape[0], a.shape[1])
 
 
 class BatchedEngine:

@@ -297,6 +297,61 @@ int32_t cpq_engine_enable_output_filter(cpq_engine* e, int32_t on);
 int32_t cpq_engine_process_block(cpq_engine* e, const double* in, double* out, int32_t n_samples);
 int32_t cpq_engine_process_block_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
 
+/* ---------------------------------------------------------------- IR ingest (host only, no GPU needed) */
+/* Everything between an IR file and cpq_engine_set_impulse(): SURVEY.md N3.  One-off loader-thread work in the
+ * reference; plain host code here. */
+typedef struct {
+    int32_t n_channels;
+    int32_t n_samples;
+    double  sample_rate;
+    double* data;                    /* planar [channel][sample], owned by the library: cpq_ir_buffer_free() */
+} cpq_ir_buffer;
+
+/* IRConverter::ScaleFactorResult (src/IRConverter.h) plus the stage-2 analysis values it is derived from */
+typedef struct {
+    double  scale_factor;
+    int32_t has_scale_factor;
+    float   additional_attenuation_db;
+    double  peak_value;              /* of the unscaled IR */
+    double  rms_value;
+    double  frequency_peak_gain;     /* IRAnalyzer::estimateMaxFrequencyResponseGain of the unscaled IR */
+} cpq_ir_scale;
+
+typedef struct {
+    cpq_ir_buffer ir;                /* conditioned IR of the target length (stepTrimmed) */
+    cpq_ir_scale  scale;             /* scale.scale_factor is what StereoConvolver::init / SetImpulse receive as `scale` */
+    int32_t       ir_peak_latency;   /* estimatePeakLatencySamples: the processor-level dry delay on top of the block */
+    int32_t       reserved;
+} cpq_ir_prepared;
+
+/* LoaderThread::doLoadStep for a WAV file (src/convolver/ConvolverProcessor.LoaderThread.cpp:431-486): RIFF / RF64,
+ * PCM 8 / 16 / 24 / 32 bit and IEEE float 32 (plain or WAVE_FORMAT_EXTENSIBLE) -> float as JUCE's reader produces it
+ * -> double, NaN and |v| < 1e-20 to 0, clamped to [-1, 1] (src/InputBitDepthTransform.h:31-100).
+ * Frames a short file does not hold read as zero (as the reference's reader does); a data chunk claiming more than
+ * twice the file size + 1 MiB is refused as corrupted instead.
+ * CPQ_ERR_INVALID_ARG: missing file / no frames; CPQ_ERR_UNSUPPORTED: not a WAV the reference's reader would accept. */
+int32_t cpq_ir_load_wav(const char* path, cpq_ir_buffer* out);
+void    cpq_ir_buffer_free(cpq_ir_buffer* b);
+
+/* doTrimStep + doTransformStep in PhaseMode::AsIs (LoaderThread.cpp:490-641, 696-709): trailing-silence trim, 1 Hz DC
+ * blocker, asymmetric Tukey window about the peak, zero-padded / cut to int(rate * target_ir_length_sec) samples
+ * (IR_LENGTH 0.5..3 s, default 1 s; cap 2^21) with a linear fade-out, computeScaleFactor against the IR playing now
+ * (current_ir may be NULL), peak latency.  An IR whose rate differs from sample_rate needs the reference's third-party
+ * resampler (r8brain): CPQ_ERR_UNSUPPORTED. */
+int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float target_ir_length_sec,
+                       const cpq_ir_buffer* current_ir, double current_scale, cpq_ir_prepared* out);
+void    cpq_ir_prepared_free(cpq_ir_prepared* p);
+
+/* IRConverter::computeScaleFactor(ir, currentIr, currentScale) (src/IRConverter.cpp:175-196): energy normalisation to
+ * -6 dB, then peak (0.5) / RMS (0.25) / frequency-response (+3 dB) clamps and the 4x jump protection. */
+int32_t cpq_ir_compute_scale_factor(const double* const* ir, int32_t n_channels, int32_t n_samples,
+                                    const double* const* current_ir, int32_t current_channels, int32_t current_samples,
+                                    double current_scale, cpq_ir_scale* out);
+/* IRAnalyzer::estimateMaxFrequencyResponseGain (src/IRAnalyzer.cpp:63-155) */
+double  cpq_ir_estimate_max_frequency_response_gain(const double* const* ir, int32_t n_channels, int32_t n_samples);
+/* LoaderThread::estimatePeakLatencySamples (LoaderThread.cpp:149-209) */
+int32_t cpq_ir_estimate_peak_latency(const double* const* ir, int32_t n_channels, int32_t n_samples);
+
 /* ---------------------------------------------------------------- profiling */
 /* Per-kernel HIP-event timing on the engine's stream (counterpart of the reference's CONV_TIME /
  * EQ_TIME diagnostics, src/convolver/ConvolverProcessor.Runtime.cpp:679-721). */

@@ -266,7 +266,7 @@ def eq_process_stereo(xl, xr, params, sr=48000.0, block=512, state=None):
     return yl, yr, state
 
 
-def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0):
+def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0, scale=1.0, spec=None):
     """Steady-state restatement of ConvolverProcessor::process for ONE channel over the whole signal x
     (src/convolver/ConvolverProcessor.Runtime.cpp:209-810): dry delay line of algorithmLatency + irPeakLatency,
     wet sanitise (NaN / Inf / |x| >= 1e300 -> 0, :50-60), out = wet*wetG + dry*dryG with the Taylor
@@ -282,7 +282,7 @@ def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0):
     if bypassed or not (mixd > 0.001):
         return dry
     nuc = Nuc()
-    assert nuc.set_impulse(ir, block)
+    assert nuc.set_impulse(ir, block, scale=scale, spec=spec)
     wet = nuc.run(x, block)
     nuc.close()
     bad = ~(np.abs(wet) < 1.0e300)

@@ -3,6 +3,8 @@
 Tolerances: north_star asks <= 1e-12 RMS per sample in fp64 versus the reference CPU path; the tests hold
 the convolver to 1e-13 RMS (absolute, signal RMS ~0.1-1) and the SVF cascade to bit equality or 1e-15.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1028,4 +1030,32 @@ def test_processor_level_mix_ramp(amd, oracle):
     ref = O.convproc_mix_schedule(irs[0], x[0, :len(per_cb) * B], B, per_cb)
     assert np.abs(y[0] - ref).max() <= 1e-13
     assert np.array_equal(y[0, 5 * T * B:], ref[5 * T * B:])           # plain copy of the delayed dry signal
+    eng.close()
+
+
+def test_ingested_ir_file_end_to_end(amd, oracle):
+    """SURVEY N3 + N1: the reference's own sample IR file through cpq_ir_load_wav -> cpq_ir_prepare (DC blocker, window,
+    1 s target length, scale factor, peak latency) -> set_impulse(scale, FilterSpec) -> processor-level process, against
+    the oracle run on the same prepared IR (the ingest itself is compared with its numpy restatement in
+    tests/test_ir_ingest_cpu.py)."""
+    O = oracle
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "impulse_room_correction_hpf_lpf.wav")
+    ir, rate = amd.ir_load_wav(path)
+    prep = amd.ir_prepare(ir, rate, 48000.0, 1.0)
+    h, sf, lat = prep["ir"], prep["scale"]["scale_factor"], prep["ir_peak_latency"]
+    assert h.shape == (2, 48000) and 0.0 < sf < 10.0 and 0 <= lat < 48000
+    S, T = 2, 8
+    n = 6 * T * B
+    x = make_inputs(O, S, n)
+    eng = amd.BatchedEngine(S, max_ir_len=48000, max_blocks_per_call=T)
+    spec_a, spec_o = amd.FilterSpec.defaults(), O.FilterSpec.defaults(applySpectrumFilter=1)
+    eng.set_impulse(amd.CPQ_ALL_STREAMS, h[0], h[1], scale=sf, spec=spec_a)
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=0.8, ir_peak_latency=lat)
+    assert eng.convproc_delay(0) == B + lat
+    y = np.concatenate([eng.convproc_process(x[:, k * T * B:(k + 1) * T * B]) for k in range(6)], axis=1)
+    worst = 0.0
+    for c in range(2 * S):
+        ref = O.convproc_steady(h[c % 2], x[c], B, mix=0.8, ir_peak_latency=lat, scale=sf, spec=spec_o)
+        worst = max(worst, rms(y[c] - ref) / max(rms(ref), 1e-30))
+    assert worst <= 1e-12, worst
     eng.close()

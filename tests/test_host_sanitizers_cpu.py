@@ -29,3 +29,20 @@ def test_host_design_and_oracle_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "0 failed checks" in r.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_ir_ingest_under_asan_ubsan(tmp_path):
+    """the WAV reader against truncated / corrupted / random files and the conditioning + analysis code on degenerate
+    buffers, with AddressSanitizer, LeakSanitizer and UBSan."""
+    exe = tmp_path / "ir_ingest_sanitize"
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    csrc = os.path.join(ROOT, "convopeq_amd", "csrc")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++20", "-ffp-contract=off", *san, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(HERE, "sanitize", "ir_ingest_sanitize.cpp"), os.path.join(csrc, "ir_ingest.cpp"),
+                    "-lm", "-o", str(exe)], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert " 0 failed checks" in r.stdout
