@@ -131,6 +131,7 @@ SYMBOLS = {
     "cpq_eq_set_params": (C.c_int32, [_E, C.c_int32, C.POINTER(EqParams)]),
     "cpq_eq_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_eq_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
+    "cpq_eq_set_bypass": (C.c_int32, [_E, C.c_int32, C.c_int32]),
     "cpq_eq_set_mode": (C.c_int32, [_E, C.c_int32]),
     "cpq_eq_reset": (C.c_int32, [_E]),
     "cpq_outfilter_design": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(BiquadCoeffs)]),
@@ -139,6 +140,8 @@ SYMBOLS = {
     "cpq_outfilter_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
     "cpq_outfilter_reset": (C.c_int32, [_E]),
     "cpq_engine_enable_output_filter": (C.c_int32, [_E, C.c_int32]),
+    "cpq_engine_set_gains": (C.c_int32, [_E, C.c_int32, C.c_double, C.c_double]),
+    "cpq_engine_set_conv_bypass": (C.c_int32, [_E, C.c_int32]),
     "cpq_engine_process_block": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_engine_process_block_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
     "cpq_ir_load_wav": (C.c_int32, [C.c_char_p, C.POINTER(IrBuffer)]),

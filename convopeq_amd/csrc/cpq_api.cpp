@@ -139,6 +139,29 @@ struct cpq_engine {
     struct GainRamp { double current = 1.0, target = 1.0, step = 0.0; int remaining = 0; double wanted = 1.0; bool devUnity = false; };
     std::vector<GainRamp> gainRamp;     // per stream
     bool eqProcessed = false;           // a process call has consumed EQ parameters since prepare
+    // EQ bypass per stream (EQProcessor::setBypassFromRT + the fade of the basic process(block),
+    // src/eqprocessor/EQProcessor.Processing.cpp:499-526, 977-1015): LinearRamp bypassFadeGain over 5 ms
+    struct EqBypass {
+        bool requested = false, effective = false;
+        double current = 1.0, target = 1.0, step = 0.0;
+        int remaining = 0;
+        int mode = 0;                   // what the device tables of the stream hold now: 0 parameters as set,
+    };                                  // 1 band nodes of the basic path, 2 pass-through
+    std::vector<EqBypass> eqBypass;
+    bool anyEqBypass = false;           // some stream is not in the plain "never bypassed" state
+    // DSPCore block routing (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:384-470)
+    std::vector<double> trimHost, makeupHost;   // per stream: convolverInputTrimGain (EQ -> conv order), outputMakeupGain
+    double* trimDev = nullptr;
+    double* makeupDev = nullptr;
+    bool anyTrim = false, anyMakeup = false;
+    bool convBypassed = false;          // state.convBypassed: the convolver stage is not called
+    std::vector<char> ofPass;           // per stream: output filter tables hold pass-through flags (nothing active)
+    double* eqDry = nullptr;            // [nCh][tMax * P] dry copy for the bypass cross-fade (allocated on first use)
+    int* blendOn = nullptr;             // [streams]
+    int* blendLen = nullptr;            // [streams] samples with their own fade gain
+    double* blendEnd = nullptr;         // [streams] gain after those
+    double* blendGains = nullptr;       // [streams][fade steps]
+    int blendCap = 0;
     int* rampOn = nullptr;              // [streams] device
     double* rampGains = nullptr;        // [streams][callbacks][2] device
 
@@ -505,32 +528,128 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
     return CPQ_OK;
 }
 
-int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int T, bool tp, int idTp, int idSeq,
+int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t stride, int n, bool tp, int idTp, int idSeq,
                    const double* coef, const int* flags, const double* satGain, double* state, const double* tables,
                    bool streamPairs = false)
 {
-    const int n = T * e->P;
     const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
     if (nTp > 0) {
         ProfScope p(e, idTp);
-        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, (int64_t)n, e->nCh, nTp, coef, flags, satGain, state, tables);
+        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables);
     }
     if (n > nTp) {
         ProfScope p(e, idSeq);
-        cpq::launch_svf_cascade(e->stream, dIn + nTp, dOut + nTp, (int64_t)n, e->nCh, n - nTp, coef, flags, satGain,
+        cpq::launch_svf_cascade(e->stream, dIn + nTp, dOut + nTp, stride, e->nCh, n - nTp, coef, flags, satGain,
                                 state, streamPairs);
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
 }
 
-int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
+// prepareToPlay / reset: bypassFadeGain.setCurrentAndTargetValue(requested ? 0 : 1), the effective flag follows the
+// request (src/eqprocessor/EQProcessor.Core.cpp:596, 656, 802)
+void syncEqBypass(cpq_engine* e)
 {
-    if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
+    e->anyEqBypass = false;
+    for (auto& b : e->eqBypass) {
+        b.effective = b.requested;
+        b.current = b.target = b.requested ? 0.0 : 1.0;
+        b.step = 0.0;
+        b.remaining = 0;
+        e->anyEqBypass = e->anyEqBypass || b.requested || b.mode != 0;
+    }
+}
+
+// Device tables of one stream's EQ as the reference would run it: createCoeffCache (bandActive = enabled && sr > 0,
+// src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90) or, for basicPath, the band nodes of the basic process(block)
+// (inactive for non-LP/HP bands within 0.01 dB of flat: createBandNode, Coefficients.cpp:48-53).  An active Mid/Side
+// band sends the whole call through the basic path (Processing.cpp:1036-1044).
+struct EqDesign {
+    double coef[2][kBands][6];
+    int flags[2][kBands];
+    std::vector<double> tp;
+    double satGain[2];
+    bool tpSafe = true, midSide = false;
+};
+
+void designEqStream(const cpq_engine* e, const cpq_eq_params& p, bool basicPath, EqDesign& d)
+{
+    d.tp.assign((size_t)kBands * cpq::kSvfTpTableDoubles, 0.0);
+    d.tpSafe = true;
+    d.midSide = false;
+    for (int b = 0; b < kBands; ++b)
+        d.midSide = d.midSide || (p.bands[b].enabled && e->sampleRate > 0.0 && p.bands[b].channel_mode >= 3);
+    const bool nodes = basicPath || d.midSide;
+    for (int b = 0; b < kBands; ++b) {
+        const cpq_eq_band& bp = p.bands[b];
+        bool active = bp.enabled && e->sampleRate > 0.0;
+        if (nodes && bp.type != 3 && bp.type != 4 && std::fabs(bp.gain) < 0.01f) active = false;
+        cpq_svf_coeffs c{ 0, 0, 0, 0, 0, 1, 0, 0 };
+        if (active) {
+            cpq::designSvf(bp.type, bp.frequency, bp.gain, bp.q, e->sampleRate, &c);
+            d.tpSafe = cpq::buildSvfTpTables(c, &d.tp[(size_t)b * cpq::kSvfTpTableDoubles]) && d.tpSafe;
+        }
+        for (int ch = 0; ch < 2; ++ch) {
+            const double v[6] = { c.a1, c.a2, c.a3, c.m0, c.m1, c.m2 };
+            std::memcpy(d.coef[ch][b], v, sizeof(v));
+            // Stereo -> both channels through the packed SSE2+FMA kernel; Left/Right -> one channel, scalar kernel
+            // Mid/Side -> both channel lanes run the scalar kernel on the encoded component (flag bit 4 / 5)
+            const bool on = active && (bp.channel_mode == 0 || bp.channel_mode == 1 + ch || bp.channel_mode >= 3);
+            d.flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0) | (p.filter_structure == 1 ? 8 : 0) |
+                             (bp.channel_mode == 3 ? 16 : 0) | (bp.channel_mode == 4 ? 32 : 0);
+        }
+    }
+    // with AGC the total-gain ramp is replaced by processAGC (Processing.cpp:1256-1259): unity gain in the cascade kernel
+    d.satGain[0] = (double)p.nonlinear_saturation;
+    d.satGain[1] = p.agc_enabled ? 1.0 : cpq::totalGainLinear(p.total_gain_db);
+    if (p.filter_structure == 1 || d.midSide) d.tpSafe = false;   // parallel structure and Mid/Side bands: lane-skewed kernel
+}
+
+// Switches what the device tables of one stream hold (on the engine's stream, in order with the kernels around it):
+// 0 = the parameters as set, 1 = the basic path's band nodes, 2 = pass-through (EQ bypass in effect: nothing runs,
+// not even the total gain, the AGC or the gain ramp).
+int setEqStreamMode(cpq_engine* e, int s, int mode)
+{
+    auto& bp = e->eqBypass[s];
+    if (bp.mode == mode) return CPQ_OK;
+    const size_t c0 = (size_t)s * 2;
+    if (mode == 2) {
+        int zeros[2 * kBands] = {};
+        const double sg[4] = { 0.0, 1.0, 0.0, 1.0 };
+        CPQ_HIP(e, hipMemcpyAsync(e->svfFlags + c0 * kBands, zeros, sizeof(zeros), hipMemcpyHostToDevice, e->stream));
+        CPQ_HIP(e, hipMemcpyAsync(e->svfSatGain + c0 * 2, sg, sizeof(sg), hipMemcpyHostToDevice, e->stream));
+        e->eqTpSafe[s] = 1;
+        e->eqMidSide[s] = 0;
+        e->gainRamp[s].devUnity = true;
+    } else {
+        if (!e->eqParamsSet[s]) { bp.mode = mode; return CPQ_OK; }      // no parameters: every band inactive anyway
+        EqDesign d;
+        designEqStream(e, e->eqParamsHost[s], mode == 1, d);
+        double sg[4] = { d.satGain[0], d.satGain[1], d.satGain[0], d.satGain[1] };
+        CPQ_HIP(e, hipMemcpyAsync(e->svfCoef + c0 * kBands * 6, d.coef, sizeof(d.coef), hipMemcpyHostToDevice, e->stream));
+        CPQ_HIP(e, hipMemcpyAsync(e->svfFlags + c0 * kBands, d.flags, sizeof(d.flags), hipMemcpyHostToDevice, e->stream));
+        CPQ_HIP(e, hipMemcpyAsync(e->svfSatGain + c0 * 2, sg, sizeof(sg), hipMemcpyHostToDevice, e->stream));
+        CPQ_HIP(e, hipMemcpyAsync(e->svfTp + (size_t)s * d.tp.size(), d.tp.data(), d.tp.size() * sizeof(double),
+                                  hipMemcpyHostToDevice, e->stream));
+        e->eqTpSafe[s] = d.tpSafe ? 1 : 0;
+        e->eqMidSide[s] = d.midSide ? 1 : 0;
+        e->gainRamp[s].devUnity = false;          // the constant gain (or 1.0 with AGC) is on the device again
+    }
+    if (e->agcOn) {
+        const int on = (mode != 2 && e->agcOnHost[s]) ? 1 : 0;
+        CPQ_HIP(e, hipMemcpyAsync(e->agcOn + s, &on, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    bp.mode = mode;
+    return CPQ_OK;
+}
+
+// EQ over n samples (a multiple of the block) of rows `stride` apart.  pass: streams (or nullptr) that are bypassed for
+// the whole range -- their device tables hold pass-through flags, and the host-side gain ramp must not move either.
+int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride, int n, const char* pass)
+{
     bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO);
     for (char s : e->eqTpSafe) tp = tp && s;
-    const int n = T * e->P;
-    const int cbs = n / e->B;            // callback blocks in this call (AGC is block-rate)
+    const int cbs = n / e->B;            // callback blocks in this range (AGC is block-rate)
     // total-gain ramp (Processing.cpp:1262-1274): per callback setTargetValue / skip on a LinearRamp (50 ms);
     // evaluated on the host (scalar per-stream state), applied by the ramp kernel only while some stream is moving
     std::vector<int> rampOnHost;
@@ -541,7 +660,7 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         const int total = std::max(1, (int)(e->sampleRate * 0.05 + 0.5));
         for (int s = 0; s < S; ++s) {
             auto& r = e->gainRamp[s];
-            if (e->agcOnHost[s]) continue;
+            if (e->agcOnHost[s] || (pass && pass[s])) continue;
             const bool moving = r.remaining > 0 || std::fabs(r.target - r.wanted) > 1e-6 || r.current != r.wanted;
             if (!moving) continue;
             if (!anyRamp) { rampOnHost.assign(S, 0); rampHost.assign((size_t)S * cbs * 2, 0.0); anyRamp = true; }
@@ -567,7 +686,7 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         // streams whose gain is applied by the ramp kernel need unity gain in the cascade kernel, and back again
         for (int s = 0; s < S; ++s) {
             auto& r = e->gainRamp[s];
-            if (e->agcOnHost[s]) continue;
+            if (e->agcOnHost[s] || (pass && pass[s])) continue;
             const bool needUnity = anyRamp && rampOnHost[s];
             if (needUnity != r.devUnity) {
                 const double g = needUnity ? 1.0 : r.wanted;
@@ -590,16 +709,16 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     e->eqProcessed = true;
     if (e->anyAgc) {
         ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_agc_block_rms(e->stream, dIn, (int64_t)n, e->nCh, e->B, cbs, e->agcRmsIn);     // cachedInputRMS (:1116-1127)
+        cpq::launch_agc_block_rms(e->stream, dIn, stride, e->nCh, e->B, cbs, e->agcRmsIn);     // cachedInputRMS (:1116-1127)
     }
     bool midSide = false;
     for (char m : e->eqMidSide) midSide = midSide || m;
-    const int rc = enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
+    const int rc = enqueueCascade(e, dIn, dOut, stride, n, tp, CPQ_K_SVF_TP, CPQ_K_SVF, e->svfCoef, e->svfFlags, e->svfSatGain,
                                   e->svfState, e->svfTp, midSide);
     if (rc != CPQ_OK) return rc;
     if (anyRamp) {
         ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_gain_ramp(e->stream, dOut, (int64_t)n, e->desc.n_streams, e->B, cbs, e->rampGains, e->rampOn);
+        cpq::launch_gain_ramp(e->stream, dOut, stride, e->desc.n_streams, e->B, cbs, e->rampGains, e->rampOn);
         CPQ_HIP(e, hipGetLastError());
     }
     if (!e->anyAgc) return rc;
@@ -609,20 +728,144 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         const double nn = (double)e->B, sr = e->sampleRate;
         const double bAtt = 1.0 - std::exp(-nn / (sr * 0.2)), bRel = 1.0 - std::exp(-nn / (sr * 2.0)),
                      bSm = 1.0 - std::exp(-nn / (sr * 0.2));
-        cpq::launch_agc_block_rms(e->stream, dOut, (int64_t)n, e->nCh, e->B, cbs, e->agcRmsOut);
-        cpq::launch_agc_apply(e->stream, dOut, (int64_t)n, e->desc.n_streams, e->B, cbs, e->agcRmsIn, e->agcRmsOut,
+        cpq::launch_agc_block_rms(e->stream, dOut, stride, e->nCh, e->B, cbs, e->agcRmsOut);
+        cpq::launch_agc_apply(e->stream, dOut, stride, e->desc.n_streams, e->B, cbs, e->agcRmsIn, e->agcRmsOut,
                               e->agcState, e->agcOn, e->agcGains, bAtt, bRel, bSm);
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
 }
 
+// EQProcessor as DSPCore drives it with a per-stream bypass request (setBypassFromRT + process,
+// src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:384-413).  Per callback and stream the host replays the
+// bypass state machine of the basic process(block) (Processing.cpp:499-526, 565-624, 977-1015): a change of the request
+// starts the 5 ms LinearRamp bypassFadeGain; callbacks that start while it runs are processed through the basic path
+// (band nodes) and cross-faded with the dry block sample by sample; once the fade-out is complete the EQ returns early
+// (states, gain ramp and AGC frozen); releasing the bypass clears every filter state and fades back in.  The call is cut
+// where some stream changes class, each piece runs the ordinary kernels with the streams' tables switched accordingly.
+int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
+{
+    if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
+    const int n = T * e->P;
+    const int S = e->desc.n_streams;
+    if (!e->anyEqBypass) { e->eqProcessed = true; return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr); }
+    const int cbs = n / e->B;
+    const int total = std::max(1, (int)(e->sampleRate * 0.005 + 0.5));       // BYPASS_FADE_TIME_SEC (EQProcessor.h:564)
+    enum : char { kNormal = 0, kFade = 1, kPass = 2 };
+    std::vector<char> cls((size_t)S * cbs, kNormal), reset((size_t)S * cbs, 0);
+    std::vector<std::vector<double>> gains(S);          // fade values of a stream's kFade callbacks, in order
+    bool stillActive = false;
+    for (int s = 0; s < S; ++s) {
+        auto& b = e->eqBypass[s];
+        for (int t = 0; t < cbs; ++t) {
+            const double want = b.requested ? 0.0 : 1.0;
+            if (std::fabs(b.target - want) > 1.0e-12) {
+                if (!b.requested && b.effective) { reset[(size_t)s * cbs + t] = 1; b.effective = false; }
+                if (want != b.target) {                                       // LinearRamp::setTargetValue
+                    b.target = want;
+                    const int steps = b.remaining > 0 ? b.remaining : total;
+                    b.step = (b.target - b.current) / (double)steps;
+                    b.remaining = steps;
+                }
+            }
+            const bool transition = b.remaining > 0;
+            if (b.requested && !b.effective && !transition) b.effective = true;
+            if (b.requested && b.effective && !transition) { cls[(size_t)s * cbs + t] = kPass; continue; }
+            if (!transition) continue;
+            cls[(size_t)s * cbs + t] = kFade;
+            for (int i = 0; i < e->B && b.remaining > 0; ++i) {              // getNextValue while the ramp runs
+                b.current += b.step;
+                if (--b.remaining <= 0) b.current = b.target;
+                gains[s].push_back(b.current);
+            }
+            if (b.remaining <= 0) b.effective = b.requested;
+        }
+        stillActive = stillActive || b.requested || b.effective || b.remaining > 0 || b.mode != 0;
+    }
+    e->eqProcessed = true;
+    std::vector<char> pass(S);
+    std::vector<int> onHost(S), lenHost(S);
+    std::vector<double> endHost(S), gainsHost;
+    std::vector<size_t> used(S, 0);                     // fade values of the stream consumed by earlier pieces
+    int rc = CPQ_OK;
+    for (int c0 = 0; c0 < cbs && rc == CPQ_OK;) {
+        int c1 = c0 + 1;
+        auto sameClass = [&](int t) {
+            for (int s = 0; s < S; ++s)
+                if (cls[(size_t)s * cbs + t] != cls[(size_t)s * cbs + c0] || reset[(size_t)s * cbs + t]) return false;
+            return true;
+        };
+        while (c1 < cbs && sameClass(c1)) ++c1;
+        const int64_t off = (int64_t)c0 * e->B;
+        const int nSeg = (c1 - c0) * e->B;
+        bool anyFade = false;
+        int cap = 1;
+        for (int s = 0; s < S && rc == CPQ_OK; ++s) {
+            const char k = cls[(size_t)s * cbs + c0];
+            if (reset[(size_t)s * cbs + c0])       // every band of the stream, Mid / Side states included
+                CPQ_HIP(e, hipMemsetAsync(e->svfState + (size_t)s * 2 * kBands * 2, 0, sizeof(double) * 2 * kBands * 2, e->stream));
+            rc = setEqStreamMode(e, s, k == kPass ? 2 : k == kFade ? 1 : 0);
+            pass[s] = k == kPass;
+            onHost[s] = k == kFade;
+            lenHost[s] = 0;
+            endHost[s] = 1.0;
+            if (k == kFade) {
+                anyFade = true;
+                lenHost[s] = (int)std::min<size_t>(gains[s].size() - used[s], (size_t)nSeg);
+                // past the end of the ramp getNextValue keeps returning its final value
+                endHost[s] = gains[s].empty() ? e->eqBypass[s].current : gains[s][std::min(gains[s].size(), used[s] + (size_t)nSeg) - 1];
+                cap = std::max(cap, lenHost[s]);
+            }
+        }
+        if (rc != CPQ_OK) break;
+        if (anyFade) {
+            if (!e->eqDry) {
+                if (hipMalloc((void**)&e->eqDry, sizeof(double) * (size_t)e->nCh * e->tMax * e->P) != hipSuccess ||
+                    hipMalloc((void**)&e->blendOn, sizeof(int) * S) != hipSuccess ||
+                    hipMalloc((void**)&e->blendLen, sizeof(int) * S) != hipSuccess ||
+                    hipMalloc((void**)&e->blendEnd, sizeof(double) * S) != hipSuccess)
+                    return fail(e, CPQ_ERR_OOM, "EQ bypass cross-fade buffers could not be allocated");
+            }
+            if (cap > e->blendCap) {
+                if (e->blendGains) (void)hipFree(e->blendGains);
+                e->blendGains = nullptr;
+                e->blendCap = 0;
+                if (hipMalloc((void**)&e->blendGains, sizeof(double) * (size_t)S * cap) != hipSuccess)
+                    return fail(e, CPQ_ERR_OOM, "EQ bypass cross-fade buffers could not be allocated");
+                e->blendCap = cap;
+            }
+            gainsHost.assign((size_t)S * e->blendCap, 0.0);
+            for (int s = 0; s < S; ++s) {
+                if (!onHost[s]) continue;
+                std::memcpy(&gainsHost[(size_t)s * e->blendCap], gains[s].data() + used[s], sizeof(double) * (size_t)lenHost[s]);
+                used[s] += (size_t)lenHost[s];
+            }
+            CPQ_HIP(e, hipMemcpyAsync(e->blendOn, onHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipMemcpyAsync(e->blendLen, lenHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipMemcpyAsync(e->blendEnd, endHost.data(), sizeof(double) * S, hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipMemcpyAsync(e->blendGains, gainsHost.data(), sizeof(double) * gainsHost.size(), hipMemcpyHostToDevice, e->stream));
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_rows_copy(e->stream, dIn, (int64_t)n, off, e->eqDry, (int64_t)nSeg, 0, nSeg, e->nCh);
+        }
+        rc = enqueueEqCore(e, dIn + off, dOut + off, (int64_t)n, nSeg, pass.data());
+        if (rc == CPQ_OK && anyFade) {
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_bypass_blend(e->stream, dOut + off, (int64_t)n, e->eqDry, (int64_t)nSeg, nSeg, e->nCh, e->blendOn,
+                                     e->blendLen, e->blendEnd, e->blendGains, e->blendCap);
+            CPQ_HIP(e, hipGetLastError());
+        }
+        c0 = c1;
+    }
+    e->anyEqBypass = stillActive;
+    return rc;
+}
+
 int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T)
 {
     if (!e->ofSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_outfilter_set_params has not been called");
     const bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO) && e->ofTpSafe;
-    return enqueueCascade(e, dIn, dOut, T, tp, CPQ_K_OUTFILT, CPQ_K_OUTFILT, e->ofCoef, e->ofFlags, e->ofSatGain,
-                          e->ofState, e->ofTp);
+    return enqueueCascade(e, dIn, dOut, (int64_t)T * e->P, T * e->P, tp, CPQ_K_OUTFILT, CPQ_K_OUTFILT, e->ofCoef, e->ofFlags,
+                          e->ofSatGain, e->ofState, e->ofTp);
 }
 
 // Host-pointer entry points: H2D, the kernel sequence and D2H.  Long calls are cut into four time chunks (each a complete
@@ -921,6 +1164,10 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->eqMidSide.assign(d->n_streams, 0);
     e->eqParamsHost.assign(d->n_streams, cpq_eq_params{});
     e->eqParamsSet.assign(d->n_streams, 0);
+    e->eqBypass.assign(d->n_streams, cpq_engine::EqBypass{});
+    e->trimHost.assign(d->n_streams, 1.0);
+    e->makeupHost.assign(d->n_streams, 1.0);
+    e->ofPass.assign(d->n_streams, 0);
     e->ofModesHost.assign(d->n_streams, cpq_engine::OfModes{ 0, 1, 0, 1 });
     e->ofModesSet.assign(d->n_streams, 0);
     e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0.0f });
@@ -959,6 +1206,13 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
     if (e->procDelay) (void)hipFree(e->procDelay);
+    if (e->eqDry) (void)hipFree(e->eqDry);
+    if (e->trimDev) (void)hipFree(e->trimDev);
+    if (e->makeupDev) (void)hipFree(e->makeupDev);
+    if (e->blendOn) (void)hipFree(e->blendOn);
+    if (e->blendLen) (void)hipFree(e->blendLen);
+    if (e->blendEnd) (void)hipFree(e->blendEnd);
+    if (e->blendGains) (void)hipFree(e->blendGains);
     if (e->mixRampLen) (void)hipFree(e->mixRampLen);
     if (e->mixRampGains) (void)hipFree(e->mixRampGains);
     for (double* p : { e->directIr, e->directHist[0], e->directHist[1], e->directOut }) if (p) (void)hipFree(p);
@@ -1018,6 +1272,7 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
     }
     e->eqProcessed = false;
     e->procProcessed = false;
+    syncEqBypass(e);
     for (size_t s = 0; s < e->mixRamp.size(); ++s) {      // mixSmoother.setCurrentAndTargetValue(mix) (Lifecycle.cpp:370-371)
         auto& r = e->mixRamp[s];
         r.current = r.target = (double)e->procParams[s].mix;
@@ -1535,38 +1790,14 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
         if (p->bands[b].enabled && (p->bands[b].channel_mode < 0 || p->bands[b].channel_mode > 4))
             return fail(e, CPQ_ERR_INVALID_ARG, "band %d: channel_mode must be 0..4 (Stereo, Left, Right, Mid, Side)", b);
 
-    // createCoeffCache: bandActive = enabled && sr > 0; coefficients only for active bands
-    // (src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90).  An active Mid/Side band makes the reference fall
-    // back to the basic process(block) for the whole call (Processing.cpp:1036-1044); its band nodes are inactive
-    // for non-LP/HP bands within 0.01 dB of flat (createBandNode, Coefficients.cpp:48-53).
-    bool midSide = false;
-    for (int b = 0; b < kBands; ++b)
-        midSide = midSide || (p->bands[b].enabled && e->sampleRate > 0.0 && p->bands[b].channel_mode >= 3);
-    double coef[2][kBands][6];
-    int flags[2][kBands];
-    std::vector<double> tp((size_t)kBands * cpq::kSvfTpTableDoubles, 0.0);
-    bool tpSafe = true;
-    for (int b = 0; b < kBands; ++b) {
-        const cpq_eq_band& bp = p->bands[b];
-        bool active = bp.enabled && e->sampleRate > 0.0;
-        if (midSide && bp.type != 3 && bp.type != 4 && std::fabs(bp.gain) < 0.01f) active = false;
-        cpq_svf_coeffs c{ 0, 0, 0, 0, 0, 1, 0, 0 };
-        if (active) {
-            cpq::designSvf(bp.type, bp.frequency, bp.gain, bp.q, e->sampleRate, &c);
-            tpSafe = cpq::buildSvfTpTables(c, &tp[(size_t)b * cpq::kSvfTpTableDoubles]) && tpSafe;
-        }
-        for (int ch = 0; ch < 2; ++ch) {
-            const double v[6] = { c.a1, c.a2, c.a3, c.m0, c.m1, c.m2 };
-            std::memcpy(coef[ch][b], v, sizeof(v));
-            // Stereo -> both channels through the packed SSE2+FMA kernel; Left/Right -> one channel, scalar kernel
-            // Mid/Side -> both channel lanes run the scalar kernel on the encoded component (flag bit 4 / 5)
-            const bool on = active && (bp.channel_mode == 0 || bp.channel_mode == 1 + ch || bp.channel_mode >= 3);
-            flags[ch][b] = (on ? 1 : 0) | ((bp.channel_mode != 0) ? 2 : 0) | (p->filter_structure == 1 ? 8 : 0) |
-                           (bp.channel_mode == 3 ? 16 : 0) | (bp.channel_mode == 4 ? 32 : 0);
-        }
-    }
-    // with AGC the total-gain ramp is replaced by processAGC (Processing.cpp:1256-1259): unity gain in the cascade kernel
-    const double satGain[2] = { (double)p->nonlinear_saturation, p->agc_enabled ? 1.0 : cpq::totalGainLinear(p->total_gain_db) };
+    EqDesign d;
+    designEqStream(e, *p, false, d);
+    const auto& coef = d.coef;
+    const auto& flags = d.flags;
+    const std::vector<double>& tp = d.tp;
+    bool tpSafe = d.tpSafe;
+    const bool midSide = d.midSide;
+    const double satGain[2] = { d.satGain[0], d.satGain[1] };
 
     CPQ_HIP(e, hipSetDevice(e->device));
     const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
@@ -1583,7 +1814,6 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
             hs[ci * 2 + 1] = satGain[1];
         }
     for (int s = s0; s < s1; ++s) std::memcpy(&ht[(size_t)(s - s0) * tp.size()], tp.data(), tp.size() * sizeof(double));
-    if (p->filter_structure == 1 || midSide) tpSafe = false;     // parallel structure and Mid/Side bands run on the lane-skewed kernel
     for (int s = s0; s < s1; ++s) { e->eqTpSafe[s] = tpSafe ? 1 : 0; e->eqMidSide[s] = midSide ? 1 : 0; }
     const size_t c0 = (size_t)s0 * 2;
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
@@ -1592,7 +1822,7 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     CPQ_HIP(e, hipMemcpy(e->svfSatGain + c0 * 2, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->svfTp + (size_t)s0 * tp.size(), ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
     e->eqSet = true;   // streams never given parameters keep all bands inactive (pass-through)
-    for (int s = s0; s < s1; ++s) { e->eqParamsHost[s] = *p; e->eqParamsSet[s] = 1; }
+    for (int s = s0; s < s1; ++s) { e->eqParamsHost[s] = *p; e->eqParamsSet[s] = 1; e->eqBypass[s].mode = 0; }
     for (int s = s0; s < s1; ++s) {
         auto& r = e->gainRamp[s];
         r.wanted = cpq::totalGainLinear(p->total_gain_db);
@@ -1621,6 +1851,28 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* p)
     return CPQ_OK;
 }
 
+int32_t cpq_eq_set_bypass(cpq_engine* e, int32_t stream, int32_t bypassed)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    for (int s = s0; s < s1; ++s) {
+        auto& b = e->eqBypass[s];
+        b.requested = bypassed != 0;
+        if (!e->eqProcessed) {            // before the first callback the fade is synchronised, not run (Core.cpp:288, 802)
+            b.effective = b.requested;
+            b.current = b.target = b.requested ? 0.0 : 1.0;
+            b.step = 0.0;
+            b.remaining = 0;
+        }
+    }
+    e->anyEqBypass = false;
+    for (const auto& b : e->eqBypass) e->anyEqBypass = e->anyEqBypass || b.requested || b.effective || b.remaining > 0 || b.mode != 0;
+    return CPQ_OK;
+}
+
 int32_t cpq_eq_set_mode(cpq_engine* e, int32_t mode)
 {
     if (!e || (mode != CPQ_EQ_MODE_AUTO && mode != CPQ_EQ_MODE_SEQUENTIAL)) return CPQ_ERR_INVALID_ARG;
@@ -1628,7 +1880,12 @@ int32_t cpq_eq_set_mode(cpq_engine* e, int32_t mode)
     return CPQ_OK;
 }
 
-int32_t cpq_eq_reset(cpq_engine* e) { return e ? zeroRuntimeState(e, false, true) : CPQ_ERR_INVALID_ARG; }
+int32_t cpq_eq_reset(cpq_engine* e)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    syncEqBypass(e);
+    return zeroRuntimeState(e, false, true);
+}
 
 int32_t cpq_eq_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
 {
@@ -1724,19 +1981,82 @@ int32_t cpq_outfilter_process(cpq_engine* e, const double* in, double* out, int3
 // ------------------------------------------------------------------------ whole path
 static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
 {
-    int rc;
+    int rc = CPQ_OK;
+    const int n = T * e->P;
     auto conv = [e](const double* x, double* y, int t) {
         return e->convLevel == CPQ_LEVEL_PROCESSOR ? enqueueConvProc(e, x, y, t) : enqueueConv(e, x, y, t);
     };
     if (e->order == CPQ_ORDER_CONV_THEN_EQ) {
-        rc = conv(a, b, T);
+        if (!e->convBypassed) rc = conv(a, b, T);
+        else if (a != b) cpq::launch_rows_copy(e->stream, a, n, 0, b, n, 0, n, e->nCh);
         if (rc == CPQ_OK) rc = enqueueEq(e, b, b, T);
+    } else if (e->convBypassed) {
+        rc = enqueueEq(e, a, b, T);
     } else {
         rc = enqueueEq(e, a, e->mid, T);
+        if (rc == CPQ_OK && e->anyTrim) {       // scaleBlockFallback(block, convolverInputTrimGain) (:440-447)
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_rows_scale(e->stream, e->mid, n, n, e->nCh, e->trimDev);
+        }
         if (rc == CPQ_OK) rc = conv(e->mid, b, T);
     }
-    if (rc == CPQ_OK && e->ofInPath) rc = enqueueOutFilter(e, b, b, T);
+    if (rc == CPQ_OK && e->ofInPath) {
+        // outputFilter.process runs when the convolver or the EQ is active (:453-463); a stream with both bypassed
+        // keeps its filter state untouched
+        bool anyActive = false;
+        for (int s = 0; s < e->desc.n_streams; ++s) {
+            const char pass = (e->convBypassed && e->eqBypass[s].requested) ? 1 : 0;
+            anyActive = anyActive || !pass;
+            if (pass == e->ofPass[s] || !e->ofModesSet[s]) continue;
+            int flags[2 * kBands] = {};
+            if (!pass) for (int ch = 0; ch < 2; ++ch) for (int k = 0; k < 3; ++k) flags[ch * kBands + k] = 1 | 4;
+            CPQ_HIP(e, hipMemcpyAsync(e->ofFlags + (size_t)2 * s * kBands, flags, sizeof(flags), hipMemcpyHostToDevice, e->stream));
+            e->ofPass[s] = pass;
+        }
+        if (anyActive) rc = enqueueOutFilter(e, b, b, T);
+    }
+    if (rc == CPQ_OK && e->anyMakeup) {         // scaleBlockFallback(block, outputMakeupGain) (:465-469)
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_rows_scale(e->stream, b, n, n, e->nCh, e->makeupDev);
+        CPQ_HIP(e, hipGetLastError());
+    }
     return rc;
+}
+
+int32_t cpq_engine_set_gains(cpq_engine* e, int32_t stream, double convInputTrimGain, double outputMakeupGain)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    if (!std::isfinite(convInputTrimGain) || !std::isfinite(outputMakeupGain))
+        return fail(e, CPQ_ERR_INVALID_ARG, "gains must be finite");
+    CPQ_HIP(e, hipSetDevice(e->device));
+    const int S = e->desc.n_streams;
+    if (!e->trimDev) {
+        if (hipMalloc((void**)&e->trimDev, sizeof(double) * S) != hipSuccess ||
+            hipMalloc((void**)&e->makeupDev, sizeof(double) * S) != hipSuccess)
+            return fail(e, CPQ_ERR_OOM, "gain buffers could not be allocated");
+    }
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? S : stream + 1;
+    for (int s = s0; s < s1; ++s) {
+        // the trim is applied only when it differs from 1 by more than 1e-12 (:440)
+        e->trimHost[s] = std::fabs(convInputTrimGain - 1.0) > 1e-12 ? convInputTrimGain : 1.0;
+        e->makeupHost[s] = outputMakeupGain;
+    }
+    e->anyTrim = e->anyMakeup = false;
+    for (int s = 0; s < S; ++s) { e->anyTrim = e->anyTrim || e->trimHost[s] != 1.0; e->anyMakeup = e->anyMakeup || e->makeupHost[s] != 1.0; }
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    CPQ_HIP(e, hipMemcpy(e->trimDev, e->trimHost.data(), sizeof(double) * S, hipMemcpyHostToDevice));
+    CPQ_HIP(e, hipMemcpy(e->makeupDev, e->makeupHost.data(), sizeof(double) * S, hipMemcpyHostToDevice));
+    return CPQ_OK;
+}
+
+int32_t cpq_engine_set_conv_bypass(cpq_engine* e, int32_t bypassed)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    e->convBypassed = bypassed != 0;
+    return CPQ_OK;
 }
 
 int32_t cpq_engine_process_block_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)

@@ -106,6 +106,12 @@ void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, 
 void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,
                           int pl2, int ol2, int d2);
 
+// EQ bypass cross-fade for the streams flagged in `on`: out = out * g + dry * (1 - g); g = gains[s][i] for i < len[s], gEnd[s] after
+void launch_bypass_blend(hipStream_t stream, double* out, int64_t outStride, const double* dry, int64_t dryStride, int n,
+                         int nCh, const int* on, const int* len, const double* gEnd, const double* gains, int cap);
+// data[c][i] *= gain[c / 2] (streams with gain exactly 1 are left alone)
+void launch_rows_scale(hipStream_t stream, double* data, int64_t stride, int n, int nCh, const double* gain);
+
 // direct head: time-domain FIR of the first <= 32 taps over [history | block] into dout ([nCh][n]); then out += dout
 void launch_direct_head(hipStream_t stream, const double* in, int64_t inStride, int n, const double* irRev, const int* taps,
                         const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh);

@@ -315,6 +315,38 @@ __global__ __launch_bounds__(256) void k_rows_add(double* out, int64_t outStride
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] += a[i];
 }
 
+// EQ bypass cross-fade (EQProcessor.Processing.cpp:977-1003): out = out * g + dry * (1 - g) for the streams flagged in
+// `on`; g = gains[s][i] for the first len[s] samples (the LinearRamp's values, formed on the host), gEnd[s] after.
+__global__ __launch_bounds__(256) void k_bypass_blend(double* out, int64_t outStride, const double* __restrict__ dry,
+                                                      int64_t dryStride, int n, const int* __restrict__ on,
+                                                      const int* __restrict__ len, const double* __restrict__ gEnd,
+                                                      const double* __restrict__ gains, int cap)
+{
+    const int c = blockIdx.y;
+    const int s = c >> 1;
+    if (!on[s]) return;
+    double* o = out + (int64_t)c * outStride;
+    const double* d = dry + (int64_t)c * dryStride;
+    const int nr = len[s];
+    const double ge = gEnd[s];
+    const double* g = gains + (int64_t)s * cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double wg = i < nr ? g[i] : ge;
+        const double dg = 1.0 - wg;
+        o[i] = (o[i] * wg) + (d[i] * dg);
+    }
+}
+
+// data[c][i] *= gain[stream] for the streams whose gain is not exactly 1 (scaleBlockFallback,
+// src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:93-105)
+__global__ __launch_bounds__(256) void k_rows_scale(double* data, int64_t stride, int n, const double* __restrict__ gain)
+{
+    const double g = gain[blockIdx.y >> 1];
+    if (g == 1.0) return;
+    double* d = data + (int64_t)blockIdx.y * stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] *= g;
+}
+
 }  // namespace
 
 void launch_agc_block_rms(hipStream_t stream, const double* x, int64_t chStride, int nCh, int B, int T, double* rms)
@@ -376,6 +408,20 @@ void launch_rows_copy(hipStream_t stream, const double* src, int64_t srcStride, 
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_rows_copy, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, srcOff, dst, dstStride, dstOff, n);
+}
+
+void launch_bypass_blend(hipStream_t stream, double* out, int64_t outStride, const double* dry, int64_t dryStride, int n,
+                         int nCh, const int* on, const int* len, const double* gEnd, const double* gains, int cap)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_bypass_blend, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, dry, dryStride, n, on, len,
+                       gEnd, gains, cap);
+}
+
+void launch_rows_scale(hipStream_t stream, double* data, int64_t stride, int n, int nCh, const double* gain)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_rows_scale, rowsGrid(n, nCh), dim3(256), 0, stream, data, stride, n, gain);
 }
 
 void launch_ring_put(hipStream_t stream, const double* z, int64_t zStride, int n, double* ring, int ringSize,

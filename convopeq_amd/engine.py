@@ -193,6 +193,15 @@ class BatchedEngine:
     def set_eq_params(self, stream, params):
         self._ck(self._lib.cpq_eq_set_params(self._h, stream, C.byref(params)))
 
+    def set_gains(self, stream, conv_input_trim_gain=1.0, output_makeup_gain=1.0):
+        self._ck(self._lib.cpq_engine_set_gains(self._h, stream, conv_input_trim_gain, output_makeup_gain))
+
+    def set_conv_bypass(self, bypassed):
+        self._ck(self._lib.cpq_engine_set_conv_bypass(self._h, int(bypassed)))
+
+    def set_eq_bypass(self, stream, bypassed):
+        self._ck(self._lib.cpq_eq_set_bypass(self._h, stream, int(bypassed)))
+
     def set_convproc_params(self, stream, mix=1.0, bypassed=False, ir_peak_latency=0, smoothing_time_sec=0.0):
         p = K.ConvProcParams(mix, int(bypassed), ir_peak_latency, smoothing_time_sec)
         self._ck(self._lib.cpq_convproc_set_params(self._h, stream, C.byref(p)))

@@ -262,6 +262,14 @@ int32_t cpq_eq_set_params(cpq_engine* e, int32_t stream, const cpq_eq_params* pa
  * (src/eqprocessor/EQProcessor.Processing.cpp:1019-1276), serial structure, steady total gain. */
 int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t n_samples);
 int32_t cpq_eq_process_device(cpq_engine* e, const double* d_in, double* d_out, int32_t n_samples);
+/* replaces EQProcessor::setBypassFromRT(bool) as DSPCore calls it before every block
+ * (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:384; src/eqprocessor/EQProcessor.Processing.cpp:499-526,
+ * 977-1015), per stream.  After the first processed call a change runs the reference's 5 ms bypass fade
+ * (BYPASS_FADE_TIME_SEC): the callbacks that start while it runs go through the basic process(block) -- whose band nodes
+ * leave flat non-LP/HP bands out -- and are cross-faded with the dry block per sample; once faded out the EQ of the
+ * stream does nothing (filter states, total-gain ramp and AGC frozen); releasing the bypass clears the stream's filter
+ * states and fades back in.  Before the first call (and at prepare / reset) the state follows the request at once. */
+int32_t cpq_eq_set_bypass(cpq_engine* e, int32_t stream, int32_t bypassed);
 /* EQ kernel choice.  AUTO: time-parallel kernel (per band: zero-state chunk runs + state scan; equal to the
  * sequential recurrence up to rounding, measured <= 3e-15) whenever the host can prove the reference's state
  * guards cannot trip, else the sequential kernel.  SEQUENTIAL: lane-skewed kernel that reproduces the
@@ -292,6 +300,17 @@ int32_t cpq_outfilter_reset(cpq_engine* e);
 int32_t cpq_engine_enable_output_filter(cpq_engine* e, int32_t on);
 
 /* ------------------------------------------------------- whole path per call */
+/* The remaining per-block values of DSPCore's routing (RuntimeSnapshot fields,
+ * src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:384-470), used by cpq_engine_process_block:
+ * conv_input_trim_gain: convolverInputTrimGain, multiplied into the EQ output before the convolver in EQ -> conv order
+ *   when it differs from 1 by more than 1e-12 (:438-447); output_makeup_gain: outputMakeupGain, multiplied into the
+ *   block after the output filter (:465-469).
+ * cpq_engine_set_conv_bypass: state.convBypassed -- the convolver stage is not called at all (no latency compensation;
+ *   the processor-level bypass with its delay line is cpq_convproc_params.bypassed).  The EQ's bypass is
+ *   cpq_eq_set_bypass.  With the output filter enabled it runs for the streams whose convolver or EQ is active (:453-463);
+ *   conv_is_last of cpq_outfilter_set_params stays the caller's to pass, as DSPCore derives it (:458-459). */
+int32_t cpq_engine_set_gains(cpq_engine* e, int32_t stream, double conv_input_trim_gain, double output_makeup_gain);
+int32_t cpq_engine_set_conv_bypass(cpq_engine* e, int32_t bypassed);
 /* replaces the DSPCore routing of convolverRt().process(block) and eqRt().process(block, params, cache)
  * (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:386-451) in the configured order. */
 int32_t cpq_engine_process_block(cpq_engine* e, const double* in, double* out, int32_t n_samples);

@@ -1003,6 +1003,12 @@ static void gain_ramp_avx_pattern(double* data, int n, double startGain, double 
 void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSize,
                            const orc_eq_params* p, double sr, double* state)
 {
+    orc_eq_process_stereo_ex(dataL, dataR, n, blockSize, p, sr, state, 0);
+}
+
+void orc_eq_process_stereo_ex(double* dataL, double* dataR, int64_t n, int blockSize,
+                              const orc_eq_params* p, double sr, double* state, int forceBasicPath)
+{
     orc_svf_coeffs co[20];
     int active[20];
     for (int b = 0; b < 20; ++b) {   /* createCoeffCache, ProcessingCache.cpp:71-90 */
@@ -1011,7 +1017,7 @@ void orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSiz
     }
     /* an active Mid/Side band sends the whole call to the basic process(block) (Processing.cpp:1036-1044), whose
      * band nodes are inactive for non-LP/HP bands within 0.01 dB of flat (createBandNode, Coefficients.cpp:48-53) */
-    int basicPath = 0;
+    int basicPath = forceBasicPath != 0;
     for (int b = 0; b < 20; ++b) if (active[b] && p->bands[b].channelMode >= 3) basicPath = 1;
     if (basicPath)
         for (int b = 0; b < 20; ++b)

@@ -150,6 +150,11 @@ void   orc_svf_band_mono(double* data, int64_t n, const orc_svf_coeffs* c,
  * processed in blocks of blockSize like the caller does; AGC (processAGC, :367-445) when agcEnabled. */
 void   orc_eq_process_stereo(double* dataL, double* dataR, int64_t n, int blockSize,
                              const orc_eq_params* p, double sr, double* state /*[168]*/);
+/* forceBasicPath != 0: the call runs through the basic process(block) (band nodes: flat non-LP/HP bands inactive), as
+ * the reference does while the EQ bypass is requested, in effect or fading (Processing.cpp:1023-1034; DSPCore calls
+ * process(block) directly while eqBypassed, AudioEngine.Processing.DSPCoreDouble.cpp:392-413) */
+void   orc_eq_process_stereo_ex(double* dataL, double* dataR, int64_t n, int blockSize,
+                                const orc_eq_params* p, double sr, double* state /*[168]*/, int forceBasicPath);
 
 /* ------------------------------------------------------- OutputFilter (N2) ---- */
 /* mirrors convo::BiquadCoeff, src/OutputFilter.h:40-44 */

@@ -104,6 +104,8 @@ def lib():
     L.orc_svf_band_mono.argtypes = [c_double_p, C.c_int64, C.POINTER(SvfCoeffs), c_double_p, C.c_double]
     L.orc_eq_process_stereo.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, C.POINTER(EqParams),
                                         C.c_double, c_double_p]
+    L.orc_eq_process_stereo_ex.argtypes = [c_double_p, c_double_p, C.c_int64, C.c_int, C.POINTER(EqParams),
+                                           C.c_double, c_double_p, C.c_int]
     L.orc_outfilter_design.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Biquad)]
     L.orc_biquad_df2t_lane.argtypes = [c_double_p, C.c_int64, C.POINTER(Biquad), c_double_p]
     L.orc_outfilter_process_stereo.argtypes = [c_double_p, c_double_p, C.c_int64, C.POINTER(Biquad), c_double_p]
@@ -264,6 +266,75 @@ def eq_process_stereo(xl, xr, params, sr=48000.0, block=512, state=None):
         state = np.zeros(2 * 20 * 2 + 3 + 5 + 2 * 20 * 2, dtype=np.float64)
     lib().orc_eq_process_stereo(dp(yl), dp(yr), len(yl), block, C.byref(params), sr, dp(state))
     return yl, yr, state
+
+
+class LinearRamp:
+    """convo::LinearRamp (src/DspNumericPolicy.h:319-421)."""
+
+    def __init__(self, value, sr, time_sec):
+        self.current = self.target = float(value)
+        self.step, self.remaining = 0.0, 0
+        self.total = max(1, int(sr * time_sec + 0.5))
+
+    def set_target(self, v):
+        if v == self.target:
+            return
+        self.target = v
+        steps = self.remaining if self.remaining > 0 else self.total
+        self.step = (self.target - self.current) / float(steps)
+        self.remaining = steps
+
+    def next(self):
+        if self.remaining <= 0:
+            return self.current
+        self.current += self.step
+        self.remaining -= 1
+        if self.remaining <= 0:
+            self.current = self.target
+        return self.current
+
+
+class EqWithBypass:
+    """EQProcessor as DSPCore drives it (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:384-413): per callback
+    setBypassFromRT(requested), then process(block, params, cache) -- which falls back to the basic process(block) while
+    the bypass is in effect or fading (src/eqprocessor/EQProcessor.Processing.cpp:1023-1034) -- or process(block)
+    directly while the bypass is requested.  The basic path (:486-1016) fades between the processed and the dry block
+    over BYPASS_FADE_TIME_SEC = 5 ms, returns early once the fade-out is complete (states frozen) and clears every
+    filter state when the bypass is released."""
+
+    def __init__(self, params, sr=48000.0, block=512):
+        self.p, self.sr, self.block = params, sr, block
+        self.state = np.zeros(168)
+        self.fade = LinearRamp(1.0, sr, 0.005)
+        self.effective = False
+
+    def callback(self, xl, xr, requested):
+        L = lib()
+        target = 0.0 if requested else 1.0
+        if abs(self.fade.target - target) > 1.0e-12:
+            if not requested and self.effective:
+                self.state[0:80] = 0.0                      # deferred reset of all bands: canSafelyResetState holds
+                self.state[88:168] = 0.0                    # (a transition is active), so it happens in this callback
+                self.effective = False
+            self.fade.set_target(target)
+        transition = self.fade.remaining > 0
+        if requested and not self.effective and not transition:
+            self.effective = True
+        if requested and self.effective and not transition:
+            return xl.copy(), xr.copy()
+        basic = requested or self.effective or transition
+        yl, yr = xl.copy(), xr.copy()
+        L.orc_eq_process_stereo_ex(dp(yl), dp(yr), len(yl), self.block, C.byref(self.p), self.sr, dp(self.state),
+                                   int(basic))
+        if transition:
+            for i in range(len(yl)):
+                g = self.fade.next()
+                d = 1.0 - g
+                yl[i] = yl[i] * g + xl[i] * d
+                yr[i] = yr[i] * g + xr[i] * d
+            if self.fade.remaining <= 0:
+                self.effective = bool(requested)
+        return yl, yr
 
 
 def convproc_steady(ir, x, block, mix=1.0, bypassed=False, ir_peak_latency=0, scale=1.0, spec=None):

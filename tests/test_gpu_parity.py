@@ -1059,3 +1059,116 @@ def test_ingested_ir_file_end_to_end(amd, oracle):
         worst = max(worst, rms(y[c] - ref) / max(rms(ref), 1e-30))
     assert worst <= 1e-12, worst
     eng.close()
+
+
+@pytest.mark.parametrize("block,agc,eq_mode", [(512, False, "seq"), (512, False, "auto"), (64, False, "seq"), (512, True, "seq")])
+def test_eq_bypass_fade_state_machine(amd, oracle, block, agc, eq_mode):
+    """SURVEY N4 (bypass fades): cpq_eq_set_bypass per stream, changed between calls while processing -- the 5 ms fade
+    through the basic path (flat bands drop out of the cascade there, visible with saturation 0.2), the frozen state
+    while bypassed, the state clear + fade-in on release, a release in the middle of a fade-out (block 64: the fade spans
+    four callbacks), a moving total gain and the AGC across the bypass.  Against the state machine restated in
+    tests/oracle_lib.py (EqWithBypass) around the oracle's EQ."""
+    O = oracle
+    S, T, calls = 3, 6, 10
+    po = O.eq_params_bench(0.2)
+    for i in (3, 8, 12):
+        po.bands[i].gain = 0.0                      # flat bands: active on the parameter path, inactive as band nodes
+    po.totalGainDb = -3.0
+    po.agcEnabled = int(agc)
+    n = T * block
+    x = make_inputs(O, S, calls * n)
+    # bypass request per call and stream; stream 2 is never bypassed
+    req = [[0, 0, 1, 1, 1, 0, 0, 1, 0, 0],
+           [0, 1, 0, 1, 1, 1, 0, 0, 0, 1],
+           [0] * 10]
+    eng = amd.BatchedEngine(S, block_size=block, max_ir_len=block, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    if eq_mode == "seq":
+        eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    outs = []
+    for k in range(calls):
+        for s in range(S):
+            eng.set_eq_bypass(s, req[s][k])
+        if k == 6:                                  # a total-gain change while stream 0 has just been released
+            pa = _copy_params(po, amd.eq_params_default())
+            pa.total_gain_db = 2.0
+            eng.set_eq_params(0, pa)
+        outs.append(eng.eq_process(x[:, k * n:(k + 1) * n]))
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    tol = 0.0 if eq_mode == "seq" else 2e-14
+    for s in range(S):
+        ps = O.EqParams.from_buffer_copy(po)
+        ref = O.EqWithBypass(ps, 48000.0, block)
+        rl, rr = [], []
+        for k in range(calls):
+            if k == 6 and s == 0:
+                ref.p.totalGainDb = 2.0
+            for t in range(T):
+                o = (k * T + t) * block
+                a, b = ref.callback(x[2 * s, o:o + block].copy(), x[2 * s + 1, o:o + block].copy(), bool(req[s][k]))
+                rl.append(a)
+                rr.append(b)
+        rl, rr = np.concatenate(rl), np.concatenate(rr)
+        err = max(np.abs(y[2 * s] - rl).max(), np.abs(y[2 * s + 1] - rr).max())
+        assert err <= tol, (s, err)
+    # while bypassed (fade complete) the output is the input, bit for bit
+    k = 3
+    assert np.array_equal(y[0, k * n + block:(k + 1) * n], x[0, k * n + block:(k + 1) * n])
+    assert not np.array_equal(y[4, k * n:(k + 1) * n], x[4, k * n:(k + 1) * n])
+
+
+def test_dspcore_routing_gains_and_bypasses(amd, oracle):
+    """The rest of DSPCore's block routing (DSPCoreDouble.cpp:384-470): EQ -> conv order with convolverInputTrimGain,
+    outputMakeupGain after the output filter, convBypassed (the convolver stage is skipped, state untouched), and with
+    the convolver and a stream's EQ both bypassed the output filter is not run for that stream either."""
+    O = oracle
+    S, T = 2, 4
+    n = T * B
+    irs = [O.gen_ir(3000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, S, 6 * n)
+    po = O.eq_params_bench(0.2)
+    q = O.outfilter_design(1, 1, 0, 1, 48000.0)
+    trim, makeup = [0.5, 1.0 + 1e-13], [1.25, 0.8]            # stream 1's trim is within 1e-12 of 1: not applied
+    eng = amd.BatchedEngine(S, max_ir_len=3000, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+        eng.set_gains(s, trim[s], makeup[s])
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    eng.set_order(amd.CPQ_ORDER_EQ_THEN_CONV)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 1, 1, 0, 1)
+    eng.enable_output_filter(True)
+    # calls 0-1: everything active; 2-3: convolver bypassed; 4: also stream 0's EQ bypass requested before the call
+    # (its fade callback still filters, the output filter does not run for it); 5: all back
+    outs = []
+    for k in range(6):
+        eng.set_conv_bypass(k in (2, 3, 4))
+        eng.set_eq_bypass(0, k == 4)
+        outs.append(eng.process(x[:, k * n:(k + 1) * n]))
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    for s in range(S):
+        eq = O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B)
+        nucs = [O.Nuc(), O.Nuc()]
+        for ch in range(2):
+            assert nucs[ch].set_impulse(irs[2 * s + ch], B)
+        of_state = None
+        ref = np.empty((2, 6 * n))
+        for k in range(6):
+            conv_bypassed, eq_req = k in (2, 3, 4), (k == 4 and s == 0)
+            blk = [np.empty(n), np.empty(n)]
+            for t in range(T):
+                o = k * n + t * B
+                a, b = eq.callback(x[2 * s, o:o + B].copy(), x[2 * s + 1, o:o + B].copy(), eq_req)
+                blk[0][t * B:(t + 1) * B], blk[1][t * B:(t + 1) * B] = a, b
+            if not conv_bypassed:
+                for ch in range(2):
+                    v = blk[ch] * trim[s] if abs(trim[s] - 1.0) > 1e-12 else blk[ch]
+                    blk[ch] = nucs[ch].run(v, B)
+            if not (conv_bypassed and eq_req):
+                blk[0], blk[1], of_state = O.outfilter_process_stereo(blk[0], blk[1], q, of_state)
+            ref[0, k * n:(k + 1) * n], ref[1, k * n:(k + 1) * n] = blk[0] * makeup[s], blk[1] * makeup[s]
+        for ch in range(2):
+            err = np.abs(y[2 * s + ch] - ref[ch]).max()
+            assert err <= 2e-13, (s, ch, err)
