@@ -203,9 +203,25 @@ struct cpq_engine {
     double* mixRampGains = nullptr;     // [streams][tMax * P][2] device (allocated when a ramp first runs)
     double* procGains = nullptr;    // [streams][2] device
     int* procDelay = nullptr;       // [streams] device
-    double* dryHist[2] = { nullptr, nullptr };   // [nCh][dryHistCap] device, allocated on first use
-    int dryHistCap = 0, dryHistSel = 0;
-    double* dryCopy = nullptr;      // [nCh][tMax*P] copy of the input when processing in place
+    // dry delay line: a ring per channel (the reference's 4 Mi-sample delayBuffer, Runtime.cpp:378-391), sized for the
+    // longest delay an IR of max_ir_len can ask for plus one call; every call's input is written before anything reads
+    double* dryRing = nullptr;      // [nCh][dryRingSize] device, allocated on first use
+    int dryRingSize = 0;
+    long long dryPos = 0;           // absolute position of the next input sample
+    // latency compensation (Runtime.cpp:263-290, 394-540): latencySmoother is only ever snapped, crossfadeGain runs 20 ms
+    struct LatencyFade {
+        double latCurrent = 0.0, latTarget = 0.0, oldDelay = 0.0;
+        double current = 1.0, target = 1.0, step = 0.0;
+        int remaining = 0;
+        bool primed = false;        // latCurrent holds the prepareToPlay value (Lifecycle.cpp:380-388)
+    };
+    std::vector<LatencyFade> latFade;
+    int* latNew = nullptr;          // [streams] device: delay of the dry read
+    int* latOld = nullptr;          // [streams] delay faded out
+    std::vector<int> latNewHost, latOldHost;    // what the two device arrays hold
+    int* latLen = nullptr;          // [streams] samples of the range that are cross-faded
+    double* latGains = nullptr;     // [streams][latCap]
+    int latCap = 0;
 
     // profiling
     bool profiling = false;
@@ -947,8 +963,9 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
             if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, sizeof(double) * 32 * e->nCh, e->stream));
         if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 3 * sizeof(long long), e->stream));
         if (e->tailRing) CPQ_HIP(e, hipMemsetAsync(e->tailRing, 0, sizeof(double) * (size_t)(e->layerPlan.num_layers - 1) * e->nCh * e->tailRingSlots, e->stream));
-        for (double* p : { e->dryHist[0], e->dryHist[1] })
-            if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, (size_t)e->nCh * e->dryHistCap * sizeof(double), e->stream));
+        if (e->dryRing) CPQ_HIP(e, hipMemsetAsync(e->dryRing, 0, (size_t)e->nCh * e->dryRingSize * sizeof(double), e->stream));
+        e->dryPos = 0;
+        for (auto& f : e->latFade) f = cpq_engine::LatencyFade{};
     }
     if (eq) {
         CPQ_HIP(e, hipMemsetAsync(e->svfState, 0, (size_t)e->nCh * kBands * 2 * sizeof(double), e->stream));
@@ -1165,6 +1182,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->eqParamsHost.assign(d->n_streams, cpq_eq_params{});
     e->eqParamsSet.assign(d->n_streams, 0);
     e->eqBypass.assign(d->n_streams, cpq_engine::EqBypass{});
+    e->latFade.assign(d->n_streams, cpq_engine::LatencyFade{});
     e->trimHost.assign(d->n_streams, 1.0);
     e->makeupHost.assign(d->n_streams, 1.0);
     e->ofPass.assign(d->n_streams, 0);
@@ -1198,7 +1216,7 @@ void cpq_engine_destroy(cpq_engine* e)
         for (int i = 0; i < 4; ++i) { (void)hipEventDestroy(e->evIn[i]); (void)hipEventDestroy(e->evDone[i]); }
     }
     if (e->arena) (void)hipFree(e->arena);
-    for (double* p : { e->dryHist[0], e->dryHist[1], e->dryCopy, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
+    for (double* p : { e->dryRing, e->latGains, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
     if (e->agcOn) (void)hipFree(e->agcOn);
     if (e->rampOn) (void)hipFree(e->rampOn);
     if (e->rampGains) (void)hipFree(e->rampGains);
@@ -1206,6 +1224,7 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
     if (e->procDelay) (void)hipFree(e->procDelay);
+    for (int* p : { e->latNew, e->latOld, e->latLen }) if (p) (void)hipFree(p);
     if (e->eqDry) (void)hipFree(e->eqDry);
     if (e->trimDev) (void)hipFree(e->trimDev);
     if (e->makeupDev) (void)hipFree(e->makeupDev);
@@ -1623,16 +1642,27 @@ int uploadProcParams(cpq_engine* e)
         CPQ_HIP(e, hipMalloc((void**)&e->procGains, sizeof(double) * 2 * S));
         CPQ_HIP(e, hipMalloc((void**)&e->procDelay, sizeof(int) * S));
     }
-    if (maxDelay > e->dryHistCap) {        // (re)allocate the dry delay line, preserving nothing: state restarts
-        for (int i = 0; i < 2; ++i) { if (e->dryHist[i]) (void)hipFree(e->dryHist[i]); e->dryHist[i] = nullptr; }
-        const int cap = (int)alignUp(maxDelay, 512);
-        for (int i = 0; i < 2; ++i) {
-            if (hipMalloc((void**)&e->dryHist[i], sizeof(double) * (size_t)e->nCh * cap) != hipSuccess)
-                return fail(e, CPQ_ERR_OOM, "dry delay line of %d samples per channel could not be allocated", cap);
-            CPQ_HIP(e, hipMemset(e->dryHist[i], 0, sizeof(double) * (size_t)e->nCh * cap));
+    // delay ring: the longest delay in sight (any IR that fits the engine: irPeakLatency < irLen) plus one call; a larger
+    // request later grows it, keeping what it holds
+    const int64_t need = (int64_t)std::max(maxDelay, e->B + e->desc.max_ir_len) + (int64_t)e->tMax * e->P + 1;
+    if (need > e->dryRingSize) {
+        const int size = nextPow2((int)std::min<int64_t>(need, (int64_t)1 << 30));
+        double* ring = nullptr;
+        if (hipMalloc((void**)&ring, sizeof(double) * (size_t)e->nCh * size) != hipSuccess)
+            return fail(e, CPQ_ERR_OOM, "dry delay line of %d samples per channel could not be allocated", size);
+        CPQ_HIP(e, hipMemset(ring, 0, sizeof(double) * (size_t)e->nCh * size));
+        if (e->dryRing) {
+            cpq::launch_ring_regrow(e->stream, e->dryRing, e->dryRingSize, ring, size, e->dryPos, e->nCh);
+            CPQ_HIP(e, hipStreamSynchronize(e->stream));
+            (void)hipFree(e->dryRing);
         }
-        e->dryHistCap = cap;
-        e->dryHistSel = 0;
+        e->dryRing = ring;
+        e->dryRingSize = size;
+    }
+    if (!e->latNew) {
+        if (hipMalloc((void**)&e->latNew, sizeof(int) * S) != hipSuccess || hipMalloc((void**)&e->latOld, sizeof(int) * S) != hipSuccess ||
+            hipMalloc((void**)&e->latLen, sizeof(int) * S) != hipSuccess)
+            return fail(e, CPQ_ERR_OOM, "latency buffers could not be allocated");
     }
     CPQ_HIP(e, hipMemcpy(e->procGains, g.data(), sizeof(double) * g.size(), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(e->procDelay, d.data(), sizeof(int) * d.size(), hipMemcpyHostToDevice));
@@ -1684,35 +1714,139 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
         CPQ_HIP(e, hipMemcpyAsync(e->mixRampGains, rampHost.data(), sizeof(double) * rampHost.size(), hipMemcpyHostToDevice, e->stream));
         CPQ_HIP(e, hipStreamSynchronize(e->stream));         // the host vectors go out of scope
     }
+    const bool firstCall = !e->procProcessed;
     e->procProcessed = true;
     const bool skipConv = e->procBypassed || (e->procDryOnly && !anyRamp);      // needsConvolution = isSmoothing || mix > 0.001
-    const double* dry = dIn;
-    if (dIn == dOut && !skipConv) {
-        // in place: the convolver overwrites the block, keep a copy for the dry path
-        if (!e->dryCopy)
-            CPQ_HIP(e, hipMalloc((void**)&e->dryCopy, sizeof(double) * (size_t)e->nCh * e->tMax * e->P));
-        CPQ_HIP(e, hipMemcpyAsync(e->dryCopy, dIn, sizeof(double) * (size_t)e->nCh * n, hipMemcpyDeviceToDevice, e->stream));
-        dry = e->dryCopy;
+    // the call's input goes into the delay ring before the convolver may overwrite it (in-place calls)
+    const long long pos0 = e->dryPos;
+    {
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_ring_put(e->stream, dIn, (int64_t)n, n, e->dryRing, e->dryRingSize, pos0, e->nCh);
     }
-    const double* wet = dOut;
+    e->dryPos += n;
     if (!skipConv) {
         const int rc = enqueueConv(e, dIn, dOut, T);
         if (rc != CPQ_OK) return rc;
-    } else if (dIn == dOut) {
-        // delayed copy in place needs the un-overwritten input as well
-        if (!e->dryCopy)
-            CPQ_HIP(e, hipMalloc((void**)&e->dryCopy, sizeof(double) * (size_t)e->nCh * e->tMax * e->P));
-        CPQ_HIP(e, hipMemcpyAsync(e->dryCopy, dIn, sizeof(double) * (size_t)e->nCh * n, hipMemcpyDeviceToDevice, e->stream));
-        dry = e->dryCopy;
     }
+    // Latency compensation per callback and stream (:263-290): a total latency that moved by >= 2 samples starts, unless
+    // one is running, a 20 ms cross-fade of the dry read from the delay in use to the new one; the callbacks that start
+    // while it runs blend sample by sample until the ramp ends (:394-540).  The bypass reads at the present latency
+    // (:141-145).  Ranges of the call between the callbacks where some stream starts a fade go to one launch each.
+    const int cbs = n / e->B;
+    const int xTotal = std::max(1, (int)(e->sampleRate * 0.02 + 0.5));
+    struct Range { int c0, c1; };
+    std::vector<Range> ranges;
+    std::vector<int> dNew, dOld, xLen;
+    std::vector<std::vector<double>> xg;          // per range: [S][len]
     {
+        std::vector<char> starts((size_t)cbs, 0);
+        // pass 1: where do fades start (needs the per-stream replay, so replay on copies)
+        if (!e->procBypassed) {
+            for (int s = 0; s < S; ++s) {
+                auto f = e->latFade[s];
+                const double total = (double)procDelayOf(e, s);
+                if (!f.primed || firstCall) {             // prepareToPlay: latency + irLatency, fade gain at 1 (Lifecycle.cpp:377-388)
+                    f.latCurrent = f.latTarget = f.oldDelay = (double)std::min(e->B + std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152), 2097152 + 524288);
+                    f.current = f.target = 1.0; f.remaining = 0; f.primed = true;
+                }
+                for (int t = 0; t < cbs; ++t) {
+                    if (std::fabs(f.latTarget - total) >= 2.0 && f.remaining <= 0) {
+                        f.oldDelay = f.latCurrent; f.current = 0.0; f.target = 1.0; f.step = 1.0 / (double)xTotal; f.remaining = xTotal;
+                        f.latTarget = total;
+                        if (t > 0) starts[t] = 1;
+                    }
+                    if (f.remaining > 0) {
+                        f.remaining = std::max(0, f.remaining - e->B);
+                        if (f.remaining <= 0) { f.latCurrent = f.latTarget; f.oldDelay = f.latCurrent; }
+                    }
+                }
+            }
+        }
+        int c0 = 0;
+        for (int t = 1; t <= cbs; ++t)
+            if (t == cbs || starts[t]) { ranges.push_back(Range{ c0, t }); c0 = t; }
+    }
+    const int R = (int)ranges.size();
+    dNew.assign((size_t)R * S, 0); dOld.assign((size_t)R * S, 0); xLen.assign((size_t)R * S, 0);
+    xg.assign(R, std::vector<double>());
+    int cap = 1;
+    for (int s = 0; s < S; ++s) {
+        auto& f = e->latFade[s];
+        const int totalI = procDelayOf(e, s);
+        if (e->procBypassed) {
+            for (int r = 0; r < R; ++r) dNew[(size_t)r * S + s] = dOld[(size_t)r * S + s] = totalI;
+            continue;
+        }
+        if (!f.primed || firstCall) {
+            f.latCurrent = f.latTarget = f.oldDelay = (double)std::min(e->B + std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152), 2097152 + 524288);
+            f.current = f.target = 1.0; f.step = 0.0; f.remaining = 0; f.primed = true;
+        }
+        for (int r = 0; r < R; ++r) {
+            std::vector<double> vals;
+            bool fading = false;
+            for (int t = ranges[r].c0; t < ranges[r].c1; ++t) {
+                if (std::fabs(f.latTarget - (double)totalI) >= 2.0 && f.remaining <= 0) {
+                    f.oldDelay = f.latCurrent;
+                    f.current = 0.0; f.target = 1.0;                     // applyImmediateValueRT(0), setTargetValue(1)
+                    f.step = (f.target - f.current) / (double)xTotal;
+                    f.remaining = xTotal;
+                    f.latTarget = (double)totalI;
+                }
+                if (t == ranges[r].c0) {
+                    fading = f.remaining > 0;
+                    dNew[(size_t)r * S + s] = fading ? (int)f.latTarget : (int)(f.latCurrent + 0.5);
+                    dOld[(size_t)r * S + s] = (int)f.oldDelay;
+                }
+                if (f.remaining > 0) {
+                    for (int i = 0; i < e->B; ++i) {                     // getNextValue until the ramp has ended
+                        f.current += f.step;
+                        if (--f.remaining <= 0) f.current = f.target;
+                        vals.push_back(f.current);
+                        if (f.remaining <= 0) break;
+                    }
+                    if (f.remaining <= 0) { f.latCurrent = f.latTarget; f.oldDelay = f.latCurrent; }
+                }
+            }
+            xLen[(size_t)r * S + s] = (int)vals.size();
+            cap = std::max(cap, (int)vals.size());
+            if (!vals.empty()) {
+                if (xg[r].empty()) xg[r].assign((size_t)S * (xTotal + e->B), 0.0);
+                std::memcpy(&xg[r][(size_t)s * (xTotal + e->B)], vals.data(), sizeof(double) * vals.size());
+            }
+        }
+    }
+    if (cap > 1 && e->latCap < xTotal + e->B) {
+        if (e->latGains) (void)hipFree(e->latGains);
+        e->latGains = nullptr;
+        e->latCap = 0;
+        if (hipMalloc((void**)&e->latGains, sizeof(double) * (size_t)S * (xTotal + e->B)) != hipSuccess)
+            return fail(e, CPQ_ERR_OOM, "latency cross-fade buffer could not be allocated");
+        e->latCap = xTotal + e->B;
+    }
+    for (int r = 0; r < R; ++r) {
+        const int off = ranges[r].c0 * e->B, len = (ranges[r].c1 - ranges[r].c0) * e->B;
+        const bool fade = !xg[r].empty();
+        const std::vector<int> rn(dNew.begin() + (size_t)r * S, dNew.begin() + (size_t)(r + 1) * S);
+        const std::vector<int> ro(dOld.begin() + (size_t)r * S, dOld.begin() + (size_t)(r + 1) * S);
+        if (rn != e->latNewHost) {
+            CPQ_HIP(e, hipMemcpyAsync(e->latNew, rn.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            e->latNewHost = rn;
+        }
+        if (ro != e->latOldHost) {
+            CPQ_HIP(e, hipMemcpyAsync(e->latOld, ro.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            e->latOldHost = ro;
+        }
+        if (fade) {
+            CPQ_HIP(e, hipMemcpyAsync(e->latLen, &xLen[(size_t)r * S], sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            CPQ_HIP(e, hipMemcpyAsync(e->latGains, xg[r].data(), sizeof(double) * xg[r].size(), hipMemcpyHostToDevice, e->stream));
+        }
         ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_convproc_mix(e->stream, wet, dry, dOut, (int64_t)n, e->nCh, n, e->procGains, e->procDelay,
-                                 e->dryHist[e->dryHistSel], e->dryHist[e->dryHistSel ^ 1], e->dryHistCap,
-                                 skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, n);
+        cpq::launch_convproc_mix(e->stream, dOut + off, dOut + off, (int64_t)n, e->nCh, len, e->procGains, e->dryRing,
+                                 e->dryRingSize, pos0 + off, e->latNew, e->latOld, fade ? e->latLen : nullptr, e->latGains,
+                                 e->latCap, skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, n, off);
+        if (fade || R > 1) CPQ_HIP(e, hipStreamSynchronize(e->stream));      // the host vectors are reused / go out of scope
     }
     CPQ_HIP(e, hipGetLastError());
-    e->dryHistSel ^= 1;
     return CPQ_OK;
 }
 

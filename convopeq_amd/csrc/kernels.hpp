@@ -68,13 +68,18 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
                            int nSamples, const double* coef, const int* flags, const double* satGain,
                            double* state, const void* tables);
 
-// Processor-level dry/wet stage (ConvolverProcessor::process steady state): out = sanitize(wet) * wetG + dryDelayed * dryG,
-// dry read `delay[stream]` samples back in (history ++ input); then the history is advanced.
-// gains: [streams][2] = {wetG, dryG}; histOld/histNew: [nCh][histCap] ping-pong.
-void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dryIn, double* out, int64_t chStride,
-                         int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
-                         double* histNew, int histCap, int wetValid, const int* rampLen = nullptr, const double* rampGains = nullptr,
-                         int rampCap = 0);
+// Processor-level dry/wet stage (ConvolverProcessor::process): out = sanitize(wet) * wetG + dryDelayed * dryG over one
+// range of a call.  The dry signal is read from the delay ring ([nCh][ringSize], the call's input already written at
+// absolute position pos0 = position of the range's first sample) dNew[stream] samples back; the first xLen[stream]
+// samples are cross-faded from the delay dOld[stream] with the gains xGains[stream][i] (latency change); gains:
+// [streams][2] = {wetG, dryG}; rampLen / rampGains: per-sample mix gains of the first samples of the CALL (rampOff =
+// offset of this range in the call).
+void launch_convproc_mix(hipStream_t stream, const double* wet, double* out, int64_t chStride, int nCh, int nSamples,
+                         const double* gains, const double* ring, int ringSize, long long pos0, const int* dNew,
+                         const int* dOld, const int* xLen, const double* xGains, int xCap, int wetValid,
+                         const int* rampLen = nullptr, const double* rampGains = nullptr, int rampCap = 0, int rampOff = 0);
+void launch_ring_regrow(hipStream_t stream, const double* oldRing, int oldSize, double* newRing, int newSize, long long end,
+                        int nCh);
 
 // EQ AGC (EQProcessor::processAGC): per-callback-block RMS in the reference's accumulation order, then envelopes /
 // gain per block (one thread per stream) and the linear gain ramp with the reference's incremental-add pattern.

@@ -9,37 +9,40 @@ namespace cpq {
 
 namespace {
 
-__device__ __forceinline__ double dry_at(const double* __restrict__ hist, const double* dryIn, int histCap, int n)
-{
-    // sample index n of the current call, n may be negative (history)
-    return n >= 0 ? dryIn[n] : hist[histCap + n];
-}
-
-__global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, const double* dryIn, double* out,
-                                                      int64_t chStride, int nSamples,
+// One range of a processor-level call.  The dry signal comes from the delay ring (the call's input has been written at
+// absolute position pos0 .. before this kernel runs, so in-place calls need no copy): delayed by dNew[s]; during a
+// latency cross-fade (:394-540) the first xLen[s] samples of the range are new * g + old * (1 - g) with the old delay
+// dOld[s] and the LinearRamp values xGains[s][i] formed on the host (integer delays: the Catmull-Rom branch of the
+// reference's reader is only reached by a fractional delay, which nothing in it produces).
+__global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, double* out, int64_t chStride, int nSamples,
                                                       const double* __restrict__ gains,
-                                                      const int* __restrict__ delay,
-                                                      const double* __restrict__ histOld,
-                                                      double* __restrict__ histNew, int histCap, int wetValid,
-                                                      const int* __restrict__ rampLen,
-                                                      const double* __restrict__ rampGains, int rampCap)
+                                                      const double* __restrict__ ring, int ringMask, long long pos0,
+                                                      const int* __restrict__ dNew, const int* __restrict__ dOld,
+                                                      const int* __restrict__ xLen, const double* __restrict__ xGains,
+                                                      int xCap, int wetValid, const int* __restrict__ rampLen,
+                                                      const double* __restrict__ rampGains, int rampCap, int rampOff)
 {
     const int c = blockIdx.y;
     const int s = c >> 1;
     const double wetG = gains[2 * s], dryG = gains[2 * s + 1];
     // mix smoothing (:591-607, mixSmoothingSmall :611-632): the first rampLen[s] samples of the call carry per-sample
-    // gains (equalPowerSin of the LinearRamp's values, formed on the host)
-    const int nRamp = rampLen ? rampLen[s] : 0;
-    const double* rg = rampGains + (int64_t)s * rampCap * 2;
-    const int d = delay[s];
+    // gains (equalPowerSin of the LinearRamp's values, formed on the host); rampOff = first sample of this range
+    const int nRamp = rampLen ? rampLen[s] - rampOff : 0;
+    const double* rg = rampGains + ((int64_t)s * rampCap + rampOff) * 2;
+    const int dn = dNew[s], dold = dOld[s];
+    const int nx = xLen ? xLen[s] : 0;
+    const double* xg = xGains + (int64_t)s * xCap;
     const double* w = wet + (int64_t)c * chStride;
-    const double* x = dryIn + (int64_t)c * chStride;
     double* o = out + (int64_t)c * chStride;
-    const double* ho = histOld + (int64_t)c * histCap;
-    double* hn = histNew + (int64_t)c * histCap;
+    const double* r = ring + (int64_t)c * (ringMask + 1);
     const int stride = gridDim.x * blockDim.x;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < nSamples; n += stride) {
-        const double dry = dry_at(ho, x, histCap, n - d);
+        double dry = r[(pos0 + n - dn) & ringMask];
+        if (n < nx) {
+            const double old = r[(pos0 + n - dold) & ringMask];
+            const double g = xg[n];
+            dry = (dry * g) + (old * (1.0 - g));
+        }
         if (wetValid) {
             double wv = w[n];
             // isFiniteAndAbsBelowNoLibm(x, 1e300): false for NaN / Inf
@@ -50,9 +53,18 @@ __global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, const d
             o[n] = dry;           // dry-only fast path (:573-585) and bypass (:123-186): plain copy of the delayed input
         }
     }
-    // next history = last histCap samples of (history ++ input)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < histCap; i += stride)
-        hn[i] = dry_at(ho, x, histCap, nSamples - histCap + i);
+}
+
+// a larger delay ring takes over the retained samples of the old one (absolute positions end - oldCap .. end - 1)
+__global__ __launch_bounds__(256) void k_ring_regrow(const double* __restrict__ oldRing, int oldMask, double* __restrict__ newRing,
+                                                     int newMask, long long end)
+{
+    const double* a = oldRing + (int64_t)blockIdx.y * (oldMask + 1);
+    double* b = newRing + (int64_t)blockIdx.y * (newMask + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= oldMask; i += gridDim.x * blockDim.x) {
+        const long long pos = end - 1 - i;
+        b[pos & newMask] = a[pos & oldMask];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -389,16 +401,24 @@ void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const
                        ringSlots - 1, nTail, g1, g2);
 }
 
-void launch_convproc_mix(hipStream_t stream, const double* wet, const double* dryIn, double* out, int64_t chStride,
-                         int nCh, int nSamples, const double* gains, const int* delay, const double* histOld,
-                         double* histNew, int histCap, int wetValid, const int* rampLen, const double* rampGains,
-                         int rampCap)
+void launch_convproc_mix(hipStream_t stream, const double* wet, double* out, int64_t chStride, int nCh, int nSamples,
+                         const double* gains, const double* ring, int ringSize, long long pos0, const int* dNew,
+                         const int* dOld, const int* xLen, const double* xGains, int xCap, int wetValid,
+                         const int* rampLen, const double* rampGains, int rampCap, int rampOff)
 {
-    const int work = nSamples > histCap ? nSamples : histCap;
-    int bx = (work + 255) / 256;
+    if (nSamples <= 0) return;
+    int bx = (nSamples + 255) / 256;
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(k_convproc_mix, dim3(bx, nCh), dim3(256), 0, stream, wet, dryIn, out, chStride, nSamples, gains,
-                       delay, histOld, histNew, histCap, wetValid, rampLen, rampGains, rampCap);
+    hipLaunchKernelGGL(k_convproc_mix, dim3(bx, nCh), dim3(256), 0, stream, wet, out, chStride, nSamples, gains, ring,
+                       ringSize - 1, pos0, dNew, dOld, xLen, xGains, xCap, wetValid, rampLen, rampGains, rampCap, rampOff);
+}
+
+void launch_ring_regrow(hipStream_t stream, const double* oldRing, int oldSize, double* newRing, int newSize, long long end,
+                        int nCh)
+{
+    int bx = (oldSize + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_ring_regrow, dim3(bx, nCh), dim3(256), 0, stream, oldRing, oldSize - 1, newRing, newSize - 1, end);
 }
 
 static dim3 rowsGrid(int n, int nCh) { int bx = (n + 255) / 256; if (bx > 64) bx = 64; if (bx < 1) bx = 1; return dim3(bx, nCh); }

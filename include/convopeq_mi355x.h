@@ -236,7 +236,12 @@ int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan);
  * A mix change after the first processor-level call is smoothed like the reference's mixSmoother (LinearRamp over
  * smoothing_time_sec, per-sample gains equalPowerSin(mix_i) / equalPowerSin(1 - mix_i) for every callback that starts
  * while the ramp runs, :340-375, :591-607); before it (and after cpq_engine_prepare) the mix applies at once, as
- * prepareToPlay sets it.  The latency crossfade (:393-547) of a live IR swap is not reproduced.
+ * prepareToPlay sets it.  The latency compensation follows :263-290 and :394-540: the dry delay line is a ring that
+ *   remembers B + max_ir_len samples (more when a larger ir_peak_latency is set); a total latency that moves by >= 2
+ *   samples on a live stream is cross-faded over 20 ms from the delay in use (a move of one sample is not followed, as in
+ *   the reference), a move during a running fade waits for its end; processing starts from latency + irLatency
+ *   (Lifecycle.cpp:377-388), so with the direct head the first 20 ms fade from B + ir_peak_latency to ir_peak_latency.
+ *   The reader's Catmull-Rom branch needs a fractional delay, which nothing in the reference produces: not built.
  * mix / ir_peak_latency may differ per stream; bypassed and mix <= 0.001 must be set for CPQ_ALL_STREAMS. */
 typedef struct {
     float   mix;                 /* 0..1, default 1 (src/ConvolverProcessor.h:950) */

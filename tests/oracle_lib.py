@@ -414,6 +414,62 @@ def convproc_mix_schedule(ir, x, block, mix_per_callback, sr=48000.0, smoothing_
     return out
 
 
+def convproc_latency_schedule(ir, x, block, peak_per_callback, mix=0.6, sr=48000.0, direct_head=False):
+    """ConvolverProcessor::process for ONE channel while irPeakLatency changes between callbacks: the latency compensation
+    of src/convolver/ConvolverProcessor.Runtime.cpp:263-290 (a total latency that moved by >= 2 samples starts, unless
+    one is running, a 20 ms cross-fade from the delay in use to the new one) and :394-540 (callbacks that start while
+    crossfadeGain runs read the delay line at both delays and blend new * g + old * (1 - g) until the ramp ends).
+    prepareToPlay starts from latency + irLatency (Lifecycle.cpp:377-388)."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(x)
+    assert n == block * len(peak_per_callback)
+    nuc = Nuc()
+    assert nuc.set_impulse(ir, block, direct=direct_head)
+    wet = nuc.run(x, block)
+    nuc.close()
+    wet = np.where(~(np.abs(wet) < 1.0e300), 0.0, wet)
+    mixd = float(np.float32(mix))
+    wg = L.orc_equal_power_sin(mixd) * 1.0
+    dg = L.orc_equal_power_sin(1.0 - mixd) if mixd < 0.999 else 0.0
+
+    def dry_at(i, d):
+        j = i - int(d)
+        return x[j] if j >= 0 else 0.0
+
+    lat_cur = lat_tgt = old = float(block + peak_per_callback[0])
+    fade = LinearRamp(1.0, sr, 0.02)
+    out = np.empty(n)
+    for cb, peak in enumerate(peak_per_callback):
+        total = float((0 if direct_head else block) + peak)
+        if abs(lat_tgt - total) >= 2.0 and fade.remaining <= 0:
+            old = lat_cur
+            fade.current = fade.target = 0.0
+            fade.set_target(1.0)
+            lat_tgt = total
+        lo = cb * block
+        dry = np.empty(block)
+        if fade.remaining > 0:
+            k = 0
+            while k < block:
+                g = fade.next()
+                dry[k] = dry_at(lo + k, lat_tgt) * g + dry_at(lo + k, old) * (1.0 - g)
+                k += 1
+                if fade.remaining <= 0:
+                    break
+            for i in range(k, block):
+                dry[i] = dry_at(lo + i, lat_tgt)
+            if fade.remaining <= 0:
+                lat_cur = lat_tgt
+                old = lat_cur
+        else:
+            d = int(lat_cur + 0.5)
+            for i in range(block):
+                dry[i] = dry_at(lo + i, d)
+        out[lo:lo + block] = (wet[lo:lo + block] * wg) + (dry * dg)
+    return out
+
+
 def outfilter_design(conv_is_last, hc_mode=1, lc_mode=0, lp_mode=1, sr=48000.0):
     out = (Biquad * 3)()
     lib().orc_outfilter_design(int(conv_is_last), hc_mode, lc_mode, lp_mode, sr, out)

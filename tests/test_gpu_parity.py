@@ -1172,3 +1172,66 @@ def test_dspcore_routing_gains_and_bypasses(amd, oracle):
         for ch in range(2):
             err = np.abs(y[2 * s + ch] - ref[ch]).max()
             assert err <= 2e-13, (s, ch, err)
+
+
+def test_processor_level_latency_crossfade(amd, oracle):
+    """SURVEY N1 transitions: irPeakLatency changing on a live stream.  The dry path cross-fades over 20 ms from the
+    delay in use to the new one; a change of one sample is below the reference's 2-sample threshold and is not followed;
+    a change that arrives while a fade runs waits for its end (here: in the middle of a call); in-place device calls
+    (the delay ring has the input before the convolver overwrites it)."""
+    import torch
+    O = oracle
+    S, T = 2, 3
+    n = T * B
+    irs = [O.gen_ir(2000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    # ir_peak_latency per call; stream 1 moves while stream 0 rests.  Calls are 3 callbacks long except where noted: a
+    # one-callback call starts a fade and the next call already carries another latency -- it has to wait for the end of
+    # the running fade, which comes inside that call's first callback, so the new fade starts at its second callback.
+    peaks = [[100, 100, 700, 700, 701, 701, 40, 40, 40, 40, 40],
+             [0, 0, 0, 1500, 300, 300, 300, 300, 301, 900, 120]]
+    blocks = [3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 3]
+    calls = len(peaks[0])
+    x = make_inputs(O, S, sum(blocks) * B)
+    eng = amd.BatchedEngine(S, max_ir_len=2000, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    outs = []
+    o = 0
+    for k in range(calls):
+        for s in range(S):
+            eng.set_convproc_params(s, mix=0.6, ir_peak_latency=peaks[s][k])
+        m = blocks[k] * B
+        d = torch.from_numpy(np.ascontiguousarray(x[:, o:o + m])).cuda()
+        eng._ck(eng._lib.cpq_convproc_process_device(eng._h, d.data_ptr(), d.data_ptr(), m))
+        torch.cuda.synchronize()
+        outs.append(d.cpu().numpy())
+        o += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    for s in range(S):
+        per_cb = [p for p, nb in zip(peaks[s], blocks) for _ in range(nb)]
+        for ch in range(2):
+            ref = O.convproc_latency_schedule(irs[2 * s + ch], x[2 * s + ch], B, per_cb, mix=0.6)
+            err = np.abs(y[2 * s + ch] - ref).max()
+            assert err <= 1e-13, (s, ch, err)
+
+
+def test_processor_level_direct_head_latency_start(amd, oracle):
+    """With the direct head the processor's algorithm latency is 0 (Runtime.cpp:266) while prepareToPlay starts the
+    latency compensation at latency + irLatency (Lifecycle.cpp:380-383): the first callbacks cross-fade the dry read
+    from block + irPeakLatency to irPeakLatency."""
+    O = oracle
+    T = 4
+    irs = [O.gen_ir(3000, channel=ch) for ch in range(2)]
+    x = make_inputs(O, 1, 3 * T * B)
+    eng = amd.BatchedEngine(1, max_ir_len=3000, max_blocks_per_call=T)
+    eng.set_impulse(0, irs[0], irs[1], direct_head=True)
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=0.5, ir_peak_latency=77)
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    assert eng.convproc_delay(0) == 77
+    y = np.concatenate([eng.convproc_process(x[:, k * T * B:(k + 1) * T * B]) for k in range(3)], axis=1)
+    eng.close()
+    for ch in range(2):
+        ref = O.convproc_latency_schedule(irs[ch], x[ch], B, [77] * (3 * T), mix=0.5, direct_head=True)
+        assert np.abs(y[ch] - ref).max() <= 1e-13
