@@ -148,6 +148,12 @@ struct cpq_engine {
         int mode = 0;                   // what the device tables of the stream hold now: 0 parameters as set,
     };                                  // 1 band nodes of the basic path, 2 pass-through
     std::vector<EqBypass> eqBypass;
+    // requestBandReset (EQProcessor.h; Processing.cpp:595-624): bands whose state is cleared at the first callback where
+    // that is safe -- the block is silent, or a bypass fade is running
+    std::vector<uint32_t> eqResetPending;
+    bool anyEqReset = false;
+    int* silentDev = nullptr;           // [streams][callbacks]
+    int* silentHost = nullptr;          // pinned
     bool anyEqBypass = false;           // some stream is not in the plain "never bypassed" state
     // DSPCore block routing (src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:384-470)
     std::vector<double> trimHost, makeupHost;   // per stream: convolverInputTrimGain (EQ -> conv order), outputMakeupGain
@@ -567,6 +573,8 @@ int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t strid
 void syncEqBypass(cpq_engine* e)
 {
     e->anyEqBypass = false;
+    std::fill(e->eqResetPending.begin(), e->eqResetPending.end(), 0u);      // the caller zeroes every state anyway
+    e->anyEqReset = false;
     for (auto& b : e->eqBypass) {
         b.effective = b.requested;
         b.current = b.target = b.requested ? 0.0 : 1.0;
@@ -764,11 +772,13 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
     const int n = T * e->P;
     const int S = e->desc.n_streams;
-    if (!e->anyEqBypass) { e->eqProcessed = true; return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr); }
+    if (!e->anyEqBypass && !e->anyEqReset) { e->eqProcessed = true; return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr); }
     const int cbs = n / e->B;
     const int total = std::max(1, (int)(e->sampleRate * 0.005 + 0.5));       // BYPASS_FADE_TIME_SEC (EQProcessor.h:564)
     enum : char { kNormal = 0, kFade = 1, kPass = 2 };
-    std::vector<char> cls((size_t)S * cbs, kNormal), reset((size_t)S * cbs, 0);
+    std::vector<char> cls((size_t)S * cbs, kNormal);
+    std::vector<uint32_t> reset((size_t)S * cbs, 0u);           // bands cleared at the start of the callback
+    std::vector<char> released((size_t)S * cbs, 0);             // the bypass is released here: every band is to be cleared
     std::vector<std::vector<double>> gains(S);          // fade values of a stream's kFade callbacks, in order
     bool stillActive = false;
     for (int s = 0; s < S; ++s) {
@@ -776,7 +786,7 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         for (int t = 0; t < cbs; ++t) {
             const double want = b.requested ? 0.0 : 1.0;
             if (std::fabs(b.target - want) > 1.0e-12) {
-                if (!b.requested && b.effective) { reset[(size_t)s * cbs + t] = 1; b.effective = false; }
+                if (!b.requested && b.effective) { released[(size_t)s * cbs + t] = 1; b.effective = false; }
                 if (want != b.target) {                                       // LinearRamp::setTargetValue
                     b.target = want;
                     const int steps = b.remaining > 0 ? b.remaining : total;
@@ -798,6 +808,45 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         }
         stillActive = stillActive || b.requested || b.effective || b.remaining > 0 || b.mode != 0;
     }
+    // pending band resets: at the first callback that is fading (canSafelyResetState, :565-568) or whose input block is
+    // silent; a fully bypassed callback returns before it gets there.  Silence is only known on the device: one small
+    // kernel, one read-back and ONE stream synchronisation per call while a reset waits on a stream that is playing.
+    {
+        bool needSilence = false;
+        for (int s = 0; s < S && !needSilence; ++s) {
+            if (!e->eqResetPending[s]) continue;
+            for (int t = 0; t < cbs; ++t) {
+                if (cls[(size_t)s * cbs + t] == kFade) break;
+                if (cls[(size_t)s * cbs + t] == kNormal) { needSilence = true; break; }
+            }
+        }
+        if (needSilence) {
+            const size_t cbMax = (size_t)e->tMax * e->P / e->B;
+            if (!e->silentDev) {
+                if (hipMalloc((void**)&e->silentDev, sizeof(int) * S * cbMax) != hipSuccess ||
+                    hipHostMalloc((void**)&e->silentHost, sizeof(int) * S * cbMax) != hipSuccess)
+                    return fail(e, CPQ_ERR_OOM, "silence flags could not be allocated");
+            }
+            cpq::launch_block_silence(e->stream, dIn, (int64_t)n, e->B, cbs, S, e->silentDev);
+            CPQ_HIP(e, hipMemcpyAsync(e->silentHost, e->silentDev, sizeof(int) * (size_t)S * cbs, hipMemcpyDeviceToHost, e->stream));
+            CPQ_HIP(e, hipStreamSynchronize(e->stream));
+        }
+        e->anyEqReset = false;
+        for (int s = 0; s < S; ++s) {
+            uint32_t pending = e->eqResetPending[s];
+            for (int t = 0; t < cbs; ++t) {
+                if (released[(size_t)s * cbs + t]) pending = 0xFFFFFFFFu;
+                if (!pending) continue;
+                const char k = cls[(size_t)s * cbs + t];
+                if (k == kFade || (k == kNormal && needSilence && e->silentHost[(size_t)s * cbs + t])) {
+                    reset[(size_t)s * cbs + t] = pending;
+                    pending = 0u;
+                }
+            }
+            e->eqResetPending[s] = pending;
+            e->anyEqReset = e->anyEqReset || pending != 0u;
+        }
+    }
     e->eqProcessed = true;
     std::vector<char> pass(S);
     std::vector<int> onHost(S), lenHost(S);
@@ -818,8 +867,15 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         int cap = 1;
         for (int s = 0; s < S && rc == CPQ_OK; ++s) {
             const char k = cls[(size_t)s * cbs + c0];
-            if (reset[(size_t)s * cbs + c0])       // every band of the stream, Mid / Side states included
+            const uint32_t mask = reset[(size_t)s * cbs + c0];
+            if (mask == 0xFFFFFFFFu) {             // every band of the stream, Mid / Side states included
                 CPQ_HIP(e, hipMemsetAsync(e->svfState + (size_t)s * 2 * kBands * 2, 0, sizeof(double) * 2 * kBands * 2, e->stream));
+            } else if (mask) {
+                for (int b = 0; b < kBands; ++b)
+                    if (mask & (1u << b))
+                        for (int ch = 0; ch < 2; ++ch)
+                            CPQ_HIP(e, hipMemsetAsync(e->svfState + ((size_t)(2 * s + ch) * kBands + b) * 2, 0, sizeof(double) * 2, e->stream));
+            }
             rc = setEqStreamMode(e, s, k == kPass ? 2 : k == kFade ? 1 : 0);
             pass[s] = k == kPass;
             onHost[s] = k == kFade;
@@ -1182,6 +1238,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->eqParamsHost.assign(d->n_streams, cpq_eq_params{});
     e->eqParamsSet.assign(d->n_streams, 0);
     e->eqBypass.assign(d->n_streams, cpq_engine::EqBypass{});
+    e->eqResetPending.assign(d->n_streams, 0u);
     e->latFade.assign(d->n_streams, cpq_engine::LatencyFade{});
     e->trimHost.assign(d->n_streams, 1.0);
     e->makeupHost.assign(d->n_streams, 1.0);
@@ -1226,6 +1283,8 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->procDelay) (void)hipFree(e->procDelay);
     for (int* p : { e->latNew, e->latOld, e->latLen }) if (p) (void)hipFree(p);
     if (e->eqDry) (void)hipFree(e->eqDry);
+    if (e->silentDev) (void)hipFree(e->silentDev);
+    if (e->silentHost) (void)hipHostFree(e->silentHost);
     if (e->trimDev) (void)hipFree(e->trimDev);
     if (e->makeupDev) (void)hipFree(e->makeupDev);
     if (e->blendOn) (void)hipFree(e->blendOn);
@@ -2004,6 +2063,22 @@ int32_t cpq_eq_set_bypass(cpq_engine* e, int32_t stream, int32_t bypassed)
     }
     e->anyEqBypass = false;
     for (const auto& b : e->eqBypass) e->anyEqBypass = e->anyEqBypass || b.requested || b.effective || b.remaining > 0 || b.mode != 0;
+    return CPQ_OK;
+}
+
+int32_t cpq_eq_request_band_reset(cpq_engine* e, int32_t stream, uint32_t bandMask)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    // requestBandReset(-1) asks for every band (mask 0xFFFFFFFF); single bands keep only the 20 real bits
+    const uint32_t m = bandMask == 0xFFFFFFFFu ? bandMask : (bandMask & ((1u << kBands) - 1u));
+    for (int s = s0; s < s1; ++s) {
+        e->eqResetPending[s] |= m;
+        e->anyEqReset = e->anyEqReset || e->eqResetPending[s] != 0u;
+    }
     return CPQ_OK;
 }
 

@@ -114,6 +114,8 @@ void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int
 // EQ bypass cross-fade for the streams flagged in `on`: out = out * g + dry * (1 - g); g = gains[s][i] for i < len[s], gEnd[s] after
 void launch_bypass_blend(hipStream_t stream, double* out, int64_t outStride, const double* dry, int64_t dryStride, int n,
                          int nCh, const int* on, const int* len, const double* gEnd, const double* gains, int cap);
+// silent[stream][callback] = no sample of the stream's two channels above 1e-8 in that callback block
+void launch_block_silence(hipStream_t stream, const double* x, int64_t chStride, int B, int T, int S, int* silent);
 // data[c][i] *= gain[c / 2] (streams with gain exactly 1 are left alone)
 void launch_rows_scale(hipStream_t stream, double* data, int64_t stride, int n, int nCh, const double* gain);
 

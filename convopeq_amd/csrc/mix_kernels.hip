@@ -349,6 +349,23 @@ __global__ __launch_bounds__(256) void k_bypass_blend(double* out, int64_t outSt
     }
 }
 
+// isAudioBlockSilent (src/eqprocessor/EQProcessor.Processing.cpp:460-475) per (stream, callback): 1 when no sample of
+// either channel exceeds 1e-8 in magnitude.  One wave per (stream, callback).
+__global__ __launch_bounds__(64) void k_block_silence(const double* __restrict__ x, int64_t chStride, int B, int T, int S,
+                                                      int* __restrict__ silent)
+{
+    const int idx = blockIdx.x;
+    if (idx >= S * T) return;
+    const int s = idx / T, t = idx - s * T;
+    int loud = 0;
+    for (int ch = 0; ch < 2; ++ch) {
+        const double* p = x + (int64_t)(2 * s + ch) * chStride + (int64_t)t * B;
+        for (int i = threadIdx.x; i < B; i += 64) loud |= (fabs(p[i]) > 1.0e-8) ? 1 : 0;
+    }
+    const unsigned long long any = __ballot(loud);
+    if (threadIdx.x == 0) silent[idx] = any == 0ull ? 1 : 0;
+}
+
 // data[c][i] *= gain[stream] for the streams whose gain is not exactly 1 (scaleBlockFallback,
 // src/audioengine/AudioEngine.Processing.DSPCoreDouble.cpp:93-105)
 __global__ __launch_bounds__(256) void k_rows_scale(double* data, int64_t stride, int n, const double* __restrict__ gain)
@@ -436,6 +453,12 @@ void launch_bypass_blend(hipStream_t stream, double* out, int64_t outStride, con
     if (n <= 0) return;
     hipLaunchKernelGGL(k_bypass_blend, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, dry, dryStride, n, on, len,
                        gEnd, gains, cap);
+}
+
+void launch_block_silence(hipStream_t stream, const double* x, int64_t chStride, int B, int T, int S, int* silent)
+{
+    if (S * T <= 0) return;
+    hipLaunchKernelGGL(k_block_silence, dim3(S * T), dim3(64), 0, stream, x, chStride, B, T, S, silent);
 }
 
 void launch_rows_scale(hipStream_t stream, double* data, int64_t stride, int n, int nCh, const double* gain)

@@ -199,6 +199,9 @@ class BatchedEngine:
     def set_conv_bypass(self, bypassed):
         self._ck(self._lib.cpq_engine_set_conv_bypass(self._h, int(bypassed)))
 
+    def request_band_reset(self, stream, band_mask=0xFFFFFFFF):
+        self._ck(self._lib.cpq_eq_request_band_reset(self._h, stream, band_mask))
+
     def set_eq_bypass(self, stream, bypassed):
         self._ck(self._lib.cpq_eq_set_bypass(self._h, stream, int(bypassed)))
 

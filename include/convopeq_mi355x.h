@@ -275,6 +275,13 @@ int32_t cpq_eq_process_device(cpq_engine* e, const double* d_in, double* d_out, 
  * stream does nothing (filter states, total-gain ramp and AGC frozen); releasing the bypass clears the stream's filter
  * states and fades back in.  Before the first call (and at prepare / reset) the state follows the request at once. */
 int32_t cpq_eq_set_bypass(cpq_engine* e, int32_t stream, int32_t bypassed);
+/* replaces EQProcessor::requestBandReset (src/eqprocessor/EQProcessor.h; consumed in process(),
+ * src/eqprocessor/EQProcessor.Processing.cpp:1083-1112 / :595-624): the filter states of the bands in band_mask (bit b =
+ * band b; 0xFFFFFFFF = all, Mid / Side states included) are cleared at the start of the first callback whose input
+ * block is silent (no sample above 1e-8, isAudioBlockSilent :460-475) or that runs a bypass fade; until then the request
+ * stays pending.  While a request is pending on a playing stream each EQ call synchronises the engine's stream once
+ * (the silence flags are read back); without a pending request nothing changes. */
+int32_t cpq_eq_request_band_reset(cpq_engine* e, int32_t stream, uint32_t band_mask);
 /* EQ kernel choice.  AUTO: time-parallel kernel (per band: zero-state chunk runs + state scan; equal to the
  * sequential recurrence up to rounding, measured <= 3e-15) whenever the host can prove the reference's state
  * guards cannot trip, else the sequential kernel.  SEQUENTIAL: lane-skewed kernel that reproduces the

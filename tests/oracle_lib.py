@@ -307,14 +307,17 @@ class EqWithBypass:
         self.state = np.zeros(168)
         self.fade = LinearRamp(1.0, sr, 0.005)
         self.effective = False
+        self.pending = 0                                    # rtDeferredBandResetMask
+
+    def request_band_reset(self, mask=0xFFFFFFFF):
+        self.pending |= mask
 
     def callback(self, xl, xr, requested):
         L = lib()
         target = 0.0 if requested else 1.0
         if abs(self.fade.target - target) > 1.0e-12:
             if not requested and self.effective:
-                self.state[0:80] = 0.0                      # deferred reset of all bands: canSafelyResetState holds
-                self.state[88:168] = 0.0                    # (a transition is active), so it happens in this callback
+                self.pending |= 0xFFFFFFFF                  # deferred reset of all bands (:507-511)
                 self.effective = False
             self.fade.set_target(target)
         transition = self.fade.remaining > 0
@@ -323,6 +326,19 @@ class EqWithBypass:
         if requested and self.effective and not transition:
             return xl.copy(), xr.copy()
         basic = requested or self.effective or transition
+        if self.pending:                                    # :565-568, :603-624 (parameter path: silence only, :1083-1112)
+            silent = not (np.any(np.abs(xl) > 1.0e-8) or np.any(np.abs(xr) > 1.0e-8))
+            if basic or silent:
+                st = self.state
+                if self.pending == 0xFFFFFFFF:
+                    st[0:80] = 0.0
+                    st[88:168] = 0.0
+                else:
+                    for b in range(20):
+                        if self.pending & (1 << b):
+                            for base in (0, 40, 88, 128):   # L, R, Mid, Side
+                                st[base + 2 * b:base + 2 * b + 2] = 0.0
+                self.pending = 0
         yl, yr = xl.copy(), xr.copy()
         L.orc_eq_process_stereo_ex(dp(yl), dp(yr), len(yl), self.block, C.byref(self.p), self.sr, dp(self.state),
                                    int(basic))

@@ -1235,3 +1235,64 @@ def test_processor_level_direct_head_latency_start(amd, oracle):
     for ch in range(2):
         ref = O.convproc_latency_schedule(irs[ch], x[ch], B, [77] * (3 * T), mix=0.5, direct_head=True)
         assert np.abs(y[ch] - ref).max() <= 1e-13
+
+
+@pytest.mark.parametrize("eq_mode", ["seq", "auto"])
+def test_eq_band_reset_waits_for_silence(amd, oracle, eq_mode):
+    """SURVEY N4 (band-reset handshake): requestBandReset is deferred until a callback whose input block is silent
+    (every sample <= 1e-8 in magnitude; a block of 1e-9 noise counts, one sample of 2e-8 does not), single bands and all
+    bands, a request that stays pending across calls, and a request consumed by a bypass fade instead."""
+    O = oracle
+    S, T, calls = 2, 4, 8
+    n = T * B
+    po = O.eq_params_bench(0.2)
+    x = make_inputs(O, S, calls * n)
+    rng = np.random.default_rng(2)
+    # stream 0: callback 9 (call 2, t = 1) almost silent but one sample at 2e-8; callback 14 (call 3, t = 2) 1e-9 noise
+    x[0:2, 9 * B:10 * B] = rng.standard_normal((2, B)) * 1e-9
+    x[1, 9 * B + 17] = 2e-8
+    x[0:2, 14 * B:15 * B] = rng.standard_normal((2, B)) * 1e-9
+    # stream 1: callback 5 (call 1, t = 1) exactly zero
+    x[2:4, 5 * B:6 * B] = 0.0
+    eng = amd.BatchedEngine(S, max_ir_len=B, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    if eq_mode == "seq":
+        eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    req = [[0] * calls, [0, 0, 0, 0, 0, 1, 0, 0]]               # stream 1: bypass engaged in call 5, released in call 6
+    outs = []
+    for k in range(calls):
+        if k == 1:
+            eng.request_band_reset(0, (1 << 3) | (1 << 17))
+            eng.request_band_reset(1)
+        if k == 5:
+            eng.request_band_reset(1, 1 << 7)                   # consumed by the fade-out callback
+        eng.set_eq_bypass(1, req[1][k])
+        outs.append(eng.eq_process(x[:, k * n:(k + 1) * n]))
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    tol = 0.0 if eq_mode == "seq" else 2e-14
+    for s in range(S):
+        rl, rr = [], []
+        # the same requests at the same calls
+        ref = O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B)
+        for k in range(calls):
+            if k == 1:
+                ref.request_band_reset((1 << 3) | (1 << 17) if s == 0 else 0xFFFFFFFF)
+            if k == 5 and s == 1:
+                ref.request_band_reset(1 << 7)
+            for t in range(T):
+                o = (k * T + t) * B
+                a, b = ref.callback(x[2 * s, o:o + B].copy(), x[2 * s + 1, o:o + B].copy(), bool(req[s][k]))
+                rl.append(a)
+                rr.append(b)
+            if s == 0:
+                assert (ref.pending != 0) == (1 <= k <= 2), k          # fires at callback 14, not at 9
+            else:
+                assert ref.pending == 0, k                             # zero block in call 1; the fade in call 5
+        rl, rr = np.concatenate(rl), np.concatenate(rr)
+        err = max(np.abs(y[2 * s] - rl).max(), np.abs(y[2 * s + 1] - rr).max())
+        assert err <= tol, (s, err)
+    # the reset is audible: without it the output after callback 14 differs
+    plain = O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B)
+    pl = np.concatenate([plain.callback(x[0, c * B:(c + 1) * B].copy(), x[1, c * B:(c + 1) * B].copy(), False)[0] for c in range(16)])
+    assert np.abs(pl[15 * B:16 * B] - y[0, 15 * B:16 * B]).max() > 1e-9
