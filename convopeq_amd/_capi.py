@@ -29,6 +29,9 @@ CPQ_LEVEL_NUC = 0
 CPQ_LEVEL_PROCESSOR = 1
 CPQ_EQ_MODE_AUTO = 0
 CPQ_EQ_MODE_SEQUENTIAL = 1
+CPQ_PHASE_AS_IS = 0
+CPQ_PHASE_MIXED = 1
+CPQ_PHASE_MINIMUM = 2
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -147,7 +150,8 @@ SYMBOLS = {
     "cpq_engine_process_block_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
     "cpq_ir_load_wav": (C.c_int32, [C.c_char_p, C.POINTER(IrBuffer)]),
     "cpq_ir_buffer_free": (None, [C.POINTER(IrBuffer)]),
-    "cpq_ir_prepare": (C.c_int32, [C.POINTER(IrBuffer), C.c_double, C.c_float, C.POINTER(IrBuffer), C.c_double, C.POINTER(IrPrepared)]),
+    "cpq_ir_prepare": (C.c_int32, [C.POINTER(IrBuffer), C.c_double, C.c_float, C.c_int32, C.POINTER(IrBuffer), C.c_double, C.POINTER(IrPrepared)]),
+    "cpq_ir_convert_to_minimum_phase": (C.c_int32, [C.POINTER(IrBuffer), C.POINTER(IrBuffer)]),
     "cpq_ir_prepared_free": (None, [C.POINTER(IrPrepared)]),
     "cpq_ir_compute_scale_factor": (C.c_int32, [C.POINTER(c_double_p), C.c_int32, C.c_int32, C.POINTER(c_double_p), C.c_int32, C.c_int32, C.c_double, C.POINTER(IrScale)]),
     "cpq_ir_estimate_max_frequency_response_gain": (C.c_double, [C.POINTER(c_double_p), C.c_int32, C.c_int32]),

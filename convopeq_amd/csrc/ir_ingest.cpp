@@ -14,7 +14,8 @@
 //   * scale factor                           src/IRConverter.cpp:17-196, src/IRAnalyzer.cpp:63-155
 //   * peak latency (energy centroid)         LoaderThread.cpp:149-209
 // Not restated: sample-rate conversion (third-party r8brain, not in the reference tree) -- an IR at another rate is
-// refused with CPQ_ERR_UNSUPPORTED -- and the minimum / mixed phase transforms (PhaseMode::AsIs only).
+// refused with CPQ_ERR_UNSUPPORTED -- and the mixed phase transform (PhaseMode::AsIs and Minimum only).
+//   * minimum phase                          src/convolver/ConvolverProcessor.ResampleAndFallback.cpp:333-469
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -247,40 +248,84 @@ void asymmetricTukey(double* x, int n)
 }
 
 // ---------------------------------------------------------------------------------------------- analysis
-// magnitudes |X[0..N/2]| of a real sequence (N a power of two): iterative radix-2 transform with exact per-index twiddles
+// in-place complex FFT, N a power of two: iterative radix-2 with exact per-index twiddles; inverse scales by 1 / N
+void fftInPlace(std::vector<std::complex<double>>& a, bool inverse)
+{
+    const size_t N = a.size();
+    int lg = 0;
+    while (((size_t)1 << lg) < N) ++lg;
+    for (size_t i = 0; i < N; ++i) {
+        size_t r = 0;
+        for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1u) << (lg - 1 - b);
+        if (r > i) std::swap(a[i], a[r]);
+    }
+    std::vector<std::complex<double>> tw(std::max<size_t>(1, N / 2));
+    for (size_t k = 0; k < N / 2; ++k) {
+        const double ang = (inverse ? 2.0 : -2.0) * kPi * (double)k / (double)N;
+        tw[k] = std::complex<double>(std::cos(ang), std::sin(ang));
+    }
+    for (size_t half = 1; half < N; half <<= 1) {
+        const size_t stride = N / (2 * half);
+        for (size_t base = 0; base < N; base += 2 * half)
+            for (size_t j = 0; j < half; ++j) {
+                const auto w = tw[j * stride];
+                const auto& hi = a[base + j + half];
+                const std::complex<double> t(w.real() * hi.real() - w.imag() * hi.imag(),
+                                             w.real() * hi.imag() + w.imag() * hi.real());
+                const auto u = a[base + j];
+                a[base + j] = u + t;
+                a[base + j + half] = u - t;
+            }
+    }
+    if (inverse) {
+        const double inv = 1.0 / (double)N;
+        for (auto& v : a) v = std::complex<double>(v.real() * inv, v.imag() * inv);
+    }
+}
+
+// magnitudes |X[0..N/2]| of a real sequence (N a power of two)
 void magnitudeSpectrum(const std::vector<double>& x, int N, std::vector<double>& mags)
 {
     std::vector<std::complex<double>> a((size_t)N);
-    int lg = 0;
-    while ((1 << lg) < N) ++lg;
-    for (int i = 0; i < N; ++i) {
-        unsigned r = 0;
-        for (int b = 0; b < lg; ++b) r |= ((unsigned)(i >> b) & 1u) << (lg - 1 - b);
-        a[r] = std::complex<double>(x[(size_t)i], 0.0);
-    }
-    std::vector<std::complex<double>> tw((size_t)std::max(1, N / 2));
-    for (int k = 0; k < N / 2; ++k) {
-        const double ang = -2.0 * kPi * (double)k / (double)N;
-        tw[(size_t)k] = std::complex<double>(std::cos(ang), std::sin(ang));
-    }
-    for (int half = 1; half < N; half <<= 1) {
-        const int stride = N / (2 * half);
-        for (int base = 0; base < N; base += 2 * half)
-            for (int j = 0; j < half; ++j) {
-                const auto w = tw[(size_t)(j * stride)];
-                const auto& hi = a[(size_t)(base + j + half)];
-                const std::complex<double> t(w.real() * hi.real() - w.imag() * hi.imag(),
-                                             w.real() * hi.imag() + w.imag() * hi.real());
-                const auto u = a[(size_t)(base + j)];
-                a[(size_t)(base + j)] = u + t;
-                a[(size_t)(base + j + half)] = u - t;
-            }
-    }
+    for (int i = 0; i < N; ++i) a[(size_t)i] = std::complex<double>(x[(size_t)i], 0.0);
+    fftInPlace(a, false);
     mags.resize((size_t)N / 2 + 1);
     mags[0] = std::fabs(a[0].real());
     mags[(size_t)N / 2] = std::fabs(a[(size_t)N / 2].real());
     for (int k = 1; k < N / 2; ++k)
         mags[(size_t)k] = std::sqrt(a[(size_t)k].real() * a[(size_t)k].real() + a[(size_t)k].imag() * a[(size_t)k].imag());
+}
+
+// convertToMinimumPhase (src/convolver/ConvolverProcessor.ResampleAndFallback.cpp:333-469) for one channel: the
+// homomorphic construction -- log magnitude -> real cepstrum -> folded onto the causal side -> exponentiated spectrum --
+// at 4x zero padding.  false: the reference gives up (non-finite intermediate values).
+bool minimumPhase(const double* src, int n, int fftSize, double* dst)
+{
+    std::vector<std::complex<double>> z((size_t)fftSize);
+    for (int i = 0; i < n; ++i) z[(size_t)i] = std::complex<double>(src[i], 0.0);
+    fftInPlace(z, false);
+    for (auto& v : z) v = std::complex<double>(std::log(std::max(std::hypot(v.real(), v.imag()), 1.0e-300)), 0.0);
+    fftInPlace(z, true);
+    const size_t half = (size_t)fftSize / 2;
+    z[0] = std::complex<double>(z[0].real(), 0.0);
+    for (size_t i = 1; i < half; ++i) z[i] = std::complex<double>(z[i].real() * 2.0, 0.0);
+    z[half] = std::complex<double>(z[half].real(), 0.0);
+    for (size_t i = half + 1; i < (size_t)fftSize; ++i) z[i] = std::complex<double>(0.0, 0.0);
+    fftInPlace(z, false);
+    for (auto& v : z) {
+        const double re = std::min(50.0, std::max(-50.0, v.real())), im = std::min(50.0, std::max(-50.0, v.imag()));
+        const double m = std::exp(re);
+        v = std::complex<double>(m * std::cos(im), m * std::sin(im));
+        if (!std::isfinite(v.real()) || !std::isfinite(v.imag())) return false;
+    }
+    fftInPlace(z, true);
+    for (int i = 0; i < n; ++i) {
+        double v = z[(size_t)i].real();
+        if (!std::isfinite(v)) return false;
+        if (std::fabs(v) < 1.0e-18) v = 0.0;
+        dst[i] = v;
+    }
+    return true;
 }
 
 int nextPow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -512,7 +557,25 @@ int32_t cpq_ir_compute_scale_factor(const double* const* ir, int32_t n_channels,
     return CPQ_OK;
 }
 
-int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float target_ir_length_sec,
+int32_t cpq_ir_convert_to_minimum_phase(const cpq_ir_buffer* in, cpq_ir_buffer* out)
+{
+    if (!out) return CPQ_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    if (!validBuffer(in)) return CPQ_ERR_INVALID_ARG;
+    if ((int64_t)in->n_samples * 4 > 8388608) return CPQ_ERR_UNSUPPORTED;      // MAX_MINPHASE_FFT_SIZE: the reference skips it
+    const int fftSize = nextPow2(in->n_samples * 4);
+    if (!allocBuffer(out, in->n_channels, in->n_samples, in->sample_rate)) return CPQ_ERR_OOM;
+    try {
+        for (int ch = 0; ch < in->n_channels; ++ch)
+            if (!minimumPhase(plane(in, ch), in->n_samples, fftSize, plane(out, ch))) {
+                cpq_ir_buffer_free(out);
+                return CPQ_ERR_UNSUPPORTED;
+            }
+    } catch (const std::bad_alloc&) { cpq_ir_buffer_free(out); return CPQ_ERR_OOM; }
+    return CPQ_OK;
+}
+
+int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float target_ir_length_sec, int32_t phase_mode,
                        const cpq_ir_buffer* current_ir, double current_scale, cpq_ir_prepared* out)
 {
     if (!out) return CPQ_ERR_INVALID_ARG;
@@ -522,6 +585,8 @@ int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float ta
     if (!validBuffer(loaded) || !(sample_rate > 0.0) || !std::isfinite(sample_rate) || !(target_ir_length_sec > 0.0f))
         return CPQ_ERR_INVALID_ARG;
     if (current_ir && !validBuffer(current_ir)) return CPQ_ERR_INVALID_ARG;
+    if (phase_mode != CPQ_PHASE_AS_IS && phase_mode != CPQ_PHASE_MINIMUM)
+        return phase_mode == CPQ_PHASE_MIXED ? CPQ_ERR_UNSUPPORTED : CPQ_ERR_INVALID_ARG;
     if (loaded->sample_rate > 0.0 && std::fabs(loaded->sample_rate - sample_rate) > 1e-6)
         return CPQ_ERR_UNSUPPORTED;                               // needs the r8brain resampler
     const double rate = loaded->sample_rate > 0.0 ? loaded->sample_rate : 0.0;
@@ -554,6 +619,24 @@ int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float ta
             double g = 1.0;
             const double inc = (0.0 - 1.0) / (float)fade;
             for (int i = copy - fade; i < copy; ++i) { d[i] *= g; g += inc; }
+        }
+    }
+
+    if (phase_mode == CPQ_PHASE_MINIMUM) {
+        // doTransformStep: the converted IR replaces the trimmed one only when it validates -- finite, peak above 1e-12
+        // (LoaderThread.cpp:652-680); a conversion the reference gives up on leaves the IR as it is
+        cpq_ir_buffer mp;
+        const int32_t rcMp = cpq_ir_convert_to_minimum_phase(&out->ir, &mp);
+        if (rcMp == CPQ_ERR_OOM) { cpq_ir_buffer_free(&out->ir); return rcMp; }
+        if (rcMp == CPQ_OK) {
+            double peak = 0.0;
+            bool finite = true;
+            for (size_t i = 0; i < (size_t)channels * (size_t)target; ++i) {
+                finite = finite && std::isfinite(mp.data[i]);
+                peak = std::max(peak, std::fabs(mp.data[i]));
+            }
+            if (finite && peak > 1.0e-12) std::memcpy(out->ir.data, mp.data, sizeof(double) * (size_t)channels * (size_t)target);
+            cpq_ir_buffer_free(&mp);
         }
     }
 

@@ -98,14 +98,14 @@ def ir_load_wav(path):
         K.load().cpq_ir_buffer_free(C.byref(b))
 
 
-def ir_prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=None, current_scale=1.0):
+def ir_prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=None, current_scale=1.0, phase_mode=0):
     """cpq_ir_prepare: dict(ir=[channels][target] float64, scale=..., ir_peak_latency=...)."""
     keep, b = _ir_buffer(ir, ir_rate)
     cur = None
     if current_ir is not None:
         keep2, cur = _ir_buffer(current_ir, sample_rate)
     out = K.IrPrepared()
-    rc = K.load().cpq_ir_prepare(C.byref(b), sample_rate, target_ir_length_sec, C.byref(cur) if cur is not None else None,
+    rc = K.load().cpq_ir_prepare(C.byref(b), sample_rate, target_ir_length_sec, phase_mode, C.byref(cur) if cur is not None else None,
                                  current_scale, C.byref(out))
     if rc != 0:
         raise CpqError(rc, "cpq_ir_prepare")
@@ -115,6 +115,18 @@ def ir_prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=No
                 "ir_peak_latency": out.ir_peak_latency}
     finally:
         K.load().cpq_ir_prepared_free(C.byref(out))
+
+
+def ir_convert_to_minimum_phase(ir, rate=48000.0):
+    keep, b = _ir_buffer(ir, rate)
+    out = K.IrBuffer()
+    rc = K.load().cpq_ir_convert_to_minimum_phase(C.byref(b), C.byref(out))
+    if rc != 0:
+        raise CpqError(rc, "cpq_ir_convert_to_minimum_phase")
+    try:
+        return np.ctypeslib.as_array(out.data, shape=(out.n_channels, out.n_samples)).copy()
+    finally:
+        K.load().cpq_ir_buffer_free(C.byref(out))
 
 
 def ir_compute_scale_factor(ir, current_ir=None, current_scale=1.0):

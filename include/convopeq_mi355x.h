@@ -364,13 +364,20 @@ typedef struct {
 int32_t cpq_ir_load_wav(const char* path, cpq_ir_buffer* out);
 void    cpq_ir_buffer_free(cpq_ir_buffer* b);
 
-/* doTrimStep + doTransformStep in PhaseMode::AsIs (LoaderThread.cpp:490-641, 696-709): trailing-silence trim, 1 Hz DC
+/* ConvolverProcessor::PhaseMode (src/ConvolverProcessor.h:117-122) */
+typedef enum { CPQ_PHASE_AS_IS = 0, CPQ_PHASE_MIXED = 1 /* not built: CPQ_ERR_UNSUPPORTED */, CPQ_PHASE_MINIMUM = 2 } cpq_phase_mode;
+
+/* doTrimStep + doTransformStep (LoaderThread.cpp:490-641, 644-709): trailing-silence trim, 1 Hz DC
  * blocker, asymmetric Tukey window about the peak, zero-padded / cut to int(rate * target_ir_length_sec) samples
  * (IR_LENGTH 0.5..3 s, default 1 s; cap 2^21) with a linear fade-out, computeScaleFactor against the IR playing now
  * (current_ir may be NULL), peak latency.  An IR whose rate differs from sample_rate needs the reference's third-party
  * resampler (r8brain): CPQ_ERR_UNSUPPORTED. */
-int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float target_ir_length_sec,
+int32_t cpq_ir_prepare(const cpq_ir_buffer* loaded, double sample_rate, float target_ir_length_sec, int32_t phase_mode,
                        const cpq_ir_buffer* current_ir, double current_scale, cpq_ir_prepared* out);
+/* ConvolverProcessorInternal::convertToMinimumPhase (src/convolver/ConvolverProcessor.ResampleAndFallback.cpp:333-469):
+ * homomorphic minimum-phase reconstruction at 4x zero padding, every channel on its own.  CPQ_ERR_UNSUPPORTED where the
+ * reference gives up (4 n above 8388608 samples, non-finite intermediate values). */
+int32_t cpq_ir_convert_to_minimum_phase(const cpq_ir_buffer* in, cpq_ir_buffer* out);
 void    cpq_ir_prepared_free(cpq_ir_prepared* p);
 
 /* IRConverter::computeScaleFactor(ir, currentIr, currentScale) (src/IRConverter.cpp:175-196): energy normalisation to

@@ -324,7 +324,43 @@ def estimate_peak_latency(ir, length):
     return min(max(lat, 0), length - 1)
 
 
-def prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=None, current_scale=1.0):
+def convert_to_minimum_phase(ir):
+    """ConvolverProcessorInternal::convertToMinimumPhase (src/convolver/ConvolverProcessor.ResampleAndFallback.cpp:333-469),
+    with numpy's FFT in place of MKL's.  None where the reference gives up."""
+    ir = np.atleast_2d(np.asarray(ir, dtype=np.float64))
+    channels, n = ir.shape
+    if n <= 0 or channels < 1:
+        return None
+    size = 1
+    while size < n * 4:
+        size <<= 1
+    if size > 8388608:
+        return None
+    out = np.empty((channels, n))
+    half = size // 2
+    for ch in range(channels):
+        z = np.fft.fft(ir[ch], size)
+        mag = np.maximum(np.abs(z), 1.0e-300)
+        c = np.fft.ifft(np.log(mag).astype(np.complex128))
+        c[0] = c[0].real
+        c[1:half] = c[1:half].real * 2.0
+        c[half] = c[half].real
+        c[half + 1:] = 0.0
+        z = np.fft.fft(c)
+        re, im = np.clip(z.real, -50.0, 50.0), np.clip(z.imag, -50.0, 50.0)
+        m = np.exp(re)
+        e = m * np.cos(im) + 1j * (m * np.sin(im))
+        if not (np.all(np.isfinite(e.real)) and np.all(np.isfinite(e.imag))):
+            return None
+        y = np.fft.ifft(e).real[:n].copy()
+        if not np.all(np.isfinite(y)):
+            return None
+        y[np.abs(y) < 1.0e-18] = 0.0
+        out[ch] = y
+    return out
+
+
+def prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=None, current_scale=1.0, minimum_phase=False):
     """doTrimStep + doTransformStep in PhaseMode::AsIs + buildConvolverFromTrimmed's latency
     (LoaderThread.cpp:490-641, 696-709, 220)."""
     ir = np.atleast_2d(np.asarray(ir, dtype=np.float64))
@@ -352,6 +388,10 @@ def prepare(ir, ir_rate, sample_rate, target_ir_length_sec=1.0, current_ir=None,
             for i in range(copy - fade, copy):
                 out[ch, i] *= g
                 g += inc
+    if minimum_phase:                           # doTransformStep (LoaderThread.cpp:652-680): kept only when it validates
+        mp = convert_to_minimum_phase(out)
+        if mp is not None and np.all(np.isfinite(mp)) and np.abs(mp).max() > 1.0e-12:
+            out = mp
     scale = compute_scale_factor(out, current_ir, current_scale)
     if not scale["has_scale_factor"]:
         scale["scale_factor"] = 1.0

@@ -106,13 +106,13 @@ int main(int argc, char** argv)
                 cpq_ir_buffer in { ch, n, 48000.0, data.data() };
                 for (float secs : { 0.001f, 0.2f }) {
                     cpq_ir_prepared p;
-                    CHECK(cpq_ir_prepare(&in, 48000.0, secs, nullptr, 1.0, &p) == CPQ_OK);
+                    CHECK(cpq_ir_prepare(&in, 48000.0, secs, (n % 2) ? CPQ_PHASE_MINIMUM : CPQ_PHASE_AS_IS, nullptr, 1.0, &p) == CPQ_OK);
                     CHECK(p.ir.n_channels == ch && p.ir.n_samples == (int)(48000.0 * (double)secs));
                     CHECK(std::isfinite(p.scale.scale_factor) && p.scale.scale_factor > 0.0);
                     CHECK(p.ir_peak_latency >= 0 && p.ir_peak_latency < p.ir.n_samples);
                     for (int i = 0; i < p.ir.n_channels * p.ir.n_samples; ++i) CHECK(std::isfinite(p.ir.data[i]));
                     cpq_ir_prepared q;
-                    CHECK(cpq_ir_prepare(&in, 48000.0, secs, &p.ir, 0.5, &q) == CPQ_OK);     // against itself as the current IR
+                    CHECK(cpq_ir_prepare(&in, 48000.0, secs, CPQ_PHASE_AS_IS, &p.ir, 0.5, &q) == CPQ_OK);     // against itself as the current IR
                     cpq_ir_prepared_free(&q);
                     cpq_ir_prepared_free(&p);
                 }
@@ -129,10 +129,12 @@ int main(int argc, char** argv)
     cpq_ir_prepared p;
     double one = 1.0;
     cpq_ir_buffer bad { 1, 1, 44100.0, &one };
-    CHECK(cpq_ir_prepare(&bad, 48000.0, 1.0f, nullptr, 1.0, &p) == CPQ_ERR_UNSUPPORTED && p.ir.data == nullptr);
-    CHECK(cpq_ir_prepare(nullptr, 48000.0, 1.0f, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
-    CHECK(cpq_ir_prepare(&bad, 0.0, 1.0f, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
-    CHECK(cpq_ir_prepare(&bad, 44100.0, -1.0f, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
+    CHECK(cpq_ir_prepare(&bad, 48000.0, 1.0f, CPQ_PHASE_AS_IS, nullptr, 1.0, &p) == CPQ_ERR_UNSUPPORTED && p.ir.data == nullptr);
+    CHECK(cpq_ir_prepare(nullptr, 48000.0, 1.0f, CPQ_PHASE_AS_IS, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
+    CHECK(cpq_ir_prepare(&bad, 0.0, 1.0f, CPQ_PHASE_AS_IS, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
+    CHECK(cpq_ir_prepare(&bad, 44100.0, -1.0f, CPQ_PHASE_AS_IS, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
+    CHECK(cpq_ir_prepare(&bad, 44100.0, 1.0f, CPQ_PHASE_MIXED, nullptr, 1.0, &p) == CPQ_ERR_UNSUPPORTED);
+    CHECK(cpq_ir_prepare(&bad, 44100.0, 1.0f, 7, nullptr, 1.0, &p) == CPQ_ERR_INVALID_ARG);
     cpq_ir_scale sc;
     CHECK(cpq_ir_compute_scale_factor(nullptr, 1, 1, nullptr, 0, 0, 1.0, &sc) == CPQ_ERR_INVALID_ARG);
     std::printf("ir ingest: %d decoded, %d rejected, %d failed checks\n", decoded, rejected, fails);

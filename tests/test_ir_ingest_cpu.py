@@ -278,3 +278,42 @@ def test_prepare_variants_and_errors(amd, O):
     # length cap of the reference (2^21 samples)
     got = amd.ir_prepare(mono, 768000.0, 768000.0, 3.0)
     assert got["ir"].shape == (1, 2097152)
+
+
+def test_minimum_phase_conversion(amd, O):
+    """PhaseMode::Minimum: the product's own radix-2 FFT against numpy's in the restatement (the cepstral construction
+    amplifies FFT rounding near spectral nulls: 1e-9 of the peak is the bar here), and against the mathematics: same
+    magnitude response, all energy moved to the front, a minimum-phase input comes back unchanged."""
+    ir, rate = amd.ir_load_wav(SAMPLE)
+    prep = amd.ir_prepare(ir, rate, 48000.0, 0.25)["ir"]                 # 12000 samples -> 65536-point transforms
+    got = amd.ir_convert_to_minimum_phase(prep)
+    ref = O.convert_to_minimum_phase(prep)
+    assert got.shape == ref.shape == prep.shape
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+    n = prep.shape[1]
+    for ch in range(2):
+        a, b = np.abs(np.fft.rfft(prep[ch], 4 * n)), np.abs(np.fft.rfft(got[ch], 4 * n))
+        strong = a > 1e-3 * a.max()
+        assert np.abs(b[strong] / a[strong] - 1.0).max() < 1e-3          # same magnitude where there is any (time aliasing of the cepstrum aside)
+        ea, eb = np.cumsum(prep[ch] ** 2), np.cumsum(got[ch] ** 2)
+        assert np.all(eb[:n // 2] >= ea[:n // 2] * (1 - 1e-9) - 1e-15)   # energy arrives no later than in any other phase
+    # a decaying exponential is minimum phase already
+    t = np.arange(4096, dtype=np.float64)
+    e = (0.5 * 0.99 ** t)[None, :]
+    assert np.abs(amd.ir_convert_to_minimum_phase(e) - e).max() < 1e-9
+    # through cpq_ir_prepare
+    a = amd.ir_prepare(ir, rate, 48000.0, 0.25, phase_mode=2)
+    b = O.prepare(ir, rate, 48000.0, 0.25, minimum_phase=True)
+    assert np.abs(a["ir"] - b["ir"]).max() <= 1e-9 * np.abs(b["ir"]).max()
+    assert abs(a["scale"]["scale_factor"] / b["scale"]["scale_factor"] - 1.0) < 1e-8
+    assert abs(a["ir_peak_latency"] - b["ir_peak_latency"]) <= 1
+    assert a["ir_peak_latency"] < amd.ir_prepare(ir, rate, 48000.0, 0.25)["ir_peak_latency"]
+    # a silent IR: the conversion does not validate (peak <= 1e-12) and the IR stays as it is
+    z = amd.ir_prepare(np.zeros((1, 300)), 48000.0, 48000.0, 0.01, phase_mode=2)
+    assert not np.any(z["ir"])
+    with pytest.raises(amd.CpqError) as ex:
+        amd.ir_prepare(ir, rate, 48000.0, 0.25, phase_mode=1)            # Mixed: not built
+    assert ex.value.status == -5
+    with pytest.raises(amd.CpqError) as ex:
+        amd.ir_convert_to_minimum_phase(np.ones((1, 2097153)))           # 4 n above the reference's limit
+    assert ex.value.status == -5
