@@ -145,8 +145,37 @@ public:
         return cpq_conv_set_impulse(e_.get(), stream, irL, irR, irLen, scale, 0, nullptr) == CPQ_OK;
     }
 
+    // IR file -> conditioned IR -> SetImpulse + peak latency, as the reference's loader thread does for one processor
+    // (LoaderThread::doLoadStep .. buildConvolverFromTrimmed); a mono file feeds both channels
+    bool loadImpulseFile(int stream, const char* wavPath, double sampleRate, float targetIrLengthSec = 1.0f,
+                         cpq_phase_mode phase = CPQ_PHASE_AS_IS, const cpq_filter_spec* spec = nullptr, float mix = 1.0f)
+    {
+        cpq_ir_buffer file{};
+        if (cpq_ir_load_wav(wavPath, &file) != CPQ_OK) return false;
+        cpq_ir_prepared prep{};
+        const bool ok = cpq_ir_prepare(&file, sampleRate, targetIrLengthSec, phase, nullptr, 1.0, &prep) == CPQ_OK;
+        cpq_ir_buffer_free(&file);
+        if (!ok) return false;
+        const double* l = prep.ir.data;
+        const double* r = prep.ir.n_channels > 1 ? prep.ir.data + prep.ir.n_samples : l;
+        bool done = cpq_conv_set_impulse(e_.get(), stream, l, r, prep.ir.n_samples, prep.scale.scale_factor, 0, spec) == CPQ_OK;
+        const cpq_convproc_params pp{ mix, 0, prep.ir_peak_latency, 0.0f };
+        done = done && cpq_convproc_set_params(e_.get(), stream, &pp) == CPQ_OK;
+        cpq_ir_prepared_free(&prep);
+        return done;
+    }
+
     bool setEqParameters(int stream, const cpq_eq_params& p) { return cpq_eq_set_params(e_.get(), stream, &p) == CPQ_OK; }
     void setProcessingOrder(cpq_order o) { cpq_engine_set_order(e_.get(), o); }
+    // EQProcessor::setBypassFromRT / requestBandReset, per stream
+    void setBypassFromRT(int stream, bool bypassed) { cpq_eq_set_bypass(e_.get(), stream, bypassed ? 1 : 0); }
+    void requestBandReset(int stream, uint32_t mask) { cpq_eq_request_band_reset(e_.get(), stream, mask); }
+    // DSPCore's remaining per-block routing values
+    void setConvolverBypassed(bool bypassed) { cpq_engine_set_conv_bypass(e_.get(), bypassed ? 1 : 0); }
+    void setGains(int stream, double convolverInputTrimGain, double outputMakeupGain)
+    {
+        cpq_engine_set_gains(e_.get(), stream, convolverInputTrimGain, outputMakeupGain);
+    }
 
     // in-place on the planar block, like ConvolverProcessor::process / EQProcessor::process
     void process(AudioBlockBatch& block)

@@ -6,7 +6,7 @@
 
 #include "convopeq_mi355x.hpp"
 
-int main()
+int main(int argc, char** argv)
 {
     const int S = 2, B = 512, L = 3000, T = 4, N = 3 * T * B;
     try {
@@ -35,7 +35,36 @@ int main()
                 worst = std::fmax(worst, std::fabs((double)acc - y[static_cast<size_t>(c) * N + n]));
             }
         std::printf("adapter max abs err %.3e\n", worst);
-        return worst < 1e-13 ? 0 : 5;
+        if (!(worst < 1e-13)) return 5;
+        if (argc > 1) {
+            // processor-level adapter: IR file -> loader steps -> engine; EQ bypassed before the first block = pass-through
+            // of the EQ stage, so the block is wet * wetG + delayed dry * dryG of the file's IR: finite, not silent
+            cpq::Engine eng2(S, B, 48000, T);
+            cpq::BatchedProcessor proc(eng2);
+            proc.prepareToPlay(48000.0, T * B);
+            if (!proc.loadImpulseFile(CPQ_ALL_STREAMS, argv[1], 48000.0, 1.0f, CPQ_PHASE_MINIMUM, nullptr, 0.7f)) return 6;
+            cpq_eq_params ep;
+            cpq_eq_params_default(&ep);
+            if (!proc.setEqParameters(CPQ_ALL_STREAMS, ep)) return 7;
+            cpq_engine_set_conv_level(eng2.get(), 1);
+            proc.setBypassFromRT(CPQ_ALL_STREAMS, true);
+            proc.requestBandReset(0, 0xFFFFFFFFu);
+            proc.setGains(1, 1.0, 0.5);
+            std::vector<std::vector<double>> planes(2 * S, std::vector<double>(T * B));
+            std::vector<double*> ptrs;
+            for (int c = 0; c < 2 * S; ++c) {
+                for (int i = 0; i < T * B; ++i) planes[c][i] = x[static_cast<size_t>(c) * N + i];
+                ptrs.push_back(planes[c].data());
+            }
+            cpq::AudioBlockBatch blk{ ptrs.data(), 2 * S, T * B };
+            proc.process(blk);
+            double energy = 0.0;
+            for (int c = 0; c < 2 * S; ++c)
+                for (int i = 0; i < T * B; ++i) { if (!std::isfinite(planes[c][i])) return 8; energy += planes[c][i] * planes[c][i]; }
+            std::printf("processor adapter block energy %.6e\n", energy);
+            if (!(energy > 1e-6)) return 9;
+        }
+        return 0;
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return 1;

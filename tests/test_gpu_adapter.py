@@ -21,6 +21,6 @@ def test_adapter_compiles_and_links(tmp_path):
 def test_adapter_add_get_matches_direct_form(tmp_path):
     exe = tmp_path / "adapter_smoke"
     subprocess.check_call(CMD + ["-o", str(exe)])
-    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    r = subprocess.run([str(exe), os.path.join(HERE, "golden", "impulse_room_correction_hpf_lpf.wav")], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
