@@ -206,7 +206,8 @@ struct cpq_engine {
     std::vector<MixRamp> mixRamp;
     bool procProcessed = false;         // a processor-level call has run since create / prepare: parameter changes ramp
     int* mixRampLen = nullptr;             // [streams] device: leading samples of the call with per-sample gains
-    double* mixRampGains = nullptr;     // [streams][tMax * P][2] device (allocated when a ramp first runs)
+    double* mixRampGains = nullptr;     // [streams][mixRampCap][2] device (allocated when a ramp first runs)
+    int mixRampCap = 0;
     double* procGains = nullptr;    // [streams][2] device
     int* procDelay = nullptr;       // [streams] device
     // dry delay line: a ring per channel (the reference's 4 Mi-sample delayBuffer, Runtime.cpp:378-391), sized for the
@@ -1739,6 +1740,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
     std::vector<int> mixRampLenHost;
     std::vector<double> rampHost;
     bool anyRamp = false;
+    int rampStride = 0;                 // samples per stream in rampHost / on the device: the longest smoothed prefix
     if (!e->procBypassed) {
         for (int s = 0; s < S; ++s) {
             auto& r = e->mixRamp[s];
@@ -1750,24 +1752,33 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
                 r.remaining = steps;
             }
             if (r.remaining <= 0) continue;
-            if (!anyRamp) { mixRampLenHost.assign(S, 0); rampHost.assign((size_t)S * n * 2, 0.0); anyRamp = true; }
-            const int nSm = (int)std::min<int64_t>(n, ((int64_t)r.remaining + e->B - 1) / e->B * e->B);
-            for (int i = 0; i < nSm; ++i) {
+            if (!anyRamp) { mixRampLenHost.assign(S, 0); anyRamp = true; }
+            mixRampLenHost[s] = (int)std::min<int64_t>(n, ((int64_t)r.remaining + e->B - 1) / e->B * e->B);
+            rampStride = std::max(rampStride, mixRampLenHost[s]);
+        }
+        if (anyRamp) rampHost.assign((size_t)S * rampStride * 2, 0.0);
+        for (int s = 0; s < S && anyRamp; ++s) {
+            auto& r = e->mixRamp[s];
+            for (int i = 0; i < mixRampLenHost[s]; ++i) {
                 if (r.remaining > 0) {                                                  // getNextValue
                     r.current += r.step;
                     if (--r.remaining <= 0) r.current = r.target;
                 }
-                rampHost[((size_t)s * n + i) * 2] = equalPowerSin(r.current) * 1.0;
-                rampHost[((size_t)s * n + i) * 2 + 1] = equalPowerSin(1.0 - r.current);
+                rampHost[((size_t)s * rampStride + i) * 2] = equalPowerSin(r.current) * 1.0;
+                rampHost[((size_t)s * rampStride + i) * 2 + 1] = equalPowerSin(1.0 - r.current);
             }
-            mixRampLenHost[s] = nSm;
         }
     }
     if (anyRamp) {
-        if (!e->mixRampGains) {
-            if (hipMalloc((void**)&e->mixRampLen, sizeof(int) * S) != hipSuccess ||
-                hipMalloc((void**)&e->mixRampGains, sizeof(double) * 2 * (size_t)S * e->tMax * e->P) != hipSuccess)
+        if (!e->mixRampLen && hipMalloc((void**)&e->mixRampLen, sizeof(int) * S) != hipSuccess)
+            return fail(e, CPQ_ERR_OOM, "mix-ramp buffers could not be allocated");
+        if (rampStride > e->mixRampCap) {
+            if (e->mixRampGains) (void)hipFree(e->mixRampGains);
+            e->mixRampGains = nullptr;
+            e->mixRampCap = 0;
+            if (hipMalloc((void**)&e->mixRampGains, sizeof(double) * 2 * (size_t)S * rampStride) != hipSuccess)
                 return fail(e, CPQ_ERR_OOM, "mix-ramp buffers could not be allocated");
+            e->mixRampCap = rampStride;
         }
         CPQ_HIP(e, hipMemcpyAsync(e->mixRampLen, mixRampLenHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
         CPQ_HIP(e, hipMemcpyAsync(e->mixRampGains, rampHost.data(), sizeof(double) * rampHost.size(), hipMemcpyHostToDevice, e->stream));
@@ -1902,7 +1913,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_convproc_mix(e->stream, dOut + off, dOut + off, (int64_t)n, e->nCh, len, e->procGains, e->dryRing,
                                  e->dryRingSize, pos0 + off, e->latNew, e->latOld, fade ? e->latLen : nullptr, e->latGains,
-                                 e->latCap, skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, n, off);
+                                 e->latCap, skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, rampStride, off);
         if (fade || R > 1) CPQ_HIP(e, hipStreamSynchronize(e->stream));      // the host vectors are reused / go out of scope
     }
     CPQ_HIP(e, hipGetLastError());
