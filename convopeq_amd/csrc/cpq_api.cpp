@@ -434,7 +434,7 @@ int specTailsRun(cpq_engine* e, double* dOut, int n)
                 cpq::launch_fdl_mac(e->stream, e->macTile, t.X, t.H, e->irSlot, t.Y, t.P, e->nCh, t.kPad, t.ringSlots, t.head,
                                     nb, (int64_t)t.hRows * t.P);
             }
-            if (cpq::fdl_mac_variant(e->macTile, nb) != 0) {      // the cooperative kernel produces the packed bin itself
+            if (cpq::fdl_mac_needs_dcnyq(e->macTile, nb)) {      // the cooperative kernel produces the packed bin itself
                 ProfScope p(e, CPQ_K_DCNYQ);
                 cpq::launch_fdl_mac_dcnyq(e->stream, t.XDN, t.HDN, e->irSlot, t.Y, t.P, e->nCh, t.K, t.ringSlots, t.head, nb,
                                           t.hRows);
@@ -496,7 +496,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
                 cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H + (int64_t)e->layerRow[l] * e->P, e->irSlot, e->Y,
                                     e->P, e->nCh, kPad, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P);
             }
-            if (cpq::fdl_mac_variant(e->macTile, T) != 0) {
+            if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {
                 ProfScope p(e, CPQ_K_DCNYQ);
                 cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN + e->layerRow[l], e->irSlot, e->Y, e->P, e->nCh,
                                           e->layerK[l], e->ringSlots, e->head, T, e->hRows);
@@ -533,7 +533,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
                             (int)alignUp(e->kMaxReal, cpq::fdl_mac_kpad_align(e->macTile, T)), e->ringSlots,
                             e->head, T, (int64_t)e->hRows * e->P);
     }
-    if (cpq::fdl_mac_variant(e->macTile, T) != 0) {      // the cooperative kernel produces the packed (DC, Nyquist) bin itself
+    if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {      // the cooperative kernel produces the packed (DC, Nyquist) bin itself
         ProfScope p(e, CPQ_K_DCNYQ);
         cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN, e->irSlot, e->Y, e->P, e->nCh, e->kMaxReal, e->ringSlots,
                                   e->head, T, e->hRows);

@@ -42,6 +42,7 @@ void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double
 // kernel variant launch_fdl_mac uses for (tile, T) (0 = workgroup-cooperative) and the multiple kPad must be padded to
 int fdl_mac_variant(int tile, int T);
 int fdl_mac_kpad_align(int tile, int T);
+bool fdl_mac_needs_dcnyq(int tile, int T);    // only the 16- and 32-row register tiles leave packed bin 0 to launch_fdl_mac_dcnyq
 void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2* HDN, const int* irSlot,
                           double2* Y, int P, int nCh, int K, int ringSlots, int head, int T, int hdnStride);
 

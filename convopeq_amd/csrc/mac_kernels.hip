@@ -44,10 +44,16 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
     const double2* __restrict__ Hc = H + (int64_t)irSlot[c] * hSlotStride + bin;
     const int base = head + t0;
 
+    // Small tiles (short, HBM-bound calls) keep the two products of the real part apart: Re = p - q with p = sum a c,
+    // q = sum b d.  Element 0 of a packed spectrum is (DC, Nyquist), two independent real MACs -- exactly (p, q) -- so
+    // these variants need no separate DC/Nyquist kernel.  Larger tiles keep the fused form (registers).
+    constexpr bool kSplitRe = TT <= 8;
     double2 acc[TT], xw[TT], xn[PF], hn[PF];
+    double accq[kSplitRe ? TT : 1];
 #pragma unroll
     for (int u = 0; u < TT; ++u) {
         acc[u] = make_double2(0.0, 0.0);
+        if (kSplitRe) accq[u] = 0.0;
         xw[u] = Xc[(int64_t)((base + u) & ringMask) * P];          // window: X[t0 + u - k] at (u - k) mod TT
     }
 #pragma unroll
@@ -70,7 +76,12 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
 #pragma unroll
             for (int i = 0; i < TT; ++i) {
                 const double2 x = xw[(i - r + TT) % TT];
-                acc[i].x = fma(x.x, h.x, fma(-x.y, h.y, acc[i].x));
+                if (kSplitRe) {
+                    acc[i].x = fma(x.x, h.x, acc[i].x);
+                    accq[i] = fma(x.y, h.y, accq[i]);
+                } else {
+                    acc[i].x = fma(x.x, h.x, fma(-x.y, h.y, acc[i].x));
+                }
                 acc[i].y = fma(x.x, h.y, fma(x.y, h.x, acc[i].y));
             }
             xw[TT - 1 - r] = xnew;    // X[t0 + TT-1 - k] retires, X[t0 - k - 1] takes its place
@@ -79,7 +90,11 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i)
-        if (t0 + i < T) Y[((int64_t)c * T + t0 + i) * P + bin] = acc[i];
+        if (t0 + i < T) {
+            double2 y = acc[i];
+            if (kSplitRe) y = (bin == 0) ? make_double2(acc[i].x, accq[i]) : make_double2(acc[i].x - accq[i], acc[i].y);
+            Y[((int64_t)c * T + t0 + i) * P + bin] = y;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -273,6 +288,9 @@ int fdl_mac_variant(int tile, int T)
     if (T >= 6) return 8;
     return 4;
 }
+
+// the variants that leave packed bin 0 to launch_fdl_mac_dcnyq
+bool fdl_mac_needs_dcnyq(int tile, int T) { return fdl_mac_variant(tile, T) > 8; }
 
 int fdl_mac_kpad_align(int tile, int T)
 {
