@@ -717,6 +717,40 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
             // (2) the zero-state part of the product, T x, does not wait for the start states: its 16 MFMAs go to the
             // matrix pipe now and run beside the reduction and the scan below (x is dead from here: acc takes its place)
 #if !(defined(CPQ_ABL) && (CPQ_ABL & 4))
+#ifndef CPQ_TX_16X16
+            {
+                // T is lower-triangular Toeplitz: of its sixteen 4 x 4 blocks only the ten on and below the diagonal are
+                // non-zero, and block (i, j) depends on i - j alone.  v_mfma_f64_4x4x4_4b_f64 multiplies one such block
+                // into four batches of four chunks; its operand layout (B[k][n] at lane 16 k + n, D[i][n] at lane
+                // 16 i + n, A[i][k] at lane 16 k + 4 batch + i: tools/ubench/mfma_f64_4x4x4.hip) is register s of the
+                // 16x16x4 layout = block row s, so the two instructions mix freely.  10 small MFMAs (~17-20 cycles each)
+                // instead of 4 large ones (64 cycles each) per tile.
+                double a4[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) a4[d] = L->ht[b][15 + 4 * d + (m & 3) - g];
+                double dacc[4][4];
+                // block-column major: consecutive MFMAs write different accumulators
+#ifdef CPQ_TX_TILE_MAJOR
+#pragma unroll
+                for (int tau = 0; tau < 4; ++tau)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = j; i < 4; ++i)
+                            dacc[tau][i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[i - j], x[tau][j], j == 0 ? 0.0 : dacc[tau][i], 0, 0, 0);
+#else
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tau = 0; tau < 4; ++tau)
+#pragma unroll
+                        for (int i = j; i < 4; ++i)
+                            dacc[tau][i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[i - j], x[tau][j], j == 0 ? 0.0 : dacc[tau][i], 0, 0, 0);
+#endif
+#pragma unroll
+                for (int tau = 0; tau < 4; ++tau) x[tau] = v4d{ dacc[tau][0], dacc[tau][1], dacc[tau][2], dacc[tau][3] };
+            }
+#else
             {
                 v4d acc[4];
 #pragma unroll
@@ -730,6 +764,7 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
 #pragma unroll
                 for (int tau = 0; tau < 4; ++tau) x[tau] = acc[tau];
             }
+#endif
 #endif
             wave_lds_sync();
             // ... the partial end states summed over the four lane groups; lane l ends up with chunk l of the wave
