@@ -1296,3 +1296,115 @@ def test_eq_band_reset_waits_for_silence(amd, oracle, eq_mode):
     plain = O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B)
     pl = np.concatenate([plain.callback(x[0, c * B:(c + 1) * B].copy(), x[1, c * B:(c + 1) * B].copy(), False)[0] for c in range(16)])
     assert np.abs(pl[15 * B:16 * B] - y[0, 15 * B:16 * B]).max() > 1e-9
+
+
+def _random_eq_params(O, rng, allow_ms=True):
+    p = O.eq_params_default()
+    freqs = np.exp(rng.uniform(np.log(15.0), np.log(26000.0), 20))          # beyond the clamps [20, min(20000, 0.95 nyq)] on purpose
+    for i in range(20):
+        b = p.bands[i]
+        b.frequency = float(freqs[i])
+        b.gain = float(rng.choice([0.0, 0.005, rng.uniform(-50, 50), rng.uniform(-6, 6), rng.uniform(-6, 6)]))
+        b.q = float(np.exp(rng.uniform(np.log(0.005), np.log(25.0))))
+        b.enabled = int(rng.random() < 0.8)
+        b.type = int(rng.integers(0, 5))
+        b.channelMode = int(rng.choice([0, 0, 0, 1, 2] + ([3, 4] if allow_ms else [])))
+    p.nonlinearSaturation = float(rng.choice([0.0, 0.2, 0.2, 1.0, rng.uniform(0, 1)]))
+    p.totalGainDb = float(rng.choice([0.0, rng.uniform(-24, 12)]))
+    p.filterStructure = int(rng.random() < 0.3)
+    p.agcEnabled = int(rng.random() < 0.2)
+    return p
+
+
+@pytest.mark.parametrize("seed,sr,blk", [(1, 48000.0, 512), (2, 48000.0, 512), (3, 48000.0, 512), (4, 96000.0, 512),
+                                         (5, 44100.0, 256), (6, 192000.0, 1024), (7, 48000.0, 64)])
+def test_eq_random_parameter_sweep(amd, oracle, seed, sr, blk):
+    """Seeded sweep of the EQ parameter space: eight streams per engine, every stream its own random parameter set (all
+    five band types, frequencies / gains / Q beyond the clamps, disabled and flat bands, Left / Right / Mid / Side
+    modes, serial and parallel structure, saturation 0..1, total gain, AGC), in the automatic kernel choice and on the
+    sequential kernel, levels from -40 dBFS to clipping, several sample rates and callback sizes.  GPU vs oracle."""
+    O = oracle
+    rng = np.random.default_rng(seed)
+    S, T, calls = 8, 2048 // blk, 3
+    n = T * blk
+    params = [_random_eq_params(O, rng) for _ in range(S)]
+    x = make_inputs(O, S, calls * n)
+    for s in range(S):
+        x[2 * s:2 * s + 2] *= float(rng.choice([0.04, 1.0, 4.0, 12.0]))
+    refs = []
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], params[s], sr=sr, block=blk)
+        refs.append((yl, yr))
+    for mode in ("auto", "seq"):
+        eng = amd.BatchedEngine(S, block_size=blk, max_ir_len=blk, max_blocks_per_call=T, sample_rate=sr)
+        for s in range(S):
+            eng.set_eq_params(s, _copy_params(params[s], amd.eq_params_default()))
+        if mode == "seq":
+            eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+        y = np.concatenate([eng.eq_process(x[:, k * n:(k + 1) * n]) for k in range(calls)], axis=1)
+        eng.close()
+        for s in range(S):
+            scale = max(1.0, float(np.abs(refs[s][0]).max()), float(np.abs(refs[s][1]).max()))
+            err = max(np.abs(y[2 * s] - refs[s][0]).max(), np.abs(y[2 * s + 1] - refs[s][1]).max()) / scale
+            assert err <= (0.0 if mode == "seq" else 1e-12), (seed, sr, blk, mode, s, err)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_convolver_random_configuration_sweep(amd, oracle, seed):
+    """Seeded sweep of the convolver's configuration space against the stateful emulation: IR length, block size,
+    FilterSpec on / off with random HC / LC / tail modes, tail start, strength and layer multiplier (powers of two),
+    scale, direct head, uniform and native non-uniform schedule, calls of varying length.  Configurations the engine
+    declares unsupported are skipped (and must say so with CPQ_ERR_UNSUPPORTED)."""
+    O = oracle
+    rng = np.random.default_rng(1000 + seed)
+    block = int(rng.choice([64, 128, 256, 512, 512, 1024, 2048]))
+    ir_len = int(np.exp(rng.uniform(np.log(40), np.log(90000))))
+    T = int(rng.choice([1, 2, 3, 5, 8]))
+    use_spec = rng.random() < 0.6
+    kw = {}
+    if use_spec:
+        kw = dict(hc_mode=int(rng.integers(0, 3)), lc_mode=int(rng.integers(0, 2)), tail_mode=int(rng.integers(0, 3)),
+                  tail_start_seconds=float(rng.choice([0.02, 0.085, 0.2, 0.5])), tail_strength=float(rng.uniform(0.0, 2.5)),
+                  tail_l1l2_multiplier=int(rng.choice([2, 4, 8, 16])), sample_rate=float(rng.choice([44100.0, 48000.0, 96000.0])))
+        kw["tail_enabled"] = int(kw["tail_mode"] != 2)
+    names = {"hc_mode": "hcMode", "lc_mode": "lcMode", "tail_enabled": "tailEnabled", "tail_mode": "tailMode",
+             "sample_rate": "sampleRate", "tail_start_seconds": "tailStartSeconds", "tail_strength": "tailStrength",
+             "tail_l1l2_multiplier": "tailL1L2Multiplier"}
+    sa = amd.FilterSpec.defaults(**kw) if use_spec else None
+    so = O.FilterSpec.defaults(applySpectrumFilter=1, **{names[k]: v for k, v in kw.items()}) if use_spec else None
+    scale = float(rng.choice([1.0, rng.uniform(0.1, 2.0)]))
+    direct = bool(rng.random() < 0.3)
+    sched = amd.CPQ_SCHED_REFERENCE_NUC if rng.random() < 0.3 else amd.CPQ_SCHED_UNIFORM
+    irs = [O.gen_ir(ir_len, seed=0x1257 + seed, channel=ch) for ch in range(2)]
+    total_blocks = max(3 * T, (ir_len + 3 * 4096) // block + 2 * T)
+    total_blocks = min(total_blocks, 40000 // block * 8 + 3 * T)
+    cfg = (block, ir_len, T, kw, scale, direct, sched)
+    try:
+        eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=T, schedule=sched,
+                                sample_rate=kw.get("sample_rate", 48000.0))
+        eng.set_impulse(0, irs[0], irs[1], scale=scale, direct_head=direct, spec=sa)
+    except amd.CpqError as e:
+        assert e.status == -5, (cfg, str(e))
+        pytest.skip(f"unsupported by the engine: {cfg}: {e}")
+    # calls of 1..T blocks
+    sizes = []
+    left = total_blocks
+    while left > 0:
+        k = int(min(left, rng.integers(1, T + 1)))
+        sizes.append(k)
+        left -= k
+    x = make_inputs(O, 1, total_blocks * block)
+    ref = np.empty_like(x)
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(irs[c], block, scale=scale, direct=direct, spec=so), cfg
+        ref[c] = nuc.run(x[c], block)
+        nuc.close()
+    outs, o = [], 0
+    for k in sizes:
+        outs.append(eng.conv_process(x[:, o:o + k * block]))
+        o += k * block
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    err = rms(y - ref) / max(rms(ref), 1e-30)
+    assert err <= 1e-12, (cfg, err)
