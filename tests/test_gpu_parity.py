@@ -1353,8 +1353,7 @@ def test_eq_random_parameter_sweep(amd, oracle, seed, sr, blk):
 def test_convolver_random_configuration_sweep(amd, oracle, seed):
     """Seeded sweep of the convolver's configuration space against the stateful emulation: IR length, block size,
     FilterSpec on / off with random HC / LC / tail modes, tail start, strength and layer multiplier (powers of two),
-    scale, direct head, uniform and native non-uniform schedule, calls of varying length.  Configurations the engine
-    declares unsupported are skipped (and must say so with CPQ_ERR_UNSUPPORTED)."""
+    scale, direct head, uniform and native non-uniform schedule, calls of varying length."""
     O = oracle
     rng = np.random.default_rng(1000 + seed)
     block = int(rng.choice([64, 128, 256, 512, 512, 1024, 2048]))
@@ -1367,6 +1366,8 @@ def test_convolver_random_configuration_sweep(amd, oracle, seed):
                   tail_start_seconds=float(rng.choice([0.02, 0.085, 0.2, 0.5])), tail_strength=float(rng.uniform(0.0, 2.5)),
                   tail_l1l2_multiplier=int(rng.choice([2, 4, 8, 16])), sample_rate=float(rng.choice([44100.0, 48000.0, 96000.0])))
         kw["tail_enabled"] = int(kw["tail_mode"] != 2)
+        if kw["tail_mode"] == 0:          # air absorption raises the multiplier to at least 6 (NUC.cpp:652): 6 x block is not a
+            kw["tail_l1l2_multiplier"] = int(rng.choice([8, 16]))      # power of two and the reference's FFT plan breaks there
     names = {"hc_mode": "hcMode", "lc_mode": "lcMode", "tail_enabled": "tailEnabled", "tail_mode": "tailMode",
              "sample_rate": "sampleRate", "tail_start_seconds": "tailStartSeconds", "tail_strength": "tailStrength",
              "tail_l1l2_multiplier": "tailL1L2Multiplier"}
@@ -1379,13 +1380,9 @@ def test_convolver_random_configuration_sweep(amd, oracle, seed):
     total_blocks = max(3 * T, (ir_len + 3 * 4096) // block + 2 * T)
     total_blocks = min(total_blocks, 40000 // block * 8 + 3 * T)
     cfg = (block, ir_len, T, kw, scale, direct, sched)
-    try:
-        eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=T, schedule=sched,
-                                sample_rate=kw.get("sample_rate", 48000.0))
-        eng.set_impulse(0, irs[0], irs[1], scale=scale, direct_head=direct, spec=sa)
-    except amd.CpqError as e:
-        assert e.status == -5, (cfg, str(e))
-        pytest.skip(f"unsupported by the engine: {cfg}: {e}")
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=T, schedule=sched,
+                            sample_rate=kw.get("sample_rate", 48000.0))
+    eng.set_impulse(0, irs[0], irs[1], scale=scale, direct_head=direct, spec=sa)
     # calls of 1..T blocks
     sizes = []
     left = total_blocks
@@ -1408,3 +1405,17 @@ def test_convolver_random_configuration_sweep(amd, oracle, seed):
     eng.close()
     err = rms(y - ref) / max(rms(ref), 1e-30)
     assert err <= 1e-12, (cfg, err)
+
+
+def test_non_power_of_two_tail_partition_is_refused(amd, oracle):
+    """Air absorption with a multiplier below 6 makes the tail partition 6 x the block (NUC.cpp:652): the reference's FFT
+    plan rounds such a size down to a power of two (FFTBackend.cpp:27-30) and its output is no convolution, so the engine
+    refuses the plan instead of imitating it."""
+    O = oracle
+    eng = amd.BatchedEngine(1, block_size=256, max_ir_len=21259, max_blocks_per_call=1)
+    ir = O.gen_ir(21259)
+    with pytest.raises(amd.CpqError) as e:
+        eng.set_impulse(0, ir, ir, spec=amd.FilterSpec.defaults(tail_mode=0, tail_start_seconds=0.5, tail_l1l2_multiplier=4))
+    assert e.value.status == -5 and "1536" in str(e.value)
+    eng.set_impulse(0, ir, ir, spec=amd.FilterSpec.defaults(tail_mode=0, tail_start_seconds=0.5, tail_l1l2_multiplier=8))
+    eng.close()
