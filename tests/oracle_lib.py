@@ -305,12 +305,32 @@ class EqWithBypass:
     def __init__(self, params, sr=48000.0, block=512):
         self.p, self.sr, self.block = params, sr, block
         self.state = np.zeros(168)
+        # prepareToPlay: smoothTotalGain.setCurrentAndTargetValue(gain at that time) (src/eqprocessor/EQProcessor.Core.cpp:765)
+        # -- set here rather than at the first processed block, which a bypass may put off
+        gdb = float(params.totalGainDb)
+        g0 = 10.0 ** (gdb * 0.05) if gdb > -100.0 else 0.0
+        self.state[83:88] = [1.0, g0, g0, 0.0, 0.0]
         self.fade = LinearRamp(1.0, sr, 0.005)
         self.effective = False
         self.pending = 0                                    # rtDeferredBandResetMask
 
     def request_band_reset(self, mask=0xFFFFFFFF):
         self.pending |= mask
+
+    def set_total_gain_db(self, db, before_first_block=False):
+        """storeTotalGainDb; before the first block (prepareToPlay) the ramp is set to the value, afterwards it runs."""
+        self.p.totalGainDb = db
+        if before_first_block:
+            gdb = float(self.p.totalGainDb)
+            g0 = 10.0 ** (gdb * 0.05) if gdb > -100.0 else 0.0
+            self.state[83:88] = [1.0, g0, g0, 0.0, 0.0]
+
+    def sync(self, requested):
+        """prepareToPlay / reset with the bypass already requested (setBypass on the message thread): the fade is set, not
+        run (src/eqprocessor/EQProcessor.Core.cpp:285-288, 800-802)."""
+        self.effective = bool(requested)
+        self.fade.current = self.fade.target = 0.0 if requested else 1.0
+        self.fade.step, self.fade.remaining = 0.0, 0
 
     def callback(self, xl, xr, requested):
         L = lib()
@@ -484,6 +504,84 @@ def convproc_latency_schedule(ir, x, block, peak_per_callback, mix=0.6, sr=48000
                 dry[i] = dry_at(lo + i, d)
         out[lo:lo + block] = (wet[lo:lo + block] * wg) + (dry * dg)
     return out
+
+
+class ConvProcStream:
+    """ConvolverProcessor::process for one stereo stream, callback by callback, with everything that can move on a live
+    stream at once: the mix ramp (src/convolver/ConvolverProcessor.Runtime.cpp:340-375, 591-607), the latency
+    compensation with its cross-fade (:263-290, 394-540) and the steady paths (:573-585, :611-676).  The two channels
+    share the smoothers, as in the reference."""
+
+    def __init__(self, ir_l, ir_r, block, mix, peak, sr=48000.0, smoothing_time=0.1, scale=1.0, spec=None):
+        self.block, self.L = block, lib()
+        self.nucs = [Nuc(), Nuc()]
+        assert self.nucs[0].set_impulse(ir_l, block, scale=scale, spec=spec)
+        assert self.nucs[1].set_impulse(ir_r, block, scale=scale, spec=spec)
+        self.mix = LinearRamp(float(np.float32(mix)), sr, smoothing_time)
+        self.fade = LinearRamp(1.0, sr, 0.02)
+        self.lat_cur = self.lat_tgt = self.old = float(block + peak)
+        self.hist = [np.zeros(0), np.zeros(0)]
+
+    def _dry(self, ch, i, d):
+        j = i - int(d)
+        return self.hist[ch][j] if j >= 0 else 0.0
+
+    def callback(self, xl, xr, mix, peak):
+        B, eps = self.block, self.L.orc_equal_power_sin
+        x = [np.ascontiguousarray(xl, dtype=np.float64), np.ascontiguousarray(xr, dtype=np.float64)]
+        lo = len(self.hist[0])
+        for ch in range(2):
+            self.hist[ch] = np.concatenate([self.hist[ch], x[ch]])
+        total = float(B + peak)
+        if abs(self.lat_tgt - total) >= 2.0 and self.fade.remaining <= 0:
+            self.old = self.lat_cur
+            self.fade.current = self.fade.target = 0.0
+            self.fade.set_target(1.0)
+            self.lat_tgt = total
+        mixd = float(np.float32(mix))
+        if abs(self.mix.target - mixd) > 1.0e-5:
+            self.mix.set_target(mixd)
+        smoothing = self.mix.remaining > 0
+        needs_conv = smoothing or mixd > 0.001
+        # dry block
+        dry = [np.empty(B), np.empty(B)]
+        if self.fade.remaining > 0:
+            gains = []
+            while len(gains) < B:
+                gains.append(self.fade.next())
+                if self.fade.remaining <= 0:
+                    break
+            for ch in range(2):
+                for i in range(B):
+                    new = self._dry(ch, lo + i, self.lat_tgt)
+                    if i < len(gains):
+                        new = new * gains[i] + self._dry(ch, lo + i, self.old) * (1.0 - gains[i])
+                    dry[ch][i] = new
+            if self.fade.remaining <= 0:
+                self.lat_cur = self.lat_tgt
+                self.old = self.lat_cur
+        else:
+            d = int(self.lat_cur + 0.5)
+            for ch in range(2):
+                for i in range(B):
+                    dry[ch][i] = self._dry(ch, lo + i, d)
+        if not needs_conv:
+            return dry[0], dry[1]
+        wet = [self.nucs[ch].run(x[ch], B) for ch in range(2)]
+        wet = [np.where(~(np.abs(w) < 1.0e300), 0.0, w) for w in wet]
+        out = [np.empty(B), np.empty(B)]
+        if smoothing:
+            for i in range(B):
+                m = self.mix.next()
+                wg, dg = eps(m) * 1.0, eps(1.0 - m)
+                for ch in range(2):
+                    out[ch][i] = (wet[ch][i] * wg) + (dry[ch][i] * dg)
+        else:
+            wg = eps(mixd) * 1.0
+            dg = eps(1.0 - mixd) if mixd < 0.999 else 0.0
+            for ch in range(2):
+                out[ch] = (wet[ch] * wg) + (dry[ch] * dg)
+        return out[0], out[1]
 
 
 def outfilter_design(conv_is_last, hc_mode=1, lc_mode=0, lp_mode=1, sr=48000.0):

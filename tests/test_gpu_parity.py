@@ -1419,3 +1419,82 @@ def test_non_power_of_two_tail_partition_is_refused(amd, oracle):
     assert e.value.status == -5 and "1536" in str(e.value)
     eng.set_impulse(0, ir, ir, spec=amd.FilterSpec.defaults(tail_mode=0, tail_start_seconds=0.5, tail_l1l2_multiplier=8))
     eng.close()
+
+
+@pytest.mark.parametrize("seed", list(range(11, 31)))
+def test_whole_chain_random_transition_sequence(amd, oracle, seed):
+    """Everything that can move on a live stream, at once and at random: per call and stream the mix, the IR peak
+    latency, the EQ bypass request, band-reset requests (single bands / all) and the total gain change with some
+    probability; silent callbacks are sprinkled in so that pending resets fire.  Chain: processor-level convolver ->
+    EQ -> output filter -> make-up gain through cpq_engine_process_block, against the per-callback restatements
+    (ConvProcStream, EqWithBypass, the output-filter oracle) chained the same way."""
+    O = oracle
+    rng = np.random.default_rng(seed)
+    S, T, calls = 3, 3, 14
+    n = T * B
+    irs = [O.gen_ir(int(rng.integers(600, 4000)), stream=s, channel=ch) for s in range(S) for ch in range(2)]
+    ir_len = max(len(h) for h in irs)
+    irs = [np.concatenate([h, np.zeros(ir_len - len(h))]) for h in irs]
+    x = make_inputs(O, S, calls * n)
+    for _ in range(6):                                   # silent callbacks (exact zeros or 1e-9 noise)
+        s, cb = int(rng.integers(0, S)), int(rng.integers(0, calls * T))
+        x[2 * s:2 * s + 2, cb * B:(cb + 1) * B] = 0.0 if rng.random() < 0.5 else rng.standard_normal((2, B)) * 1e-9
+    po = O.eq_params_bench(0.2)
+    po.bands[5].gain = 0.0
+    q = O.outfilter_design(0, 1, 0, 1, 48000.0)
+    makeup = [1.0, 0.7, 1.3]
+    mix = [float(rng.uniform(0.2, 1.0)) for _ in range(S)]
+    peak = [int(rng.integers(0, 1500)) for _ in range(S)]
+    byp = [False] * S
+    gain_db = [0.0] * S
+    eng = amd.BatchedEngine(S, max_ir_len=ir_len, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+        eng.set_convproc_params(s, mix=mix[s], ir_peak_latency=peak[s])
+        eng.set_gains(s, 1.0, makeup[s])
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    if seed % 2:                                          # odd seeds: sequential EQ kernel, even seeds: time-parallel
+        eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    eng.enable_output_filter(True)
+    conv = [O.ConvProcStream(irs[2 * s], irs[2 * s + 1], B, mix[s], peak[s]) for s in range(S)]
+    eqs = [O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B) for _ in range(S)]
+    ofs = [None] * S
+    ref = np.empty_like(x)
+    outs = []
+    for k in range(calls):
+        for s in range(S):
+            if k > 0 and rng.random() < 0.3:
+                mix[s] = float(rng.uniform(0.05, 1.0))
+            if k > 0 and rng.random() < 0.3:
+                peak[s] = int(rng.integers(0, 1500)) if rng.random() < 0.8 else peak[s] + 1
+            if rng.random() < 0.25:
+                byp[s] = not byp[s]
+            eng.set_convproc_params(s, mix=mix[s], ir_peak_latency=peak[s])
+            eng.set_eq_bypass(s, byp[s])
+            if k == 0:
+                eqs[s].sync(byp[s])                     # requested before the first block: the state follows at once
+            if rng.random() < 0.2:
+                mask = 0xFFFFFFFF if rng.random() < 0.4 else int(rng.integers(1, 1 << 20))
+                eng.request_band_reset(s, mask)
+                eqs[s].request_band_reset(mask)
+            if rng.random() < 0.15:
+                gain_db[s] = float(rng.uniform(-9.0, 3.0))
+                pa = _copy_params(po, amd.eq_params_default())
+                pa.total_gain_db = gain_db[s]
+                eng.set_eq_params(s, pa)
+                eqs[s].set_total_gain_db(gain_db[s], before_first_block=(k == 0))
+        outs.append(eng.process(x[:, k * n:(k + 1) * n]))
+        for s in range(S):
+            for t in range(T):
+                o = (k * T + t) * B
+                a, b = conv[s].callback(x[2 * s, o:o + B], x[2 * s + 1, o:o + B], mix[s], peak[s])
+                a, b = eqs[s].callback(np.ascontiguousarray(a), np.ascontiguousarray(b), byp[s])
+                a, b, ofs[s] = O.outfilter_process_stereo(a, b, q, ofs[s])
+                ref[2 * s, o:o + B], ref[2 * s + 1, o:o + B] = a * makeup[s], b * makeup[s]
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    for s in range(S):
+        err = np.abs(y[2 * s:2 * s + 2] - ref[2 * s:2 * s + 2]).max()
+        assert err <= 1e-12, (seed, s, err)
