@@ -1425,7 +1425,7 @@ def test_non_power_of_two_tail_partition_is_refused(amd, oracle):
 def test_whole_chain_random_transition_sequence(amd, oracle, seed):
     """Everything that can move on a live stream, at once and at random: per call and stream the mix, the IR peak
     latency, the EQ bypass request, band-reset requests (single bands / all) and the total gain change with some
-    probability; silent callbacks are sprinkled in so that pending resets fire.  Chain: processor-level convolver ->
+    probability, DSPCore's convolver bypass toggles now and then, every third seed runs EQ -> conv with trim gains; silent callbacks are sprinkled in so that pending resets fire.  Chain: processor-level convolver ->
     EQ -> output filter -> make-up gain through cpq_engine_process_block, against the per-callback restatements
     (ConvProcStream, EqWithBypass, the output-filter oracle) chained the same way."""
     O = oracle
@@ -1443,6 +1443,9 @@ def test_whole_chain_random_transition_sequence(amd, oracle, seed):
     po.bands[5].gain = 0.0
     q = O.outfilter_design(0, 1, 0, 1, 48000.0)
     makeup = [1.0, 0.7, 1.3]
+    order = amd.CPQ_ORDER_EQ_THEN_CONV if seed % 3 == 0 else amd.CPQ_ORDER_CONV_THEN_EQ
+    trim = [0.5, 1.0, 1.7]                               # convolverInputTrimGain, used in EQ -> conv order
+    conv_byp = False
     mix = [float(rng.uniform(0.2, 1.0)) for _ in range(S)]
     peak = [int(rng.integers(0, 1500)) for _ in range(S)]
     byp = [False] * S
@@ -1451,19 +1454,23 @@ def test_whole_chain_random_transition_sequence(amd, oracle, seed):
     for s in range(S):
         eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
         eng.set_convproc_params(s, mix=mix[s], ir_peak_latency=peak[s])
-        eng.set_gains(s, 1.0, makeup[s])
+        eng.set_gains(s, trim[s], makeup[s])
+    eng.set_order(order)
     eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
     if seed % 2:                                          # odd seeds: sequential EQ kernel, even seeds: time-parallel
         eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
     eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
     eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
     eng.enable_output_filter(True)
-    conv = [O.ConvProcStream(irs[2 * s], irs[2 * s + 1], B, mix[s], peak[s]) for s in range(S)]
+    conv = [None] * S        # created at the first block the convolver stage sees: what is set before that applies at once
     eqs = [O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B) for _ in range(S)]
     ofs = [None] * S
     ref = np.empty_like(x)
     outs = []
     for k in range(calls):
+        if rng.random() < 0.12:                          # DSPCore's convBypassed: the convolver stage is not called
+            conv_byp = not conv_byp
+        eng.set_conv_bypass(conv_byp)
         for s in range(S):
             if k > 0 and rng.random() < 0.3:
                 mix[s] = float(rng.uniform(0.05, 1.0))
@@ -1489,9 +1496,21 @@ def test_whole_chain_random_transition_sequence(amd, oracle, seed):
         for s in range(S):
             for t in range(T):
                 o = (k * T + t) * B
-                a, b = conv[s].callback(x[2 * s, o:o + B], x[2 * s + 1, o:o + B], mix[s], peak[s])
-                a, b = eqs[s].callback(np.ascontiguousarray(a), np.ascontiguousarray(b), byp[s])
-                a, b, ofs[s] = O.outfilter_process_stereo(a, b, q, ofs[s])
+                a, b = x[2 * s, o:o + B].copy(), x[2 * s + 1, o:o + B].copy()
+                if not conv_byp and conv[s] is None:
+                    conv[s] = O.ConvProcStream(irs[2 * s], irs[2 * s + 1], B, mix[s], peak[s])
+                if order == amd.CPQ_ORDER_CONV_THEN_EQ:
+                    if not conv_byp:
+                        a, b = conv[s].callback(a, b, mix[s], peak[s])
+                    a, b = eqs[s].callback(np.ascontiguousarray(a), np.ascontiguousarray(b), byp[s])
+                else:
+                    a, b = eqs[s].callback(a, b, byp[s])
+                    if not conv_byp:
+                        if abs(trim[s] - 1.0) > 1e-12:
+                            a, b = a * trim[s], b * trim[s]
+                        a, b = conv[s].callback(a, b, mix[s], peak[s])
+                if not (conv_byp and byp[s]):            # the output filter runs when the convolver or the EQ is active
+                    a, b, ofs[s] = O.outfilter_process_stereo(np.ascontiguousarray(a), np.ascontiguousarray(b), q, ofs[s])
                 ref[2 * s, o:o + B], ref[2 * s + 1, o:o + B] = a * makeup[s], b * makeup[s]
     y = np.concatenate(outs, axis=1)
     eng.close()

@@ -34,6 +34,8 @@ def main():
     amd.BatchedEngine.request_band_reset = lambda self, s, m=0xFFFFFFFF: (LOG.append((CALL[0], s, "reset", hex(m))), _orig_reset(self, s, m))[1]
     amd.BatchedEngine.set_eq_bypass = lambda self, s, b: (LOG.append((CALL[0], s, "bypass", bool(b))), _orig_byp(self, s, b))[1]
     amd.BatchedEngine.set_convproc_params = lambda self, s, **kw: (LOG.append((CALL[0], s, "convproc", kw)), _orig_cp(self, s, **kw))[1]
+    _orig_cb = amd.BatchedEngine.set_conv_bypass
+    amd.BatchedEngine.set_conv_bypass = lambda self, b: (LOG.append((CALL[0], -1, "conv bypass", bool(b))), _orig_cb(self, b))[1]
     amd.BatchedEngine.set_eq_params = lambda self, s, p: (LOG.append((CALL[0], s, "eq gain dB", round(p.total_gain_db, 4))), _orig_eq(self, s, p))[1]
     for seed in [int(a) for a in sys.argv[1:]]:
         LOG.clear(); OUT.clear(); CALL[0] = 0
