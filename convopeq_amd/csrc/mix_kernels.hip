@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_agc_ramp(double* data, int64_t chStride
 }
 
 
-// ---- FilterSpec tail layers run at the reference's own partition size (cpq_api.cpp, SpecTail) -------------------
+// ---- FilterSpec tail layers run at the reference's own partition size (engine_conv.cpp, SpecTail) -------------------
 // dst[c][dstOff + i] = src[c][srcOff + i], i < n: input accumulation of a tail layer (inputAccBuf, NUC.cpp:1433-1452)
 __global__ __launch_bounds__(256) void k_rows_copy(const double* __restrict__ src, int64_t srcStride, int64_t srcOff,
                                                    double* __restrict__ dst, int64_t dstStride, int64_t dstOff, int n)
