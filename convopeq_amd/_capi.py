@@ -136,6 +136,7 @@ SYMBOLS = {
     "cpq_eq_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),
     "cpq_eq_set_bypass": (C.c_int32, [_E, C.c_int32, C.c_int32]),
     "cpq_eq_request_band_reset": (C.c_int32, [_E, C.c_int32, C.c_uint32]),
+    "cpq_eq_request_agc_reset": (C.c_int32, [_E, C.c_int32]),
     "cpq_eq_set_mode": (C.c_int32, [_E, C.c_int32]),
     "cpq_eq_reset": (C.c_int32, [_E]),
     "cpq_outfilter_design": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(BiquadCoeffs)]),

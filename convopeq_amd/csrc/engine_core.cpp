@@ -291,6 +291,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->eqParamsSet.assign(d->n_streams, 0);
     e->eqBypass.assign(d->n_streams, cpq_engine::EqBypass{});
     e->eqResetPending.assign(d->n_streams, 0u);
+    e->agcResetPending.assign(d->n_streams, 0);
     e->latFade.assign(d->n_streams, cpq_engine::LatencyFade{});
     e->trimHost.assign(d->n_streams, 1.0);
     e->makeupHost.assign(d->n_streams, 1.0);

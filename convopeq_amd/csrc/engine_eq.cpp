@@ -32,6 +32,7 @@ void syncEqBypass(cpq_engine* e)
 {
     e->anyEqBypass = false;
     std::fill(e->eqResetPending.begin(), e->eqResetPending.end(), 0u);      // the caller zeroes every state anyway
+    std::fill(e->agcResetPending.begin(), e->agcResetPending.end(), 0);
     e->anyEqReset = false;
     for (auto& b : e->eqBypass) {
         b.effective = b.requested;
@@ -230,7 +231,17 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
     const int n = T * e->P;
     const int S = e->desc.n_streams;
-    if (!e->anyEqBypass && !e->anyEqReset) { e->eqProcessed = true; return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr); }
+    auto agcReset = [e](int s) -> int {        // rtAgcCurrentGainShadow = 1, envelopes = 0 (Processing.cpp:586-593, 1070-1077)
+        if (e->agcState) CPQ_HIP(e, hipMemsetAsync(e->agcState + (size_t)s * 3, 0, sizeof(double) * 3, e->stream));
+        e->agcResetPending[s] = 0;
+        return CPQ_OK;
+    };
+    if (!e->anyEqBypass && !e->anyEqReset) {
+        for (int s = 0; s < S; ++s)
+            if (e->agcResetPending[s]) { const int rc = agcReset(s); if (rc != CPQ_OK) return rc; }
+        e->eqProcessed = true;
+        return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr);
+    }
     const int cbs = n / e->B;
     const int total = std::max(1, (int)(e->sampleRate * 0.005 + 0.5));       // BYPASS_FADE_TIME_SEC (EQProcessor.h:564)
     enum : char { kNormal = 0, kFade = 1, kPass = 2 };
@@ -335,6 +346,7 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
                             CPQ_HIP(e, hipMemsetAsync(e->svfState + ((size_t)(2 * s + ch) * kBands + b) * 2, 0, sizeof(double) * 2, e->stream));
             }
             rc = setEqStreamMode(e, s, k == kPass ? 2 : k == kFade ? 1 : 0);
+            if (rc == CPQ_OK && e->agcResetPending[s] && k != kPass) rc = agcReset(s);      // a bypassed block returns before it
             pass[s] = k == kPass;
             onHost[s] = k == kFade;
             lenHost[s] = 0;
@@ -510,6 +522,17 @@ int32_t cpq_eq_request_band_reset(cpq_engine* e, int32_t stream, uint32_t bandMa
         e->eqResetPending[s] |= m;
         e->anyEqReset = e->anyEqReset || e->eqResetPending[s] != 0u;
     }
+    return CPQ_OK;
+}
+
+int32_t cpq_eq_request_agc_reset(cpq_engine* e, int32_t stream)
+{
+    if (!e) return CPQ_ERR_INVALID_ARG;
+    if (stream != CPQ_ALL_STREAMS && (stream < 0 || stream >= e->desc.n_streams))
+        return fail(e, CPQ_ERR_INVALID_ARG, "stream %d out of range", stream);
+    const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
+    const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    for (int s = s0; s < s1; ++s) e->agcResetPending[s] = 1;
     return CPQ_OK;
 }
 

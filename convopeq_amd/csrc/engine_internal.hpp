@@ -145,6 +145,7 @@ struct cpq_engine {
     // requestBandReset (EQProcessor.h; Processing.cpp:595-624): bands whose state is cleared at the first callback where
     // that is safe -- the block is silent, or a bypass fade is running
     std::vector<uint32_t> eqResetPending;
+    std::vector<char> agcResetPending;  // requestAgcReset: envelopes and gain back to their initial values at the next processed block
     bool anyEqReset = false;
     int* silentDev = nullptr;           // [streams][callbacks]
     int* silentHost = nullptr;          // pinned

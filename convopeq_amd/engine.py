@@ -214,6 +214,9 @@ class BatchedEngine:
     def request_band_reset(self, stream, band_mask=0xFFFFFFFF):
         self._ck(self._lib.cpq_eq_request_band_reset(self._h, stream, band_mask))
 
+    def request_agc_reset(self, stream):
+        self._ck(self._lib.cpq_eq_request_agc_reset(self._h, stream))
+
     def set_eq_bypass(self, stream, bypassed):
         self._ck(self._lib.cpq_eq_set_bypass(self._h, stream, int(bypassed)))
 

@@ -282,6 +282,9 @@ int32_t cpq_eq_set_bypass(cpq_engine* e, int32_t stream, int32_t bypassed);
  * stays pending.  While a request is pending on a playing stream each EQ call synchronises the engine's stream once
  * (the silence flags are read back); without a pending request nothing changes. */
 int32_t cpq_eq_request_band_reset(cpq_engine* e, int32_t stream, uint32_t band_mask);
+/* replaces EQProcessor::requestAgcReset (src/eqprocessor/EQProcessor.h:538-541): at the stream's next processed block the AGC
+ * envelopes return to 0 and its gain to 1 (src/eqprocessor/EQProcessor.Processing.cpp:586-593, 1070-1077). */
+int32_t cpq_eq_request_agc_reset(cpq_engine* e, int32_t stream);
 /* EQ kernel choice.  AUTO: time-parallel kernel (per band: zero-state chunk runs + state scan; equal to the
  * sequential recurrence up to rounding, measured <= 3e-15) whenever the host can prove the reference's state
  * guards cannot trip, else the sequential kernel.  SEQUENTIAL: lane-skewed kernel that reproduces the

@@ -170,6 +170,7 @@ public:
     // EQProcessor::setBypassFromRT / requestBandReset, per stream
     void setBypassFromRT(int stream, bool bypassed) { cpq_eq_set_bypass(e_.get(), stream, bypassed ? 1 : 0); }
     void requestBandReset(int stream, uint32_t mask) { cpq_eq_request_band_reset(e_.get(), stream, mask); }
+    void requestAgcReset(int stream) { cpq_eq_request_agc_reset(e_.get(), stream); }
     // DSPCore's remaining per-block routing values
     void setConvolverBypassed(bool bypassed) { cpq_engine_set_conv_bypass(e_.get(), bypassed ? 1 : 0); }
     void setGains(int stream, double convolverInputTrimGain, double outputMakeupGain)

@@ -313,9 +313,13 @@ class EqWithBypass:
         self.fade = LinearRamp(1.0, sr, 0.005)
         self.effective = False
         self.pending = 0                                    # rtDeferredBandResetMask
+        self.agc_reset = False                              # agcResetSerial moved
 
     def request_band_reset(self, mask=0xFFFFFFFF):
         self.pending |= mask
+
+    def request_agc_reset(self):
+        self.agc_reset = True
 
     def set_total_gain_db(self, db, before_first_block=False):
         """storeTotalGainDb; before the first block (prepareToPlay) the ramp is set to the value, afterwards it runs."""
@@ -346,6 +350,9 @@ class EqWithBypass:
         if requested and self.effective and not transition:
             return xl.copy(), xr.copy()
         basic = requested or self.effective or transition
+        if self.agc_reset:                                  # :586-593 / :1070-1077: envelopes 0, gain 1
+            self.state[80:83] = 0.0
+            self.agc_reset = False
         if self.pending:                                    # :565-568, :603-624 (parameter path: silence only, :1083-1112)
             silent = not (np.any(np.abs(xl) > 1.0e-8) or np.any(np.abs(xr) > 1.0e-8))
             if basic or silent:

@@ -1517,3 +1517,38 @@ def test_whole_chain_random_transition_sequence(amd, oracle, seed):
     for s in range(S):
         err = np.abs(y[2 * s:2 * s + 2] - ref[2 * s:2 * s + 2]).max()
         assert err <= 1e-12, (seed, s, err)
+
+
+def test_eq_agc_reset_request(amd, oracle):
+    """requestAgcReset: the AGC envelopes and gain of the stream restart at its next processed block -- also when that
+    block comes only after a bypass has been released."""
+    O = oracle
+    S, T, calls = 2, 4, 8
+    n = T * B
+    po = O.eq_params_bench(0.2)
+    po.agcEnabled = 1
+    x = make_inputs(O, S, calls * n)
+    x[0:2] *= 3.0                                        # loud: the AGC gain settles well below 1
+    eng = amd.BatchedEngine(S, max_ir_len=B, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    refs = [O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, B) for _ in range(S)]
+    byp1 = [0, 0, 0, 1, 1, 0, 0, 0]                      # stream 1: request while bypassed, consumed at the release
+    outs, ref = [], np.empty_like(x)
+    for k in range(calls):
+        if k == 3:
+            eng.request_agc_reset(0); refs[0].request_agc_reset()
+        if k == 4:
+            eng.request_agc_reset(1); refs[1].request_agc_reset()
+        eng.set_eq_bypass(1, byp1[k])
+        outs.append(eng.eq_process(x[:, k * n:(k + 1) * n]))
+        for s in range(S):
+            for t in range(T):
+                o = (k * T + t) * B
+                a, b = refs[s].callback(x[2 * s, o:o + B].copy(), x[2 * s + 1, o:o + B].copy(), bool(byp1[k]) if s == 1 else False)
+                ref[2 * s, o:o + B], ref[2 * s + 1, o:o + B] = a, b
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    assert np.array_equal(y, ref)
+    plain = O.eq_process_stereo(x[0], x[1], po)[0]
+    assert np.abs(plain[3 * n:4 * n] - y[0, 3 * n:4 * n]).max() > 1e-3      # the reset is audible
