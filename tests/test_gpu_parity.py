@@ -1552,3 +1552,76 @@ def test_eq_agc_reset_request(amd, oracle):
     assert np.array_equal(y, ref)
     plain = O.eq_process_stereo(x[0], x[1], po)[0]
     assert np.abs(plain[3 * n:4 * n] - y[0, 3 * n:4 * n]).max() > 1e-3      # the reset is audible
+
+
+def test_abi_argument_errors_leave_the_engine_usable(amd, oracle):
+    """Every entry point with arguments it must refuse (null handle, null buffers, stream out of range, sizes that are
+    not block multiples, calls before the data they need, non-finite gains): a negative status, a message in
+    cpq_last_error, no crash -- and the engine computes the same result afterwards."""
+    import ctypes as C
+    O = oracle
+    K = amd._capi
+    L = K.load()
+    eng = amd.BatchedEngine(2, max_ir_len=2048, max_blocks_per_call=2)
+    h = eng._h
+    n = 2 * B
+    x = make_inputs(O, 2, n)
+    buf_in = np.ascontiguousarray(x)
+    buf_out = np.empty_like(buf_in)
+    dp = lambda a: a.ctypes.data_as(K.c_double_p)
+    # before set_impulse / set_eq_params / set_outfilter_params
+    assert L.cpq_conv_process(h, dp(buf_in), dp(buf_out), n) == K.CPQ_ERR_NOT_READY
+    assert L.cpq_eq_process(h, dp(buf_in), dp(buf_out), n) == K.CPQ_ERR_NOT_READY
+    assert L.cpq_outfilter_process(h, dp(buf_in), dp(buf_out), n) == K.CPQ_ERR_NOT_READY
+    assert L.cpq_engine_process_block(h, dp(buf_in), dp(buf_out), n) == K.CPQ_ERR_NOT_READY
+    assert L.cpq_conv_is_ready(h) == 0 and len(L.cpq_last_error(h)) > 0
+    ir = O.gen_ir(2048)
+    eng.set_impulse(amd.CPQ_ALL_STREAMS, ir, ir)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(O.eq_params_bench(0.2), amd.eq_params_default()))
+    y0 = eng.process(x)
+    eng.conv_reset(); eng.eq_reset()
+    null = C.c_void_p(None)
+    bad = []
+    bad.append(L.cpq_conv_process(null, dp(buf_in), dp(buf_out), n))
+    bad.append(L.cpq_conv_process(h, None, dp(buf_out), n))
+    bad.append(L.cpq_conv_process(h, dp(buf_in), None, n))
+    bad.append(L.cpq_conv_process(h, dp(buf_in), dp(buf_out), 0))
+    bad.append(L.cpq_conv_process(h, dp(buf_in), dp(buf_out), -B))
+    bad.append(L.cpq_conv_process(h, dp(buf_in), dp(buf_out), B + 1))
+    bad.append(L.cpq_conv_process(h, dp(buf_in), dp(buf_out), 3 * B))                  # more than max_blocks_per_call
+    bad.append(L.cpq_conv_process_device(h, C.c_void_p(8), C.c_void_p(16), n))         # misaligned device pointers
+    bad.append(L.cpq_conv_set_impulse(h, 2, dp(ir), dp(ir), 2048, 1.0, 0, None))      # stream out of range
+    bad.append(L.cpq_conv_set_impulse(h, 0, None, dp(ir), 2048, 1.0, 0, None))
+    bad.append(L.cpq_conv_set_impulse(h, 0, dp(ir), dp(ir), 0, 1.0, 0, None))
+    bad.append(L.cpq_conv_set_impulse(h, 0, dp(ir), dp(ir), 4096, 1.0, 0, None))      # longer than max_ir_len
+    bad.append(L.cpq_eq_set_params(h, 0, None))
+    bad.append(L.cpq_eq_set_params(h, -2, C.byref(amd.eq_params_default())))
+    bad.append(L.cpq_eq_set_bypass(h, 7, 1))
+    bad.append(L.cpq_eq_request_band_reset(h, 7, 1))
+    bad.append(L.cpq_eq_request_agc_reset(h, -3))
+    bad.append(L.cpq_eq_set_mode(h, 9))
+    bad.append(L.cpq_engine_set_order(h, 5))
+    bad.append(L.cpq_engine_set_conv_level(h, 5))
+    bad.append(L.cpq_engine_set_gains(h, 0, float("nan"), 1.0))
+    bad.append(L.cpq_engine_set_gains(h, 0, 1.0, float("inf")))
+    bad.append(L.cpq_engine_set_gains(h, 9, 1.0, 1.0))
+    bad.append(L.cpq_convproc_set_params(h, 0, None))
+    bad.append(L.cpq_convproc_set_params(h, 0, C.byref(K.ConvProcParams(1.5, 0, 0, 0.0))))      # mix > 1
+    bad.append(L.cpq_convproc_set_params(h, 0, C.byref(K.ConvProcParams(0.5, 0, -1, 0.0))))     # negative latency
+    bad.append(L.cpq_convproc_set_params(h, 0, C.byref(K.ConvProcParams(0.5, 0, 0, 5.0))))      # smoothing time out of range
+    bad.append(L.cpq_outfilter_set_params(h, 0, 0, 7, 0, 0))
+    bad.append(L.cpq_engine_prepare(h, -1.0, B))
+    bad.append(L.cpq_engine_prepare(h, 48000.0, 64 * B))                               # beyond the engine's call size
+    bad.append(L.cpq_profile_read(h, 99, None, None))
+    bad.append(L.cpq_convproc_delay(h, 5))
+    assert all(b < 0 for b in bad), bad
+    created = K._E()
+    d = K.EngineDesc(C.sizeof(K.EngineDesc), 0, 0, 512, 4096, 4, 0, 0, 48000.0, 0, 0)            # zero streams
+    assert L.cpq_engine_create(C.byref(d), C.byref(created)) < 0 and not created.value
+    d = K.EngineDesc(C.sizeof(K.EngineDesc), 99, 1, 512, 4096, 4, 0, 0, 48000.0, 0, 0)           # no such device
+    assert L.cpq_engine_create(C.byref(d), C.byref(created)) < 0 and not created.value
+    assert L.cpq_engine_create(None, C.byref(created)) < 0
+    L.cpq_engine_destroy(None)
+    # nothing above has touched the state
+    assert np.array_equal(eng.process(x), y0)
+    eng.close()
