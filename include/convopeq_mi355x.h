@@ -183,8 +183,9 @@ int64_t cpq_engine_arena_bytes(const cpq_engine* e);
  * and EQProcessor::prepareToPlay(double,int) (src/eqprocessor/EQProcessor.Core.cpp:679-826):
  * publishes the rate, zeroes all run-time state (FDL, overlap history, SVF state) and, when the rate changed, re-designs
  * the EQ and OutputFilter coefficients from the parameters set so far (the reference rebuilds its band nodes on a rate
- * change).  IR spectra are not touched: an IR belongs to a rate, load it again if needed.  max_block must not exceed
- * block_size * max_blocks_per_call. */
+ * change).  The smoothers take their present targets at once (mix, total gain, EQ bypass fade, latency), pending band /
+ * AGC reset requests are dropped with the state they would have cleared.  IR spectra are not touched: an IR belongs to
+ * a rate, load it again if needed.  max_block must not exceed block_size * max_blocks_per_call. */
 int32_t cpq_engine_prepare(cpq_engine* e, double sample_rate, int32_t max_block);
 int32_t cpq_engine_set_order(cpq_engine* e, int32_t order);
 /* Pin / unpin a caller buffer that is passed to the host-pointer entry points (cpq_*_process, cpq_engine_process_block):
@@ -225,7 +226,7 @@ int32_t cpq_conv_latency(const cpq_engine* e);
 int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan);
 
 /* ------------------------------------------- convolver, processor level (N1) */
-/* Steady-state restatement of ConvolverProcessor::process(AudioBlock<double>&)
+/* Restatement of ConvolverProcessor::process(AudioBlock<double>&), steady state and the transitions of a live stream,
  * (src/convolver/ConvolverProcessor.Runtime.cpp:209-810) around the kernel-level convolver:
  *   dry signal through a delay line of (algorithmLatency + irPeakLatency) samples (:266-288, :549-567),
  *   wet = convolver output with NaN / Inf / |x| >= 1e300 replaced by 0 (:50-60, :722),
