@@ -317,3 +317,38 @@ def test_minimum_phase_conversion(amd, O):
     with pytest.raises(amd.CpqError) as ex:
         amd.ir_convert_to_minimum_phase(np.ones((1, 2097153)))           # 4 n above the reference's limit
     assert ex.value.status == -5
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_prepare_random_sweep(amd, O, seed):
+    """Seeded sweep of cpq_ir_prepare against the restatement: 1-3 channels, 50..60000 samples, decays, peak positions,
+    DC offsets, trailing silence, sample rates, target lengths from 10 ms to 1.2 s, as-is and minimum phase, with and
+    without an IR playing now."""
+    rng = np.random.default_rng(seed)
+    ch = int(rng.integers(1, 4))
+    n = int(np.exp(rng.uniform(np.log(50), np.log(60000))))
+    rate = float(rng.choice([44100.0, 48000.0, 96000.0]))
+    t = np.arange(n, dtype=np.float64)
+    peak_at = int(rng.integers(0, max(1, n // 3)))
+    ir = rng.standard_normal((ch, n)) * np.exp(-np.abs(t - peak_at) / rng.uniform(5.0, n / 2.0)) * rng.uniform(0.01, 0.9)
+    ir += rng.choice([0.0, 0.0, 0.02])                      # DC offset
+    ir = np.clip(ir, -1.0, 1.0)
+    if rng.random() < 0.4:
+        ir[:, int(n * rng.uniform(0.5, 0.95)):] = 0.0       # trailing silence
+    secs = float(rng.choice([0.01, 0.05, 0.3, 1.0, 1.2]))
+    minimum = bool(rng.random() < 0.4)
+    cur = None
+    cur_scale = 1.0
+    if rng.random() < 0.4:
+        cur = rng.standard_normal((int(rng.integers(1, 3)), int(rng.integers(100, 5000)))) * float(rng.choice([1e-4, 0.05, 0.5]))
+        cur_scale = float(rng.uniform(0.05, 2.0))
+    got = amd.ir_prepare(ir, rate, rate, secs, current_ir=cur, current_scale=cur_scale, phase_mode=2 if minimum else 0)
+    ref = O.prepare(ir, rate, rate, secs, cur, cur_scale, minimum_phase=minimum)
+    assert got["ir"].shape == ref["ir"].shape
+    tol_ir = 1e-9 if minimum else 1e-15
+    assert np.abs(got["ir"] - ref["ir"]).max() <= tol_ir * max(1.0, np.abs(ref["ir"]).max()), (seed, minimum)
+    assert got["scale"]["has_scale_factor"] == ref["scale"]["has_scale_factor"]
+    rel = 1e-8 if minimum else 1e-12
+    for k in ("scale_factor", "peak_value", "rms_value", "frequency_peak_gain"):
+        assert abs(got["scale"][k] - ref["scale"][k]) <= rel * max(abs(ref["scale"][k]), 1e-300), (seed, k)
+    assert abs(got["ir_peak_latency"] - ref["ir_peak_latency"]) <= (1 if minimum else 0)
