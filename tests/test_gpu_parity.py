@@ -1625,3 +1625,98 @@ def test_abi_argument_errors_leave_the_engine_usable(amd, oracle):
     # nothing above has touched the state
     assert np.array_equal(eng.process(x), y0)
     eng.close()
+
+
+def test_two_engines_interleaved_and_no_device_memory_leak(amd, oracle):
+    """Handles are independent: two engines with different configurations, called alternately on the same device, give
+    what each gives alone.  Creating and destroying engines that have exercised every lazily allocated buffer (FilterSpec
+    tail layers, processor-level ring, ramps, bypass cross-fade, AGC, silence flags, profiling events) returns the
+    device memory."""
+    import torch
+    O = oracle
+    x = make_inputs(O, 2, 8 * B)
+
+    def build(kind):
+        if kind == 0:
+            e = amd.BatchedEngine(2, max_ir_len=9000, max_blocks_per_call=4)
+            irs = [O.gen_ir(9000, stream=7, channel=c) for c in range(2)]
+            e.set_impulse(amd.CPQ_ALL_STREAMS, irs[0], irs[1], spec=amd.FilterSpec.defaults(hc_mode=0))
+            po = O.eq_params_bench(0.2); po.agcEnabled = 1
+            e.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+            e.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+            e.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+            e.enable_output_filter(True)
+        else:
+            e = amd.BatchedEngine(2, block_size=256, max_ir_len=3000, max_blocks_per_call=8)
+            irs = [O.gen_ir(3000, stream=3, channel=c) for c in range(2)]
+            e.set_impulse(amd.CPQ_ALL_STREAMS, irs[0], irs[1], direct_head=True)
+            e.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(O.eq_params_bench(0.0), amd.eq_params_default()))
+            e.set_order(amd.CPQ_ORDER_EQ_THEN_CONV)
+        return e
+
+    def run(e, k, step):
+        if step == 1:                                    # move everything that allocates lazily
+            e.set_eq_bypass(0, True)
+            e.request_band_reset(1, 0xFFFFFFFF)
+            e.request_agc_reset(1)
+            e.set_gains(0, 0.5, 1.5)
+            if k == 0:
+                e.set_convproc_params(0, mix=0.4, ir_peak_latency=300)
+        if step == 2:
+            e.set_eq_bypass(0, False)
+        n = 4 * B if k == 0 else 8 * 256
+        return e.process(x[:, :n])
+
+    alone = []
+    for k in range(2):
+        e = build(k)
+        e.profile_enable(True)
+        alone.append([run(e, k, s) for s in range(3)])
+        e.profile_read()
+        e.close()
+    a, b = build(0), build(1)
+    both = [[], []]
+    for s in range(3):
+        both[0].append(run(a, 0, s))
+        both[1].append(run(b, 1, s))
+    a.close(); b.close()
+    for k in range(2):
+        for s in range(3):
+            assert np.array_equal(both[k][s], alone[k][s]), (k, s)
+    # leak check with engines large enough that every lazily allocated buffer is >= 1 MB: memory after 4 and after 16
+    # create / use / destroy cycles must agree (allocator slack does not grow, a leak does: >= 12 MB per forgotten buffer)
+    def big(kind):
+        S2 = 32
+        if kind == 0:
+            e = amd.BatchedEngine(S2, max_ir_len=9000, max_blocks_per_call=8)
+            ir = O.gen_ir(9000, stream=7)
+            e.set_impulse(amd.CPQ_ALL_STREAMS, ir, ir, spec=amd.FilterSpec.defaults(hc_mode=0))
+            po = O.eq_params_bench(0.2); po.agcEnabled = 1
+            e.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+            e.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+            e.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+            e.enable_output_filter(True)
+        else:
+            e = amd.BatchedEngine(S2, block_size=256, max_ir_len=3000, max_blocks_per_call=16)
+            ir = O.gen_ir(3000, stream=3)
+            e.set_impulse(amd.CPQ_ALL_STREAMS, ir, ir, direct_head=True)
+            e.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(O.eq_params_bench(0.0), amd.eq_params_default()))
+            e.set_order(amd.CPQ_ORDER_EQ_THEN_CONV)
+        return e
+    xb = np.tile(x[:2, :8 * 512], (32, 1))
+    free = []
+    for i in range(16):
+        e = big(i % 2)
+        e.profile_enable(True)
+        for st in range(3):
+            if st == 1:
+                e.set_eq_bypass(0, True); e.request_band_reset(1, 0xFFFFFFFF); e.request_agc_reset(1); e.set_gains(0, 0.5, 1.5)
+                if i % 2 == 0:
+                    e.set_convproc_params(0, mix=0.4, ir_peak_latency=300)
+            if st == 2:
+                e.set_eq_bypass(0, False)
+            e.process(xb[:, :4096])
+        e.close()
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert abs(free[3] - free[15]) < 4 << 20, free
