@@ -55,6 +55,9 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in src and "cpq_oracle" not in src and "libcpq_oracle" not in src, f
+                assert "ir_ingest_oracle" not in src, f
+                code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith(("//", "*", "/*", "#", '"""')))
+                assert "oracle/" not in code and "import oracle" not in code, f
 
 
 def test_no_gpu_means_loud_failure(amd):
