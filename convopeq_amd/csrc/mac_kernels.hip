@@ -181,7 +181,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     const bool active = t0w < T;                  // wave-uniform
     for (int j = 0; j < nChunks; ++j) {
         // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
-        const double2 xs = xrow(base + kWgTile * (-j - 2) + w)[bin];
+        // the FDL rows of a channel are read by this workgroup alone (one group at T <= 64): streaming hint; the IR rows
+        // may be shared by every channel (CPQ_ALL_STREAMS) and stay cacheable
+        const double* xp = reinterpret_cast<const double*>(xrow(base + kWgTile * (-j - 2) + w) + bin);
+        const double2 xs = make_double2(__builtin_nontemporal_load(xp), __builtin_nontemporal_load(xp + 1));
         const double2 hsn = hrow((j + 1) * kWgTile + w)[bin];     // IR row w of the next chunk (zero rows past K)
         const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
         // a wave whose 8 outputs lie beyond T only feeds the ring (partial last group: T mod 64 != 0)
@@ -227,7 +230,10 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
             // element 0 packs (DC, Nyquist), two independent REAL MACs: exactly M1 and M2 of the Gauss form, so this
             // kernel needs no separate DC/Nyquist pass
             const double2 y = (bin == 0) ? make_double2(m1[i], m2[i]) : make_double2(m1[i] - m2[i], (m3[i] - m1[i]) - m2[i]);
-            Y[((int64_t)c * T + t0w + i) * P + bin] = y;
+            // streaming store: the row is not touched again before the inverse FFT (0.724 -> 0.717 ms)
+            double* yp = reinterpret_cast<double*>(Y + ((int64_t)c * T + t0w + i) * P + bin);
+            __builtin_nontemporal_store(y.x, yp);
+            __builtin_nontemporal_store(y.y, yp + 1);
         }
 }
 
