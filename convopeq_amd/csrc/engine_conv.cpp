@@ -141,7 +141,7 @@ int specTailsRun(cpq_engine* e, double* dOut, int n)
             {
                 ProfScope p(e, CPQ_K_FDL_MAC);
                 cpq::launch_fdl_mac(e->stream, e->macTile, t.X, t.H, e->irSlot, t.Y, t.P, e->nCh, t.kPad, t.ringSlots, t.head,
-                                    nb, (int64_t)t.hRows * t.P);
+                                    nb, (int64_t)t.hRows * t.P, e->irPrivate);
             }
             if (cpq::fdl_mac_needs_dcnyq(e->macTile, nb)) {      // the cooperative kernel produces the packed bin itself
                 ProfScope p(e, CPQ_K_DCNYQ);
@@ -203,7 +203,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
             {
                 ProfScope p(e, CPQ_K_FDL_MAC);
                 cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H + (int64_t)e->layerRow[l] * e->P, e->irSlot, e->Y,
-                                    e->P, e->nCh, kPad, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P);
+                                    e->P, e->nCh, kPad, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
             }
             if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {
                 ProfScope p(e, CPQ_K_DCNYQ);
@@ -240,7 +240,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T)
         ProfScope p(e, CPQ_K_FDL_MAC);
         cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh,
                             (int)alignUp(e->kMaxReal, cpq::fdl_mac_kpad_align(e->macTile, T)), e->ringSlots,
-                            e->head, T, (int64_t)e->hRows * e->P);
+                            e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
     }
     if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {      // the cooperative kernel produces the packed (DC, Nyquist) bin itself
         ProfScope p(e, CPQ_K_DCNYQ);
@@ -499,6 +499,8 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         for (int ch = 0; ch < 2; ++ch) { e->irSlotHost[2 * stream + ch] = 2 * stream + ch; e->irLoaded[2 * stream + ch] = 1; }
     }
     CPQ_HIP(e, hipMemcpy(e->irSlot, e->irSlotHost.data(), sizeof(int) * e->nCh, hipMemcpyHostToDevice));
+    e->irPrivate = true;
+    for (int c = 0; c < e->nCh; ++c) e->irPrivate = e->irPrivate && e->irSlotHost[c] == c;
     e->anyDirect = false;
     if (e->directIr)
         for (int c = 0; c < e->nCh; ++c) if (e->irLoaded[c] && e->directTapsHost[e->irSlotHost[c]] > 0) e->anyDirect = true;

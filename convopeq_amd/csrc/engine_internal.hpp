@@ -110,6 +110,7 @@ struct cpq_engine {
     int kActive = 0;            // max partitions over the loaded IRs (multiple of kMacMaxTile)
     int kMaxReal = 0;           // max real partition count (DC/Nyquist loop bound)
     std::vector<int> irSlotHost;
+    bool irPrivate = true;      // every channel reads its own IR rows (no shared slot)
     std::vector<char> irLoaded; // per channel
     std::vector<int> irParts;   // per IR slot: partitions in use
     std::vector<char> slotSpecTail;   // per IR slot: loaded with a FilterSpec plan that has tail layers
