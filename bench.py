@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--host-buffers", action="store_true", help="diagnostic: host-pointer entry point (PCIe-inclusive rate)")
     ap.add_argument("--pinned", action="store_true", help="with --host-buffers: pin the host buffers (cpq_host_register)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json"))
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json"))
     args = ap.parse_args()
 
     import torch
