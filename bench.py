@@ -6,15 +6,21 @@ One *step* = one pass of the hot path over one batch: every one of S stereo stre
 samples through the convolver (131072-tap private IR per channel, reference semantics) and, unless --no-eq,
 the 20-band SVF EQ -- one cpq_engine_process_block_device() call with inputs already resident in HBM.
 
-N = 1 runs BASELINE.json configs[1] (256 stereo streams).  N > 1 (launched by torch.distributed.run, one rank
-per GPU) keeps the per-GPU workload fixed (weak scaling, streams sharded across ranks, no data-path
-collective); the only collective is the final RCCL all-reduce of the counters.
+N = 1 runs BASELINE.json configs[1] (256 stereo streams).  N > 1 runs configs[4]: 8192 / 8 = 1024 streams per GPU,
+one rank per GPU, streams sharded across ranks (convopeq_amd/sharding.py), no data-path collective; the only
+collective is the end-of-run reduction of the counters (RCCL).  `python bench.py --gpus N` with no WORLD_SIZE in the
+environment starts the N ranks itself (torch.distributed.run, from a parent that never touches the GPU); under a
+launcher (WORLD_SIZE set) the process is one of the ranks and WORLD_SIZE must equal --gpus.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -28,6 +34,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 B = 512
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (fp64 vector FMA)
+STREAMS_CONFIG2 = 256           # BASELINE.json configs[1]
+STREAMS_CONFIG5_SHARE = 1024    # BASELINE.json configs[4]: 8192 streams over 8 GPUs
 
 
 # ----------------------------------------------------------------------------- synthetic data
@@ -54,35 +62,77 @@ def gen_ir(length, stream, channel, seed=0x1257):
     return 0.05 * rand_pm1(seed, stream, channel, i) * np.exp(-6.9 * i.astype(np.float64) / length)
 
 
-def bench_eq_params(amd, saturation):
-    """SURVEY.md 8(d) EQ bench preset."""
-    freqs = [25.0, 40.0, 63.0, 100.0, 160.0, 250.0, 400.0, 630.0, 1000.0, 1600.0, 2500.0, 4000.0, 6300.0,
-             10000.0, 11000.0, 12500.0, 14000.0, 16500.0, 18000.0, 19500.0]
-    gains = [3, -2, 4, -3, 2, -4, 3, -2, 1.5, -1.5, 2, -2, 3, -3, 1, -1, 2, -2, 1, -1]
-    p = amd.eq_params_default()
-    for i in range(20):
-        b = p.bands[i]
-        b.frequency, b.gain, b.q = freqs[i], gains[i], 1.41
-        b.enabled, b.channel_mode = 1, 0
-        b.type = 0 if i == 0 else (2 if i == 19 else 1)
-    p.nonlinear_saturation = saturation
+BENCH_FREQS = [25.0, 40.0, 63.0, 100.0, 160.0, 250.0, 400.0, 630.0, 1000.0, 1600.0, 2500.0, 4000.0, 6300.0,
+               10000.0, 11000.0, 12500.0, 14000.0, 16500.0, 18000.0, 19500.0]
+BENCH_GAINS = [3, -2, 4, -3, 2, -4, 3, -2, 1.5, -1.5, 2, -2, 3, -3, 1, -1, 2, -2, 1, -1]
+
+
+def load_autoeq_preset():
+    """tests/golden/autoeq_he400se.json: the values of the reference's sample AutoEq preset."""
+    with open(os.path.join(ROOT, "tests", "golden", "autoeq_he400se.json")) as f:
+        return json.load(f)
+
+
+def fill_eq_params(p, preset, saturation, attr):
+    """Fills an EqParams-like ctypes struct (product or oracle flavour; `attr` maps the field names that differ)."""
+    if preset == "autoeq":
+        d = load_autoeq_preset()
+        for i in range(20):
+            b = p.bands[i]
+            if i < len(d["filters"]):
+                f = d["filters"][i]
+                b.frequency, b.gain, b.q = f["fc"], f["gain"], f["q"]
+                b.type = {"LSC": 0, "PK": 1, "HSC": 2}[f["type"]]
+                b.enabled = 1
+            else:                   # loadFromTextFile first disables every band and zeroes its gain (Core.cpp:305-310)
+                b.enabled, b.gain = 0, 0.0
+            setattr(b, attr["channel_mode"], 0)
+        setattr(p, attr["total_gain_db"], d["preamp_db"])
+    else:
+        for i in range(20):
+            b = p.bands[i]
+            b.frequency, b.gain, b.q = BENCH_FREQS[i], BENCH_GAINS[i], 1.41
+            b.enabled = 1
+            setattr(b, attr["channel_mode"], 0)
+            b.type = 0 if i == 0 else (2 if i == 19 else 1)
+    setattr(p, attr["saturation"], saturation)
     return p
 
 
+PRODUCT_ATTR = {"channel_mode": "channel_mode", "total_gain_db": "total_gain_db", "saturation": "nonlinear_saturation"}
+ORACLE_ATTR = {"channel_mode": "channelMode", "total_gain_db": "totalGainDb", "saturation": "nonlinearSaturation"}
+
+
+def bench_eq_params(amd, saturation, preset="bench"):
+    """SURVEY.md 8(d) EQ bench preset (or the AutoEq one)."""
+    return fill_eq_params(amd.eq_params_default(), preset, saturation, PRODUCT_ATTR)
+
+
 # ----------------------------------------------------------------------------- CPU baseline (oracle, "port")
-def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
-    """Times the CPU oracle (restatement of the reference NUC + SVF EQ) on the host cores of this box.
-    Bounded sample: one stereo stream per thread, each with its own 131072-tap IRs, blocks of 512."""
+def _pin_to(cpu):
+    try:
+        os.sched_setaffinity(0, {cpu})          # pid 0 = the calling thread
+        return True
+    except (AttributeError, OSError):
+        return False
+
+
+def cpu_baseline(ir_len, use_eq, saturation, preset, target_seconds=6.0):
+    """Times the CPU oracle (restatement of the reference NUC + SVF EQ) on the host cores of this box: one stereo stream
+    per thread, each with its own IRs, blocks of 512, every thread pinned to one of the CPUs this process may run on.
+    Then the single-thread config-1 leg (1 stream, 4096 taps, EQ bypassed: the reference's plumbing case)."""
     import oracle_lib as O
     O.lib()
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = max(1, len(cpus))
     n_blocks = 1024                       # per thread and pass: 524288 samples per channel
-    po = O.eq_params_bench(saturation)
+    po = fill_eq_params(O.eq_params_default(), preset, saturation, ORACLE_ATTR)
     done = [0] * cores
+    pinned = [False] * cores
     stop_at = [0.0]
-    first = {}                            # thread 0's first 64 blocks of output: the parity sample
 
     def work(tid):
+        pinned[tid] = _pin_to(cpus[tid])
         irs = [O.gen_ir(ir_len, stream=tid, channel=ch) for ch in range(2)]
         nucs = [O.Nuc(), O.Nuc()]
         for ch in range(2):
@@ -93,9 +143,7 @@ def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
         while True:
             y = [nucs[ch].run(x[ch], B) for ch in range(2)]
             if use_eq:
-                y[0], y[1], _ = O.eq_process_stereo(y[0], y[1], po, state=state)
-            if tid == 0 and not first:
-                first["y"] = np.stack([y[0][:64 * B].copy(), y[1][:64 * B].copy()])
+                O.eq_process_stereo(y[0], y[1], po, state=state)
             done[tid] += n_blocks * B
             if time.perf_counter() >= stop_at[0]:
                 break
@@ -112,56 +160,234 @@ def cpu_baseline(ir_len, use_eq, saturation, target_seconds=6.0):
         t.join()
     dt = time.perf_counter() - t0
     total = sum(done)
+
+    # config 1, single thread: SetImpulse(ir, 4096, 512) -> Add/Get per block
+    h = O.gen_ir(4096, stream=0, channel=0)
+    hr = O.gen_ir(4096, stream=0, channel=1)
+    c1 = [O.Nuc(), O.Nuc()]
+    c1[0].set_impulse(h, B)
+    c1[1].set_impulse(hr, B)
+    x1 = [O.gen_pcm(4096 * B, stream=0, channel=ch) for ch in range(2)]
+    t1 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t1 < 1.5:
+        for ch in range(2):
+            c1[ch].run(x1[ch], B)
+        n1 += 4096 * B
+    dt1 = time.perf_counter() - t1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(total / dt / 1e6, 3), "unit": "Mega stereo-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} stereo streams (one per thread), {ir_len}-tap IR each, blk {B}, "
+            "host_cpu_count": os.cpu_count(), "cpu_model": model, "threads_pinned": all(pinned),
+            "sample": f"{cores} stereo streams (one per pinned thread; the box reports os.cpu_count() = {os.cpu_count()}, "
+                      f"{cores} usable by this process), {ir_len}-tap IR each, blk {B}, "
                       f"{total // cores} samples per stream, conv{'+EQ' if use_eq else ''}, {dt:.1f} s wall; "
-                      "oracle = C restatement of the reference NUC schedule (own radix-2 FFT, not IPP)"}, first.get("y")
+                      "oracle = C restatement of the reference NUC schedule (own radix-2 FFT, not IPP)",
+            "config1_single_thread": {"value": round(n1 / dt1 / 1e6, 3), "unit": "Mega stereo-samples/s", "cores": 1,
+                                      "sample": f"1 stereo stream, 4096-tap IR, blk {B}, EQ bypassed, {n1} samples, {dt1:.1f} s"}}
 
 
-def parity_against(amd, ref, ir_len, use_eq, saturation, device):
-    """fp64 RMS / max-abs difference between the HIP path and the CPU baseline's own output for stream 0 (first 64 blocks
-    from reset, same IR / PCM / EQ preset): the oracle here is the checker, nothing of it is timed or shipped."""
-    n = ref.shape[1]
-    eng = amd.BatchedEngine(1, block_size=B, max_ir_len=ir_len, max_blocks_per_call=n // B, device=device)
-    eng.set_impulse(0, gen_ir(ir_len, 0, 0), gen_ir(ir_len, 0, 1))
-    x = np.stack([gen_pcm(n, 0, 0), gen_pcm(n, 0, 1)])
-    if use_eq:
-        eng.set_eq_params(amd.CPQ_ALL_STREAMS, bench_eq_params(amd, saturation))
-        y = eng.process(x)
-    else:
-        y = eng.conv_process(x)
-    eng.close()
-    d = y - ref
-    return {"rms_err": float(np.sqrt(np.mean(d * d))), "max_abs_err": float(np.abs(d).max()),
-            "signal_rms": float(np.sqrt(np.mean(ref * ref))), "target_rms_err": 1e-12,
-            "sample": f"stream 0, {n} samples per channel from reset, conv{'+EQ' if use_eq else ''}, GPU vs the CPU baseline's output"}
+def parity_of_timed_engine(amd, eng, d_in, d_out, torch, S, n, ir_len, use_eq, saturation, preset, stream_ids, exact,
+                           schedule_nuc):
+    """Parity of the TIMED engine itself: its state is reset, two calls of the step's input run from reset, and the output
+    rows of a few streams (first, second, middle, last) are read back and compared with the oracle fed the same IR / PCM.
+    The oracle is the checker here; nothing of it is timed or shipped."""
+    import oracle_lib as O
+    O.lib()
+    eng.conv_reset()
+    eng.eq_reset()
+    outs = []
+    for _ in range(2):
+        if use_eq:
+            eng.process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        else:
+            eng.conv_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
+        torch.cuda.synchronize()
+        outs.append(d_out.clone())
+    picks = sorted({0, min(1, S - 1), S // 2, S - 1})
+    po = fill_eq_params(O.eq_params_default(), preset, saturation, ORACLE_ATTR)
+    err2, cnt, emax, sig2 = 0.0, 0, 0.0, 0.0
+    for s in picks:
+        gid = stream_ids[s]
+        ref = []
+        for ch in range(2):
+            h = gen_ir(ir_len, gid, ch)
+            x = gen_pcm(n, gid, ch)
+            xx = np.concatenate([x, x])
+            if exact:
+                import scipy.signal
+                ref.append(scipy.signal.fftconvolve(xx, h)[:2 * n])
+            else:
+                nuc = O.Nuc()
+                nuc.set_impulse(h, B)
+                ref.append(nuc.run(xx, B))
+        if use_eq:
+            ref[0], ref[1], _ = O.eq_process_stereo(ref[0], ref[1], po)
+        for ch in range(2):
+            y = np.concatenate([o[2 * s + ch].cpu().numpy() for o in outs])
+            d = y - ref[ch]
+            err2 += float(np.dot(d, d))
+            sig2 += float(np.dot(ref[ch], ref[ch]))
+            emax = max(emax, float(np.abs(d).max()))
+            cnt += d.size
+    return {"rms_err": float(np.sqrt(err2 / cnt)), "max_abs_err": emax, "signal_rms": float(np.sqrt(sig2 / cnt)),
+            "target_rms_err": 1e-12, "err_sq_sum": err2, "count": cnt,
+            "sample": f"the timed engine ({S} streams), reset, two calls of {n} samples; streams {picks} of this rank "
+                      f"(global ids {[stream_ids[s] for s in picks]}), both channels, conv{'+EQ' if use_eq else ''}, "
+                      f"HIP output vs the oracle ({'scipy fftconvolve' if exact else 'stateful NUC emulation'}) on the same IR + PCM"}
 
 
-def load_pmc_traffic(path, kernel):
-    """HBM bytes per launch of `kernel` from a committed rocprofv3 PMC summary (profiles/*.json), or None."""
+# ----------------------------------------------------------------------------- PMC traffic (committed profiles)
+def kernel_source_hash():
+    """Identifies the kernels a PMC summary was measured on: sha256 over the .hip sources."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "convopeq_amd", "csrc", "*.hip"))):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic(path, kernel, running):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 PMC summary, with its provenance.  The number is only
+    returned when the summary says which workload and kernel sources it was measured on and both match this run;
+    otherwise traffic is null (a stale number is worse than none)."""
+    src = {"file": os.path.relpath(path, ROOT) if path else None, "match": False}
+    if not path or not os.path.exists(path):
+        src["reason"] = "no PMC summary found"
+        return None, src
     try:
         with open(path) as f:
             d = json.load(f)
-        # the profiler id k_fdl_mac covers the workgroup-cooperative variant of long calls (k_fdl_mac_wg in rocprof
-        # names) and the register-tile variants of short ones (k_fdl_mac<TT, PF>, summarised as "k_fdl_mac")
-        if kernel == "k_fdl_mac" and "k_fdl_mac_wg" in d:
-            return d["k_fdl_mac_wg"].get("hbm_bytes_per_launch")
-        if kernel == "k_fdl_mac:tile":
-            kernel = "k_fdl_mac"
-        if kernel in d:
-            return d[kernel].get("hbm_bytes_per_launch")
-        cands = [v for k, v in d.items() if k.startswith(kernel) and isinstance(v, dict)]
-        return max((v.get("hbm_bytes_per_launch") for v in cands), default=None)
-    except Exception:
-        return None
+    except Exception as ex:       # noqa: BLE001
+        src["reason"] = f"unreadable: {ex}"
+        return None, src
+    tag = d.get("_config")
+    if not tag:
+        src["reason"] = "summary carries no _config tag (pre-round-2 file)"
+        return None, src
+    src["measured_on"] = tag
+    mism = [k for k in ("streams", "ir_len", "block", "blocks_per_call", "partition", "schedule", "eq", "kernel_sources")
+            if tag.get(k) != running.get(k)]
+    if mism:
+        src["reason"] = "differs from this run in: " + ", ".join(mism)
+        return None, src
+    # the profiler id k_fdl_mac covers the workgroup-cooperative variant of long calls (k_fdl_mac_wg in rocprof names)
+    # and the register-tile variants of short ones (k_fdl_mac<TT, PF>, summarised as "k_fdl_mac")
+    names = {"k_fdl_mac": ["k_fdl_mac_wg", "k_fdl_mac"], "k_fdl_mac:tile": ["k_fdl_mac"],
+             "k_svf_cascade_tp": ["k_svf_cascade_tp8", "k_svf_cascade_tp"]}.get(kernel, [kernel])
+    for nme in names:
+        if nme in d and isinstance(d[nme], dict):
+            src["match"] = True
+            src["kernel"] = nme
+            return d[nme].get("hbm_bytes_per_launch"), src
+    src["reason"] = f"kernel {kernel} not in the summary"
+    return None, src
 
 
-def main():
+def newest_pmc_summary():
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return c[-1] if c else None
+
+
+# ----------------------------------------------------------------------------- launcher
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv, run=subprocess.call):
+    """Parent of `python bench.py --gpus N` (no WORLD_SIZE): starts N ranks of this script as CHILD processes and returns
+    their exit code.  The parent has not imported torch, loaded the HIP library or touched the GPU (and never execs)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return run(cmd, env=env)
+
+
+def rank_layout(args, env, device_count):
+    """(rank, local_rank, world, device index) of this process, or SystemExit when the launch does not match --gpus."""
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    world = int(env.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher)")
+    if local_rank >= device_count:
+        if args.dist_backend != "gloo":
+            raise SystemExit(f"bench.py: rank {rank} (local {local_rank}) has no GPU of its own: {device_count} visible")
+        return rank, local_rank, world, local_rank % max(device_count, 1)      # gloo rehearsal: ranks share the devices
+    return rank, local_rank, world, local_rank
+
+
+def timed_steps(step, sync, dist, steps, warmup, after_warmup=None):
+    """The timing contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + device synchronise on
+    both sides.  Returns (this rank's own time to its last step, time to the closing barrier)."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if after_warmup:
+        after_warmup()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    mine = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    return mine, time.perf_counter() - t0
+
+
+def run_stub(args):
+    """--stub-step (tests/test_sharding_gloo_cpu.py): the rank layout, the timing harness and the counter reduction of
+    the real bench with a sleep in place of the engine call -- no GPU, no library; the line says so and is no measurement."""
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    from convopeq_amd import sharding
+    rank, _, world, _ = rank_layout(args, os.environ, 0 if args.dist_backend == "gloo" else 1 << 30)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, n = args.streams, args.blocks_per_call * args.block
+    ids = sharding.weak_scaling_streams(S, world, rank)
+    mine, elapsed = timed_steps(lambda: time.sleep(0.001 * (1 + rank)), lambda: None, dist if world > 1 else None,
+                                args.steps, args.warmup)
+    samples = float(S) * n * args.steps
+    rate = samples / mine / 1e6
+    samples, elapsed, _, _ = sharding.reduce_counters(samples, elapsed)
+    rates = sharding.gather_values(rate)
+    firsts = sharding.gather_values(float(ids[0]))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no kernels)", "value": round(samples / elapsed / 1e6, 3),
+                          "unit": "Mega stereo-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "data": "stub", "scaling": "weak",
+                          "config": {"streams_per_gpu": S, "first_stream_of_rank": [int(f) for f in firsts]},
+                          "per_rank": {"samples_per_s_mega": [round(r, 1) for r in rates]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=256, help="stereo streams per GPU")
+    ap.add_argument("--streams", type=int, default=0,
+                    help=f"stereo streams per GPU (default {STREAMS_CONFIG2} at --gpus 1 = configs[1], "
+                         f"{STREAMS_CONFIG5_SHARE} at --gpus N>1 = the per-GPU share of configs[4])")
     ap.add_argument("--ir-len", type=int, default=131072)
     ap.add_argument("--block", type=int, default=512, help="diagnostic: block size")
     ap.add_argument("--partition", type=int, default=0, help="internal FFT partition size (0 = block size)")
@@ -170,30 +396,42 @@ def main():
     ap.add_argument("--no-eq", action="store_true")
     ap.add_argument("--eq-only", action="store_true", help="diagnostic: time the EQ kernel alone")
     ap.add_argument("--saturation", type=float, default=0.2)
+    ap.add_argument("--eq-preset", choices=["bench", "autoeq"], default="bench",
+                    help="bench: SURVEY 8(d) preset; autoeq: the reference's sample AutoEq preset (tests/golden fixture)")
+    ap.add_argument("--pcm-scale", type=float, default=1.0,
+                    help="diagnostic: multiplies the synthetic PCM (e.g. 64 drives the EQ's guarded hot-signal path)")
     ap.add_argument("--shared-ir", action="store_true")
     ap.add_argument("--schedule", choices=["uniform", "nuc"], default="uniform",
                     help="uniform: one partition size for the whole h_eff (headline, HBM-roofline path); nuc: the reference's "
                          "own non-uniform schedule run natively (BASELINE.json configs[3])")
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="diagnostic: host-pointer entry point (PCIe-inclusive rate)")
     ap.add_argument("--pinned", action="store_true", help="with --host-buffers: pin the host buffers (cpq_host_register)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
-    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json"))
-    args = ap.parse_args()
+    ap.add_argument("--stub-step", action="store_true", help="test-only: launcher / reduction self-test without a GPU")
+    ap.add_argument("--pmc-json", default=None, help="PMC summary for roofline.traffic (default: newest profiles/r*_pmc_traffic.json)")
+    args = ap.parse_args(argv)
+    if args.streams <= 0:
+        args.streams = STREAMS_CONFIG2 if args.gpus <= 1 else STREAMS_CONFIG5_SHARE
+    return args
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.stub_step:
+        return run_stub(args)
 
     import torch
     import convopeq_amd as amd
+    from convopeq_amd import sharding
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    rank, local_rank, world, dev_index = rank_layout(args, os.environ, torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()      # (== local_rank on a full node)
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
@@ -203,6 +441,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    red_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"
 
     global B
     B = args.block
@@ -216,20 +455,22 @@ def main():
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
 
-    # synthetic IRs and PCM; stream ids are global so every rank convolves different streams
+    # synthetic IRs and PCM; stream ids are global (rank-major, sharding.py) so every rank convolves different streams
     t_setup = time.perf_counter()
-    g0 = rank * S
+    ids = sharding.weak_scaling_streams(S, world, rank)
     if args.shared_ir:
         eng.set_impulse(amd.CPQ_ALL_STREAMS, gen_ir(L, 0, 0), gen_ir(L, 0, 1))
     else:
         for s in range(S):
-            eng.set_impulse(s, gen_ir(L, g0 + s, 0), gen_ir(L, g0 + s, 1))
+            eng.set_impulse(s, gen_ir(L, ids[s], 0), gen_ir(L, ids[s], 1))
     if use_eq:
-        eng.set_eq_params(amd.CPQ_ALL_STREAMS, bench_eq_params(amd, args.saturation))
+        eng.set_eq_params(amd.CPQ_ALL_STREAMS, bench_eq_params(amd, args.saturation, args.eq_preset))
     host = np.empty((2 * S, n))
     for s in range(S):
         for ch in range(2):
-            host[2 * s + ch] = gen_pcm(n, g0 + s, ch)
+            host[2 * s + ch] = gen_pcm(n, ids[s], ch)
+    if args.pcm_scale != 1.0:
+        host *= args.pcm_scale
     d_in = torch.from_numpy(host).cuda()
     d_out = torch.empty_like(d_in)
     plan = eng.plan()
@@ -257,22 +498,11 @@ def main():
         else:
             eng.conv_process_device(d_in.data_ptr(), d_out.data_ptr(), n)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    eng.profile_enable(True)
-    eng.profile_reset()
+    def start_profile():
+        eng.profile_enable(True)        # pre-creates the event pool: no hipEventCreate inside the timed region
+        eng.profile_reset()
 
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    my_elapsed, elapsed = timed_steps(step, torch.cuda.synchronize, dist, args.steps, args.warmup, start_profile)
     prof = eng.profile_read()
 
     # The same MAC path with ONE partition per call (the reference's own call pattern): every FDL and IR row is
@@ -288,14 +518,22 @@ def main():
         prof1 = eng.profile_read()
     eng.profile_enable(False)
 
+    # parity of the timed engine (every rank checks its own shard; squared errors are summed over ranks)
+    parity = None
+    if not (args.no_parity or args.eq_only or args.host_buffers or args.partition or args.pcm_scale != 1.0) and B == 512:
+        parity = parity_of_timed_engine(amd, eng, d_in, d_out, torch, S, n, L, use_eq, args.saturation, args.eq_preset,
+                                        ids, args.exact, args.schedule == "nuc")
+
     samples = float(S) * n * args.steps          # stereo samples this rank processed
-    if dist is not None:
-        red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        ss = torch.tensor([samples], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
-        elapsed, samples = tt.item(), ss.item()
+    my_rate = samples / my_elapsed / 1e6
+    samples, elapsed, err2, emax = sharding.reduce_counters(samples, elapsed, parity["err_sq_sum"] if parity else 0.0,
+                                                            parity["max_abs_err"] if parity else 0.0, device=red_dev)
+    rates = sharding.gather_values(my_rate, device=red_dev)
+    if parity and world > 1:
+        cnt_all = parity["count"] * world
+        parity["rms_err"] = float(np.sqrt(err2 / cnt_all))
+        parity["max_abs_err"] = emax
+        parity["sample"] += f"; squared errors summed over {world} ranks"
 
     if rank == 0:
         n_ch = 2 * S
@@ -320,8 +558,9 @@ def main():
         # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF ~35 fp64 instructions per band-sample
         # the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex MAC (Gauss), the tile kernels 4
         mac_flop = lambda nb: 6.0 if nb >= 48 else 8.0
+        n_bands = 20 if args.eq_preset == "bench" else len(load_autoeq_preset()["filters"])
         alg_flops = {"k_fdl_mac": sum(mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb in layers),
-                     "k_svf_cascade_tp": 2.0 * 35 * 20 * n_ch * n}
+                     "k_svf_cascade_tp": 2.0 * 35 * n_bands * n_ch * n}
         per_kernel = {}
         for name, (cnt, ms) in prof.items():
             if cnt == 0:
@@ -337,21 +576,52 @@ def main():
         tot = {k: v["avg_launch_ms"] * v["launches"] for k, v in per_kernel.items()}
         dominant = max(tot, key=tot.get)
         co_dominant = sorted(k for k in tot if tot[k] >= 0.9 * tot[dominant])
-        # the FDL MAC and the SVF cascade tie within a few percent at the default config; when they do, the roofline
-        # object describes the HBM-streaming one (the kernel north_star defines the roofline on), both are listed
+        # the FDL MAC and the SVF cascade can tie within a few percent; when they do, the roofline object describes the
+        # HBM-streaming one (the kernel north_star defines the roofline on), both are listed
         if "k_fdl_mac" in co_dominant:
             dominant = "k_fdl_mac"
         dk = per_kernel[dominant]
+        running = {"streams": S, "ir_len": L, "block": B, "blocks_per_call": T, "partition": P,
+                   "schedule": args.schedule, "eq": use_eq, "kernel_sources": kernel_source_hash()}
+        pmc_path = args.pmc_json or newest_pmc_summary()
         hbm_regime = None
         if prof1 and prof1.get("k_fdl_mac", (0, 0.0))[0] > 0:
             cnt1, ms1 = prof1["k_fdl_mac"]
             b1 = (n_ch * k_parts + ir_rows + n_ch) * spec_bytes
             gbs1 = b1 / (ms1 / cnt1 * 1e-3) / 1e9
+            tr1, src1 = load_pmc_traffic(pmc_path, "k_fdl_mac:tile", running)
             hbm_regime = {"kernel": "k_fdl_mac", "blocks_per_call": P // B, "algorithmic_bytes_per_launch": b1,
                           "avg_launch_ms": round(ms1 / cnt1, 4), "achieved": round(gbs1, 1),
-                          "frac": round(gbs1 / HBM_PEAK_GBS, 4), "launches": cnt1,
-                          "traffic": load_pmc_traffic(args.pmc_json, "k_fdl_mac:tile")}
+                          "frac": round(gbs1 / HBM_PEAK_GBS, 4), "launches": cnt1, "traffic": tr1}
         flop_per_byte = alg_flops["k_fdl_mac"] / alg_bytes["k_fdl_mac"]
+        ridge = FP64_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+        traffic, traffic_src = load_pmc_traffic(pmc_path, dominant, running)
+        if dominant.startswith("k_svf"):
+            # 16 B of HBM per sample against ~35 fp64 instructions per band-sample: the fp64 vector issue rate bounds it
+            roof = {"kernel": dominant, "bound": "fp64_vector", "achieved": dk.get("fp64_tflops"),
+                    "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round((dk.get("fp64_tflops") or 0.0) / FP64_VECTOR_PEAK_TFLOPS, 4),
+                    "note": "k_svf_cascade_tp is fp64-VALU issue bound, not HBM bound: 20 sequential nonlinear bands per "
+                            "sample (~35 fp64 instructions per band-sample) against 16 B of HBM traffic per sample"}
+        else:
+            roof = {"kernel": dominant, "bound": "hbm" if flop_per_byte < ridge else "fp64_vector",
+                    "achieved": dk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dk["achieved_gbs"] / HBM_PEAK_GBS, 4),
+                    "note": "HBM stream of FDL and IR spectra; `bound` from the kernel's flop/byte against the fp64 ridge"}
+        roof.update({
+            "traffic": traffic, "traffic_source": traffic_src,
+            "frac_of_pmc_traffic": (round(traffic / (dk["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+            "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_launch"],
+            "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
+            "co_dominant_kernels": co_dominant,
+            "fp64_vector": {"achieved_tflops": dk.get("fp64_tflops"), "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+            # k_fdl_mac at T partitions per call executes 6 K T flop (3 FMAs per complex MAC) per 16 (2K + T) bytes
+            "mac_flop_per_byte": round(flop_per_byte, 2), "ridge_flop_per_byte": round(ridge, 2),
+            "hbm_regime": hbm_regime,
+        })
+        config_name = ("configs[1]" if (world == 1 and S == STREAMS_CONFIG2 and L == 131072 and B == 512) else
+                       "configs[4] per-GPU share (8192 streams / 8 GPUs)" if (S == STREAMS_CONFIG5_SHARE and L == 131072 and B == 512) else
+                       "modified")
         out = {
             "metric": "Mega stereo-samples/s convolved (131072-tap IR, blk=512)",
             "value": round(samples / elapsed / 1e6, 3),
@@ -366,10 +636,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{S} stereo streams per GPU, {L}-tap IR "
+                "workload": f"{S} stereo streams per GPU x {world} GPU(s) = {S * world} streams, {L}-tap IR "
                             f"({'one shared stereo IR' if args.shared_ir else 'private IR per channel'}), blk {B}, "
-                            f"fp64 overlap-save conv{' + 20-band SVF EQ (sat %.1f)' % args.saturation if use_eq else ''}"
-                            f" [BASELINE.json configs[1]{'' if (S == 256 and L == 131072) else ' (modified)'}]",
+                            f"fp64 overlap-save conv"
+                            f"{' + 20-band SVF EQ (%s preset, sat %.1f)' % (args.eq_preset, args.saturation) if use_eq else ''}"
+                            f" [BASELINE.json {config_name}]",
                 "streams_per_gpu": S, "ir_taps": L, "block": B, "blocks_per_call": T,
                 "schedule": (f"uniform overlap-save, FFT partition P={P}, K={k_parts} partitions of "
                              f"{'h' if args.exact else 'h_eff (reference NUC semantics at blk 512)'}, "
@@ -377,38 +648,27 @@ def main():
                             else ("non-uniform (the reference's own layer plan run natively): " +
                                   " + ".join(f"{kl} x {pl}" for pl, kl, _ in layers) + f" partitions, {T} blocks per call"),
                 "partition": P,
-                "eq": use_eq, "parallelism": f"streams sharded, {world} rank(s)",
+                "eq": use_eq, "eq_preset": args.eq_preset if use_eq else None, "saturation": args.saturation if use_eq else None,
+                "pcm_scale": args.pcm_scale,
+                "parallelism": f"streams sharded rank-major, {world} rank(s), one per GPU"
+                               + (" (gloo rehearsal: ranks share the visible devices)" if args.dist_backend == "gloo" and world > 1 else ""),
                 "gb_per_s_of_samples": round(samples / elapsed * 16 / 1e9, 3),
             },
-            "roofline": {
-                "kernel": dominant, "bound": "hbm", "achieved": dk["achieved_gbs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(dk["achieved_gbs"] / HBM_PEAK_GBS, 4),
-                "traffic": load_pmc_traffic(args.pmc_json, dominant),
-                "algorithmic_bytes_per_launch": dk["algorithmic_bytes_per_launch"],
-                "avg_launch_ms": dk["avg_launch_ms"], "launches": dk["launches"],
-                "co_dominant_kernels": co_dominant,
-                "note": ("k_svf_cascade_tp is fp64-VALU issue bound, not HBM bound: 20 sequential nonlinear bands per "
-                         "sample (~35 fp64 instructions per band-sample) against 16 B of HBM traffic per sample"
-                         if dominant.startswith("k_svf") else "HBM stream of FDL and IR spectra"),
-                "fp64_vector": {"achieved_tflops": dk.get("fp64_tflops"), "peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
-                # k_fdl_mac at T partitions per call executes 6 K T flop (3 FMAs per complex MAC) per 16 (2K + T) bytes:
-                # at the fp64 ridge (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) around T = 64 at K = 259
-                "mac_flop_per_byte": round(flop_per_byte, 2),
-                "ridge_flop_per_byte": round(FP64_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 2),
-                "hbm_regime": hbm_regime,
-            },
+            "per_rank": {"samples_per_s_mega": [round(r, 1) for r in rates], "min": round(min(rates), 1),
+                         "max": round(max(rates), 1)},
+            "parity": ({k: v for k, v in parity.items() if k not in ("err_sq_sum", "count")} if parity else None),
+            "roofline": roof,
             "kernels": per_kernel,
             "kernels_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof.items()},
             "setup_s": round(setup_s, 2),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], ref = cpu_baseline(L, use_eq, args.saturation)
-            if ref is not None and B == 512 and not (args.exact or args.partition):
-                out["cpu_baseline"]["parity"] = parity_against(amd, ref, L, use_eq, args.saturation, dev_index)
+            out["cpu_baseline"] = cpu_baseline(L, use_eq, args.saturation, args.eq_preset)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -534,6 +534,18 @@ int32_t cpq_profile_enable(cpq_engine* e, int32_t on)
 {
     if (!e) return CPQ_ERR_INVALID_ARG;
     e->profiling = on != 0;
+    if (e->profiling) {
+        // event pool up front, so that no hipEventCreate runs inside a timed region (ProfScope only creates on exhaustion)
+        CPQ_HIP(e, hipSetDevice(e->device));
+        constexpr size_t kPool = 96;
+        for (auto& s : e->prof)
+            while (s.freeList.size() + s.pending.size() < kPool) {
+                std::pair<hipEvent_t, hipEvent_t> ev;
+                CPQ_HIP(e, hipEventCreate(&ev.first));
+                CPQ_HIP(e, hipEventCreate(&ev.second));
+                s.freeList.push_back(ev);
+            }
+    }
     return CPQ_OK;
 }
 

@@ -26,3 +26,13 @@ def reduce_counters(samples, elapsed_s, err_sq_sum=0.0, err_max=0.0, device="cpu
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return s[0].item(), m[0].item(), s[1].item(), m[1].item()
+
+
+def gather_values(value, device="cpu"):
+    """One float per rank, in rank order (per-rank throughput: a slow GPU shows up as the minimum)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [t.item() for t in out]

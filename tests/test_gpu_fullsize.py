@@ -1,0 +1,117 @@
+"""GPU parity at the BENCHMARKED sizes: the engines bench.py times (BASELINE.json configs[1], [3], and the per-GPU share
+of [4]) are built at full size, run for two calls, and checked three ways --
+
+ (a) streams {0, 1, S/2, S-1} against the oracle's stateful emulation on the same IR + PCM (<= 1e-12 RMS, north_star);
+ (b) two far-apart streams given identical IR + PCM must come out bit-equal (64-bit offsets, XCD / pair remapping of the
+     MAC grid, grid padding: any addressing slip between channels of a 2-14 GB arena breaks this);
+ (c) every other stream must differ from them and from each other (no channel computed from another channel's rows).
+
+One NUC per channel, independent between streams: /root/reference/src/ConvolverProcessor.h:669 (cited, not read at run time).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+B = 512
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a))))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import convopeq_amd
+    return convopeq_amd
+
+
+def _eq_params(amd, O, sat=0.2):
+    po = O.eq_params_bench(sat)
+    pa = amd.eq_params_default()
+    for i in range(20):
+        b, o = pa.bands[i], po.bands[i]
+        b.frequency, b.gain, b.q, b.enabled, b.type, b.channel_mode = o.frequency, o.gain, o.q, o.enabled, o.type, o.channelMode
+    pa.nonlinear_saturation = sat
+    return pa, po
+
+
+def _run_fullsize(amd, O, S, L, T, use_eq, schedule, calls=2):
+    n = T * B
+    twin_a, twin_b, twin_id = 3, S - 5, 7777            # two far-apart streams fed the IR + PCM of virtual stream 7777
+    ids = list(range(S))
+    ids[twin_a] = ids[twin_b] = twin_id
+    eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T, schedule=schedule)
+    try:
+        for s in range(S):
+            eng.set_impulse(s, O.gen_ir(L, stream=ids[s], channel=0), O.gen_ir(L, stream=ids[s], channel=1))
+        pa = po = None
+        if use_eq:
+            pa, po = _eq_params(amd, O)
+            eng.set_eq_params(amd.CPQ_ALL_STREAMS, pa)
+        assert eng.is_ready()
+        x = np.empty((2 * S, calls * n))
+        for s in range(S):
+            for ch in range(2):
+                x[2 * s + ch] = O.gen_pcm(calls * n, stream=ids[s], channel=ch)
+        ys = []
+        for c in range(calls):
+            xc = np.ascontiguousarray(x[:, c * n:(c + 1) * n])
+            ys.append(eng.process(xc) if use_eq else eng.conv_process(xc))
+        y = np.concatenate(ys, axis=1)
+    finally:
+        eng.close()
+
+    # (a) oracle on the same IR + PCM
+    picks = sorted({0, 1, S // 2, S - 1})
+    worst = 0.0
+    for s in picks:
+        ref = []
+        for ch in range(2):
+            nuc = O.Nuc()
+            assert nuc.set_impulse(O.gen_ir(L, stream=ids[s], channel=ch), B)
+            ref.append(nuc.run(x[2 * s + ch], B))
+            nuc.close()
+        if use_eq:
+            ref[0], ref[1], _ = O.eq_process_stereo(ref[0], ref[1], po)
+        for ch in range(2):
+            e = rms(y[2 * s + ch] - ref[ch])
+            worst = max(worst, e)
+            assert e <= 1e-12, (s, ch, e)
+            assert rms(ref[ch]) > 1e-3
+    # (b) the twins are bit-equal
+    for ch in range(2):
+        assert np.array_equal(y[2 * twin_a + ch], y[2 * twin_b + ch]), ch
+    # (c) all other rows are pairwise different: a 64-bit digest per row, one collision allowed per channel (the twins)
+    digest = [hash(y[c].tobytes()) for c in range(2 * S)]
+    assert len(set(digest)) == 2 * S - 2
+    assert np.isfinite(y).all()
+    return worst
+
+
+def test_config2_at_benchmark_size(amd, oracle):
+    """BASELINE.json configs[1] exactly as bench.py runs it: 256 streams, 131072 taps, 64 blocks per call, conv + EQ."""
+    worst = _run_fullsize(amd, oracle, 256, 131072, 64, True, amd.CPQ_SCHED_UNIFORM)
+    print("config 2 full size: worst rms err", worst)
+
+
+def test_config2_convolver_only_at_benchmark_size(amd, oracle):
+    worst = _run_fullsize(amd, oracle, 256, 131072, 64, False, amd.CPQ_SCHED_UNIFORM)
+    print("config 2 (conv only) full size: worst rms err", worst)
+
+
+def test_config4_native_schedule_at_benchmark_size(amd, oracle):
+    """BASELINE.json configs[3]: 64 streams, 524288 taps, the reference's own non-uniform schedule (512 / 4096 / 32768)."""
+    worst = _run_fullsize(amd, oracle, 64, 524288, 64, False, amd.CPQ_SCHED_REFERENCE_NUC, calls=3)
+    print("config 4 full size (native schedule): worst rms err", worst)
+
+
+def test_config4_uniform_schedule_at_benchmark_size(amd, oracle):
+    worst = _run_fullsize(amd, oracle, 64, 524288, 64, False, amd.CPQ_SCHED_UNIFORM)
+    print("config 4 full size (uniform): worst rms err", worst)
+
+
+def test_config5_share_at_benchmark_size(amd, oracle):
+    """The per-GPU share of BASELINE.json configs[4]: 1024 streams, 131072 taps, conv + EQ (~14 GB arena)."""
+    worst = _run_fullsize(amd, oracle, 1024, 131072, 64, True, amd.CPQ_SCHED_UNIFORM)
+    print("config 5 share full size: worst rms err", worst)

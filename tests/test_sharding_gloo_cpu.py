@@ -58,3 +58,67 @@ def test_sharding_helpers():
     owned = sorted(s for r in range(8) for s in streams_of_rank(8192, 8, r))
     assert owned == list(range(8192)) and len(streams_of_rank(8192, 8, 3)) == 1024
     assert weak_scaling_streams(256, 4, 2) == list(range(512, 768))
+
+
+# ---------------------------------------------------------------- bench.py's own launcher, rank layout and reduction
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_launcher_command_and_defaults():
+    b = _bench()
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    assert b.launch_ranks(4, ["--gpus", "4", "--steps", "3"], run=fake_run) == 7           # the children's exit code comes back
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # configs[1] on one GPU, the per-GPU share of configs[4] on several
+    assert b.parse_args([]).streams == 256 and b.parse_args(["--gpus", "8"]).streams == 1024
+    assert b.parse_args(["--gpus", "8", "--streams", "64"]).streams == 64
+
+
+def test_bench_rank_layout_refuses_a_mismatched_launch():
+    b = _bench()
+    a = b.parse_args(["--gpus", "2"])
+    assert b.rank_layout(a, {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2"}, 8) == (1, 1, 2, 1)
+    with pytest.raises(SystemExit):                     # WORLD_SIZE != --gpus: an error, not a warning
+        b.rank_layout(a, {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "4"}, 8)
+    with pytest.raises(SystemExit):                     # more ranks than GPUs over RCCL: no silent device sharing
+        b.rank_layout(a, {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2"}, 1)
+    g = b.parse_args(["--gpus", "2", "--dist-backend", "gloo"])
+    assert b.rank_layout(g, {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2"}, 1) == (1, 1, 2, 0)     # rehearsal
+
+
+def test_bench_self_launches_two_ranks_and_reduces(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: two child ranks, one JSON line, whole-job counters."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--stub-step",
+                        "--steps", "4", "--warmup", "1", "--streams", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                              # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1
+    assert d["config"]["first_stream_of_rank"] == [0, 8]            # rank-major global stream ids, disjoint shards
+    total = 2 * 8 * 64 * 512 * 4                                    # SUM over ranks of streams x samples x steps
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 4 - total) / total < 1e-3      # value = total / MAX elapsed
+    assert len(d["per_rank"]["samples_per_s_mega"]) == 2
+    # rank 1 sleeps twice as long per step: the job's time is the slower rank's
+    assert d["ms_per_step"] >= 2.0 and d["per_rank"]["samples_per_s_mega"][0] > d["per_rank"]["samples_per_s_mega"][1]
+    # a launch whose world size disagrees with --gpus fails instead of running one rank
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r2.stderr + r2.stdout)

@@ -6,7 +6,11 @@ gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE a
 exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so it is doubled; WRITE_SIZE is exact
 for 16-B-per-lane streaming stores.
 
-usage: summarize_profiles.py <tag> <stats_csv> <fetch_counter_csv> <write_counter_csv>
+usage: summarize_profiles.py <tag> <stats_csv> <fetch_counter_csv> <write_counter_csv> [bench_log_with_the_json_line]
+
+The optional bench log (stdout of the profiled bench.py run) tags the summary with the workload and the hash of the
+kernel sources it was measured on (`_config`); bench.py only reports roofline.traffic from a summary whose tag matches
+the run.
 """
 import collections
 import csv
@@ -35,7 +39,8 @@ def per_kernel(path, counter):
 
 def main():
     tag, stats, fetch, write = sys.argv[1:5]
-    out_dir = os.path.join(ROOT, "profiles")
+    bench_log = sys.argv[5] if len(sys.argv) > 5 else None
+    out_dir = os.environ.get("CPQ_PROFILES_OUT", os.path.join(ROOT, "profiles"))
     os.makedirs(out_dir, exist_ok=True)
     shutil.copy(stats, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
     fs = per_kernel(fetch, "FETCH_SIZE")
@@ -54,6 +59,23 @@ def main():
         }
     res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
                     "per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B). Infinity-Cache hits are included.")
+    if bench_log:
+        import hashlib, glob
+        h = hashlib.sha256()
+        for p in sorted(glob.glob(os.path.join(ROOT, "convopeq_amd", "csrc", "*.hip"))):
+            with open(p, "rb") as f:
+                h.update(f.read())
+        line = None
+        with open(bench_log) as f:
+            for ln in f:
+                if ln.startswith("{") and '"metric"' in ln:
+                    line = json.loads(ln)
+        if line:
+            c = line["config"]
+            res["_config"] = {"streams": c["streams_per_gpu"], "ir_len": c["ir_taps"], "block": c["block"],
+                              "blocks_per_call": c["blocks_per_call"], "partition": c["partition"],
+                              "schedule": "uniform" if c["schedule"].startswith("uniform") else "nuc", "eq": c["eq"],
+                              "kernel_sources": h.hexdigest()[:16]}
     with open(os.path.join(out_dir, f"{tag}_pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
