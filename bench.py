@@ -117,6 +117,30 @@ def _pin_to(cpu):
         return False
 
 
+def cpu_share():
+    """CPUs this process may actually use at once: CPQ_CPU_THREADS, else the cgroup CPU quota (v2 cpu.max, v1
+    cfs_quota / cfs_period) when one is set.  (threads, where the number came from) or (None, ...)."""
+    if os.environ.get("CPQ_CPU_THREADS"):
+        return int(os.environ["CPQ_CPU_THREADS"]), "CPQ_CPU_THREADS"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period) + 0.5)), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            return max(1, int(quota / period + 0.5)), "cgroup cfs_quota"
+    except (OSError, ValueError):
+        pass
+    return None, "no quota: every CPU in the affinity mask"
+
+
 def cpu_baseline(ir_len, use_eq, saturation, preset, target_seconds=6.0):
     """Times the CPU oracle (restatement of the reference NUC + SVF EQ) on the host cores of this box: one stereo stream
     per thread, each with its own IRs, blocks of 512, every thread pinned to one of the CPUs this process may run on.
@@ -124,7 +148,9 @@ def cpu_baseline(ir_len, use_eq, saturation, preset, target_seconds=6.0):
     import oracle_lib as O
     O.lib()
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    cores = max(1, len(cpus))
+    share, share_src = cpu_share()
+    cores = max(1, min(len(cpus), share) if share else len(cpus))
+    cpus = cpus[:cores]
     n_blocks = 1024                       # per thread and pass: 524288 samples per channel
     po = fill_eq_params(O.eq_params_default(), preset, saturation, ORACLE_ATTR)
     done = [0] * cores
@@ -185,9 +211,10 @@ def cpu_baseline(ir_len, use_eq, saturation, preset, target_seconds=6.0):
     except OSError:
         pass
     return {"value": round(total / dt / 1e6, 3), "unit": "Mega stereo-samples/s", "cores": cores, "kind": "port",
-            "host_cpu_count": os.cpu_count(), "cpu_model": model, "threads_pinned": all(pinned),
+            "host_cpu_count": os.cpu_count(), "cpu_share": share, "cpu_share_source": share_src, "cpu_model": model,
+            "threads_pinned": all(pinned),
             "sample": f"{cores} stereo streams (one per pinned thread; the box reports os.cpu_count() = {os.cpu_count()}, "
-                      f"{cores} usable by this process), {ir_len}-tap IR each, blk {B}, "
+                      f"{cores} threads used: {share_src}), {ir_len}-tap IR each, blk {B}, "
                       f"{total // cores} samples per stream, conv{'+EQ' if use_eq else ''}, {dt:.1f} s wall; "
                       "oracle = C restatement of the reference NUC schedule (own radix-2 FFT, not IPP)",
             "config1_single_thread": {"value": round(n1 / dt1 / 1e6, 3), "unit": "Mega stereo-samples/s", "cores": 1,

@@ -21,6 +21,8 @@ CPQ_SEM_REFERENCE = 0
 CPQ_SEM_EXACT = 1
 CPQ_SCHED_UNIFORM = 0
 CPQ_SCHED_REFERENCE_NUC = 1
+CPQ_CALLS_WHOLE_BLOCKS = 0
+CPQ_CALLS_ANY = 1
 CPQ_ORDER_CONV_THEN_EQ = 0
 CPQ_ORDER_EQ_THEN_CONV = 1
 KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4,
@@ -97,7 +99,7 @@ class EngineDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("n_streams", C.c_int32),
                 ("block_size", C.c_int32), ("max_ir_len", C.c_int32), ("max_blocks_per_call", C.c_int32),
                 ("semantics", C.c_int32), ("mac_tile", C.c_int32), ("sample_rate", C.c_double),
-                ("partition_size", C.c_int32), ("schedule", C.c_int32)]
+                ("partition_size", C.c_int32), ("schedule", C.c_int32), ("call_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/convopeq_mi355x.h declares: (restype, argtypes)
@@ -126,6 +128,7 @@ SYMBOLS = {
     "cpq_conv_is_ready": (C.c_int32, [_E]),
     "cpq_conv_latency": (C.c_int32, [_E]),
     "cpq_conv_get_plan": (C.c_int32, [_E, C.POINTER(NucPlan)]),
+    "cpq_conv_last_got": (C.c_int32, [_E, C.c_int32]),
     "cpq_convproc_set_params": (C.c_int32, [_E, C.c_int32, C.POINTER(ConvProcParams)]),
     "cpq_convproc_process": (C.c_int32, [_E, c_double_p, c_double_p, C.c_int32]),
     "cpq_convproc_process_device": (C.c_int32, [_E, C.c_void_p, C.c_void_p, C.c_int32]),

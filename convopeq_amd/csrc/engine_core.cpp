@@ -35,20 +35,23 @@ int64_t alignUp(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 cpq::FftTables tables(const cpq_engine* e) { return cpq::FftTables{ e->tw512, e->tw1024 }; }
 
 
-int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int* T)
+int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples)
 {
     if (!e) return CPQ_ERR_INVALID_ARG;
     if (!in || !out) return fail(e, CPQ_ERR_INVALID_ARG, "null buffer");
-    if (nSamples <= 0 || nSamples % e->P != 0)
-        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d is not a positive multiple of the partition size %d", nSamples,
-                    e->P);
-    const int t = nSamples / e->P;
-    if (t > e->tMax)
-        return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d exceeds max_blocks_per_call=%d blocks of %d", nSamples,
-                    e->desc.max_blocks_per_call, e->B);
+    if (e->anyCalls) {
+        if (nSamples <= 0 || nSamples > e->maxCall)
+            return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d outside 1..%d (max_blocks_per_call * block_size)", nSamples, e->maxCall);
+    } else {
+        if (nSamples <= 0 || nSamples % e->P != 0)
+            return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d is not a positive multiple of the partition size %d "
+                        "(create the engine with CPQ_CALLS_ANY for other call sizes)", nSamples, e->P);
+        if (nSamples / e->P > e->tMax)
+            return fail(e, CPQ_ERR_INVALID_ARG, "n_samples=%d exceeds max_blocks_per_call=%d blocks of %d", nSamples,
+                        e->desc.max_blocks_per_call, e->B);
+    }
     if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
         return fail(e, CPQ_ERR_INVALID_ARG, "buffers must be 16-byte aligned");
-    *T = t;
     return CPQ_OK;
 }
 
@@ -63,7 +66,7 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         CPQ_HIP(e, hipMemsetAsync(e->hist[1], 0, (size_t)e->nCh * e->P * sizeof(double), e->stream));
         e->head = 0;
         e->histSel = 0;
-        { const int rc = resetSpecTails(e); if (rc != CPQ_OK) return rc; }
+        { const int rc = resetGroups(e); if (rc != CPQ_OK) return rc; }
         for (double* p : { e->directHist[0], e->directHist[1] })
             if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, sizeof(double) * 32 * e->nCh, e->stream));
         if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 3 * sizeof(long long), e->stream));
@@ -165,8 +168,16 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "struct_size %d != %zu", d->struct_size, sizeof(cpq_engine_desc));
     if (d->n_streams <= 0 || d->max_ir_len <= 0 || d->max_blocks_per_call <= 0)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "n_streams, max_ir_len and max_blocks_per_call must be positive");
-    if (d->block_size < 64 || d->block_size > 4096 || (d->block_size & (d->block_size - 1)))
-        return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 4096]");
+    if (d->call_mode != CPQ_CALLS_WHOLE_BLOCKS && d->call_mode != CPQ_CALLS_ANY)
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "call_mode must be CPQ_CALLS_WHOLE_BLOCKS or CPQ_CALLS_ANY");
+    const bool anyCalls = d->call_mode == CPQ_CALLS_ANY;
+    if (anyCalls) {
+        if (d->block_size < 1 || d->block_size > 4096)
+            return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size (the call quantum) must be in [1, 4096]");
+        if (d->semantics != CPQ_SEM_REFERENCE || d->partition_size != 0)
+            return fail(nullptr, CPQ_ERR_INVALID_ARG, "CPQ_CALLS_ANY runs the reference's own layer plan: reference semantics, partition_size 0");
+    } else if (d->block_size < 64 || d->block_size > 4096 || (d->block_size & (d->block_size - 1)))
+        return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 4096] (any quantum from 1 to 4096: call_mode = CPQ_CALLS_ANY)");
     if (d->semantics != CPQ_SEM_REFERENCE && d->semantics != CPQ_SEM_EXACT)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "bad semantics");
     if (d->mac_tile != 0 && d->mac_tile != 4 && d->mac_tile != 8 && d->mac_tile != 16 && d->mac_tile != 32)
@@ -197,14 +208,17 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->sampleRate = d->sample_rate > 0.0 ? d->sample_rate : 48000.0;
     e->nCh = 2 * d->n_streams;
     e->B = d->block_size;
-    e->P = d->partition_size ? d->partition_size : d->block_size;
-    if (e->P < e->B || e->P > 4096 || (e->P & (e->P - 1)) || ((int64_t)d->max_blocks_per_call * e->B) % e->P != 0) {
+    e->anyCalls = anyCalls;
+    e->P0 = nextPow2(std::max(d->block_size, 64));
+    e->maxCall = (int)std::min<int64_t>((int64_t)d->max_blocks_per_call * d->block_size, (int64_t)1 << 30);
+    e->P = d->partition_size ? d->partition_size : (anyCalls ? e->P0 : d->block_size);
+    if (!anyCalls && (e->P < e->B || e->P > 4096 || (e->P & (e->P - 1)) || ((int64_t)d->max_blocks_per_call * e->B) % e->P != 0)) {
         const int p = e->P;
         delete e;
         return fail(nullptr, CPQ_ERR_INVALID_ARG,
                     "partition_size %d must be a power of two in [block_size, 4096] dividing block_size*max_blocks_per_call", p);
     }
-    e->tMax = (int)(((int64_t)d->max_blocks_per_call * e->B) / e->P);     // partitions per call
+    e->tMax = (int)(((int64_t)e->maxCall + e->P - 1) / e->P);     // partitions per call (rounded up for ragged calls)
     e->macTile = d->mac_tile;     // 0 = automatic (workgroup-cooperative kernel for calls of >= 32 blocks)
 
     // partition capacity from the longest h_eff the plan can produce for max_ir_len
@@ -214,11 +228,13 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "cannot plan max_ir_len=%d", d->max_ir_len);
     }
     const int taps = (d->semantics == CPQ_SEM_REFERENCE) ? std::max(pl.heff_len, d->max_ir_len) : d->max_ir_len;
-    const int kReal = (taps + e->P - 1) / e->P;
+    // engines whose every stream runs in a plan group (engine_native.cpp) keep only a token main-path arena
+    const bool allNative = anyCalls || d->schedule == CPQ_SCHED_REFERENCE_NUC;
+    const int kReal = allNative ? 1 : (taps + e->P - 1) / e->P;
     e->kCap = (int)alignUp(kReal, cpq::kMacMaxTile);
     e->hRows = e->kCap + 4 * cpq::kMacMaxTile;   // zero rows read by the prefetch past the last partition (per layer in layered mode)
     e->ringSlots = nextPow2(e->kCap + cpq::kMacMaxTile + e->tMax);
-    e->heffCap = (int64_t)e->kCap * e->P;
+    e->heffCap = std::max<int64_t>((int64_t)e->kCap * e->P, d->max_ir_len);
 
     // ---- arena layout
     struct Item { void** ptr; int64_t bytes; };
@@ -284,7 +300,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     for (int c = 0; c < e->nCh; ++c) e->irSlotHost[c] = c;
     e->irLoaded.assign(e->nCh, 0);
     e->irParts.assign(e->nCh, 0);
-    e->slotSpecTail.assign(e->nCh, 0);
+    e->groupOf.assign(d->n_streams, -1);
     e->eqTpSafe.assign(d->n_streams, 1);   // no active band yet: trivially guard-free
     e->eqMidSide.assign(d->n_streams, 0);
     e->eqParamsHost.assign(d->n_streams, cpq_eq_params{});
@@ -319,7 +335,8 @@ void cpq_engine_destroy(cpq_engine* e)
         for (auto& ev : s.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         for (auto& ev : s.freeList) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     }
-    freeSpecTails(e);
+    freeGroups(e);
+    freePinnedRing(e);
     if (e->copyIn) {
         (void)hipStreamDestroy(e->copyIn);
         (void)hipStreamDestroy(e->copyOut);
@@ -372,7 +389,7 @@ int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
 {
     if (!e) return CPQ_ERR_INVALID_ARG;
     if (sampleRate <= 0.0) return fail(e, CPQ_ERR_INVALID_ARG, "sample rate must be positive");
-    if (maxBlock <= 0 || maxBlock > e->P * e->tMax)
+    if (maxBlock <= 0 || maxBlock > e->maxCall)
         return fail(e, CPQ_ERR_INVALID_ARG, "max_block %d exceeds block_size*max_blocks_per_call", maxBlock);
     const bool rateChanged = sampleRate != e->sampleRate;
     e->sampleRate = sampleRate;
@@ -435,26 +452,25 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order)
 
 
 // ------------------------------------------------------------------------ whole path
-static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
+static int enqueueBoth(cpq_engine* e, const double* a, double* b, int n)
 {
     int rc = CPQ_OK;
-    const int n = T * e->P;
     auto conv = [e](const double* x, double* y, int t) {
         return e->convLevel == CPQ_LEVEL_PROCESSOR ? enqueueConvProc(e, x, y, t) : enqueueConv(e, x, y, t);
     };
     if (e->order == CPQ_ORDER_CONV_THEN_EQ) {
-        if (!e->convBypassed) rc = conv(a, b, T);
+        if (!e->convBypassed) rc = conv(a, b, n);
         else if (a != b) cpq::launch_rows_copy(e->stream, a, n, 0, b, n, 0, n, e->nCh);
-        if (rc == CPQ_OK) rc = enqueueEq(e, b, b, T);
+        if (rc == CPQ_OK) rc = enqueueEq(e, b, b, n);
     } else if (e->convBypassed) {
-        rc = enqueueEq(e, a, b, T);
+        rc = enqueueEq(e, a, b, n);
     } else {
-        rc = enqueueEq(e, a, e->mid, T);
+        rc = enqueueEq(e, a, e->mid, n);
         if (rc == CPQ_OK && e->anyTrim) {       // scaleBlockFallback(block, convolverInputTrimGain) (:440-447)
             ProfScope p(e, CPQ_K_MIX);
             cpq::launch_rows_scale(e->stream, e->mid, n, n, e->nCh, e->trimDev);
         }
-        if (rc == CPQ_OK) rc = conv(e->mid, b, T);
+        if (rc == CPQ_OK) rc = conv(e->mid, b, n);
     }
     if (rc == CPQ_OK && e->ofInPath) {
         // outputFilter.process runs when the convolver or the EQ is active (:453-463); a stream with both bypassed
@@ -469,7 +485,7 @@ static int enqueueBoth(cpq_engine* e, const double* a, double* b, int T)
             CPQ_HIP(e, hipMemcpyAsync(e->ofFlags + (size_t)2 * s * kBands, flags, sizeof(flags), hipMemcpyHostToDevice, e->stream));
             e->ofPass[s] = pass;
         }
-        if (anyActive) rc = enqueueOutFilter(e, b, b, T);
+        if (anyActive) rc = enqueueOutFilter(e, b, b, n);
     }
     if (rc == CPQ_OK && e->anyMakeup) {         // scaleBlockFallback(block, outputMakeupGain) (:465-469)
         ProfScope p(e, CPQ_K_MIX);
@@ -517,16 +533,15 @@ int32_t cpq_engine_set_conv_bypass(cpq_engine* e, int32_t bypassed)
 
 int32_t cpq_engine_process_block_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
 {
-    int T = 0;
-    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    const int rc = checkCall(e, dIn, dOut, nSamples);
     if (rc != CPQ_OK) return rc;
     CPQ_HIP(e, hipSetDevice(e->device));
-    return enqueueBoth(e, dIn, dOut, T);
+    return enqueueBoth(e, dIn, dOut, nSamples);
 }
 
 int32_t cpq_engine_process_block(cpq_engine* e, const double* in, double* out, int32_t nSamples)
 {
-    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueBoth(e, a, b, T); });
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int n) { return enqueueBoth(e, a, b, n); });
 }
 
 // -------------------------------------------------------------------------- profiling

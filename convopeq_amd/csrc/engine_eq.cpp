@@ -133,6 +133,7 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
     bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO);
     for (char s : e->eqTpSafe) tp = tp && s;
     const int cbs = n / e->B;            // callback blocks in this range (AGC is block-rate)
+    const bool raggedTail = n % e->B != 0;     // CPQ_CALLS_ANY: the last callback of the call is shorter than the quantum
     // total-gain ramp (Processing.cpp:1262-1274): per callback setTargetValue / skip on a LinearRamp (50 ms);
     // evaluated on the host (scalar per-stream state), applied by the ramp kernel only while some stream is moving
     std::vector<int> rampOnHost;
@@ -146,6 +147,8 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
             if (e->agcOnHost[s] || (pass && pass[s])) continue;
             const bool moving = r.remaining > 0 || std::fabs(r.target - r.wanted) > 1e-6 || r.current != r.wanted;
             if (!moving) continue;
+            if (raggedTail)
+                return fail(e, CPQ_ERR_UNSUPPORTED, "a total-gain ramp is running: the call must be whole callbacks of %d samples until it ends", e->B);
             if (!anyRamp) { rampOnHost.assign(S, 0); rampHost.assign((size_t)S * cbs * 2, 0.0); anyRamp = true; }
             rampOnHost[s] = 1;
             for (int t = 0; t < cbs; ++t) {
@@ -190,6 +193,7 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
         }
     }
     e->eqProcessed = true;
+    if (e->anyAgc && raggedTail) return fail(e, CPQ_ERR_UNSUPPORTED, "the block-rate AGC needs calls of whole callbacks of %d samples", e->B);
     if (e->anyAgc) {
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_agc_block_rms(e->stream, dIn, stride, e->nCh, e->B, cbs, e->agcRmsIn);     // cachedInputRMS (:1116-1127)
@@ -226,10 +230,9 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
 // (band nodes) and cross-faded with the dry block sample by sample; once the fade-out is complete the EQ returns early
 // (states, gain ramp and AGC frozen); releasing the bypass clears every filter state and fades back in.  The call is cut
 // where some stream changes class, each piece runs the ordinary kernels with the streams' tables switched accordingly.
-int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
+int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
 {
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
-    const int n = T * e->P;
     const int S = e->desc.n_streams;
     auto agcReset = [e](int s) -> int {        // rtAgcCurrentGainShadow = 1, envelopes = 0 (Processing.cpp:586-593, 1070-1077)
         if (e->agcState) CPQ_HIP(e, hipMemsetAsync(e->agcState + (size_t)s * 3, 0, sizeof(double) * 3, e->stream));
@@ -242,6 +245,8 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
         e->eqProcessed = true;
         return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr);
     }
+    if (n % e->B != 0)
+        return fail(e, CPQ_ERR_UNSUPPORTED, "an EQ bypass transition or band reset is pending: the call must be whole callbacks of %d samples", e->B);
     const int cbs = n / e->B;
     const int total = std::max(1, (int)(e->sampleRate * 0.005 + 0.5));       // BYPASS_FADE_TIME_SEC (EQProcessor.h:564)
     enum : char { kNormal = 0, kFade = 1, kPass = 2 };
@@ -402,11 +407,11 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T)
     return rc;
 }
 
-int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T)
+int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int n)
 {
     if (!e->ofSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_outfilter_set_params has not been called");
     const bool tp = (e->eqMode == CPQ_EQ_MODE_AUTO) && e->ofTpSafe;
-    return enqueueCascade(e, dIn, dOut, (int64_t)T * e->P, T * e->P, tp, CPQ_K_OUTFILT, CPQ_K_OUTFILT, e->ofCoef, e->ofFlags,
+    return enqueueCascade(e, dIn, dOut, (int64_t)n, n, tp, CPQ_K_OUTFILT, CPQ_K_OUTFILT, e->ofCoef, e->ofFlags,
                           e->ofSatGain, e->ofState, e->ofTp);
 }
 
@@ -552,16 +557,15 @@ int32_t cpq_eq_reset(cpq_engine* e)
 
 int32_t cpq_eq_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
 {
-    int T = 0;
-    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    const int rc = checkCall(e, dIn, dOut, nSamples);
     if (rc != CPQ_OK) return rc;
     CPQ_HIP(e, hipSetDevice(e->device));
-    return enqueueEq(e, dIn, dOut, T);
+    return enqueueEq(e, dIn, dOut, nSamples);
 }
 
 int32_t cpq_eq_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
 {
-    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueEq(e, a, b, T); });
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int n) { return enqueueEq(e, a, b, n); });
 }
 
 // ------------------------------------------------------------------- output filter (N2)
@@ -629,16 +633,15 @@ int32_t cpq_outfilter_reset(cpq_engine* e)
 
 int32_t cpq_outfilter_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
 {
-    int T = 0;
-    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    const int rc = checkCall(e, dIn, dOut, nSamples);
     if (rc != CPQ_OK) return rc;
     CPQ_HIP(e, hipSetDevice(e->device));
-    return enqueueOutFilter(e, dIn, dOut, T);
+    return enqueueOutFilter(e, dIn, dOut, nSamples);
 }
 
 int32_t cpq_outfilter_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
 {
-    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueOutFilter(e, a, b, T); });
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int n) { return enqueueOutFilter(e, a, b, n); });
 }
 
 }  // extern "C"

@@ -32,18 +32,52 @@ struct ProfileSlot {
 };
 
 
-// One tail layer of a FilterSpec plan, run at the reference's OWN partition size: the HC/LC gains (and the air-absorption
-// damping) multiply every partition spectrum of the layer at that layer's FFT size, which folds time-aliased energy
-// into the frame (src/MKLNonUniformConvolver.cpp:336-443) -- only reproducible with the same partitioning.
-struct SpecTail {
+// One layer of a plan group (engine_native.cpp), run at the reference's OWN partition size: the HC/LC gains (and the
+// air-absorption damping) multiply every partition spectrum of a layer at that layer's FFT size, which folds time-aliased
+// energy into the frame (src/MKLNonUniformConvolver.cpp:336-443) -- only reproducible with the same partitioning; and the
+// reference's Add / Get bookkeeping (input fill, distributed tail MAC, delay-line reader) runs per layer.
+struct NativeLayer {
     int P = 0, K = 0, kPad = 0, hRows = 0, ringSlots = 0, nbMax = 0, accCap = 0, outRing = 0;
-    int head = 0, histSel = 0, accSel = 0, fill = 0;
-    long long blocksDone = 0;
+    int head = 0, histSel = 0, accSel = 0, fill = 0;     // FDL ring head, ping-pong selectors, input fill (inputPos)
     double gain = 1.0;          // tail-layer gain applied by the delay-line reader
+    int ppc = 1, outputDelay = 0;       // partsPerCallback (:988-994), outputDelaySamples (:1005-1024)
+    // host replay of the reference's integer state: layer 0 -- samples written to / read from the output ring
+    // (m_ringAvail = wPos - rPos); tail layers -- delayWriteCursor / delayReadCursor, the distributed MAC's progress
+    bool distributing = false;
+    int nextPart = 0;
+    long long wPos = 0, rPos = 0;
     char* mem = nullptr;
     double2 *X = nullptr, *XDN = nullptr, *H = nullptr, *HDN = nullptr, *Y = nullptr, *tw = nullptr, *tw2 = nullptr;
     double *hist[2] = { nullptr, nullptr }, *acc[2] = { nullptr, nullptr }, *z = nullptr, *ring = nullptr, *gainDev = nullptr;
     double2* scratch = nullptr;   // four-step FFT workspace (P > 4096): [max(nCh * nbMax, K)][P]
+};
+
+// Streams that share one layer plan and one phase (loaded while the group was fresh); see engine_native.cpp
+struct PlanGroup {
+    cpq_nuc_plan plan{};
+    bool hasSpec = false, shared = false;       // shared: CPQ_ALL_STREAMS (one stereo IR for every member)
+    cpq_filter_spec spec{};
+    int capCh = 0, usedCh = 0;                  // allocated / launched local channels (2 per pair slot)
+    std::vector<int> streamOfPair;              // pair slot -> stream, -1 = free
+    std::vector<NativeLayer> layers;
+    int* chMapDev = nullptr;                    // [capCh] local channel -> row of the call's buffers (-1 = free slot)
+    int* irSlotDev = nullptr;                   // [capCh] local channel -> IR slot
+    long long* tabDev = nullptr;                // the call's chunk tables
+    int tabCap = 0;
+    std::vector<long long> tabHost;
+    std::vector<size_t> tabOffs;
+    std::vector<int> nbOf;
+    long long samplesSinceReset = 0;
+    int lastGot = 0, lastCall = 0;              // Get()'s return value summed over the chunks of the last call
+};
+
+struct PinnedRing {
+    static constexpr int kSlots = 4;
+    char* host = nullptr;
+    size_t slotBytes = 0;
+    hipEvent_t done[kSlots] = {};
+    bool used[kSlots] = {};
+    int next = 0;
 };
 
 struct cpq_engine {
@@ -56,13 +90,16 @@ struct cpq_engine {
 
     // geometry
     int nCh = 0;          // 2 * streams
-    int B = 0;            // caller's block size (the reference's blockSize: layer plan, latency)
+    int B = 0;            // caller's block size (the reference's blockSize / callQuantum: layer plan, chunking)
+    int P0 = 0;           // the reference's layer-0 partition = getLatency(): nextPow2(max(B, 64))
     int P = 0;            // internal partition size (samples) == complex bins per packed spectrum; multiple of B
     int kCap = 0;         // partition capacity per IR slot (multiple of kMacMaxTile)
     int hRows = 0;        // kCap + prefetch rows allocated per IR slot
     int ringSlots = 0;    // FDL ring slots per channel (power of two)
     int tMax = 0;
     int macTile = 16;
+    bool anyCalls = false;  // CPQ_CALLS_ANY: any call quantum, ragged calls; every stream runs in a plan group
+    int maxCall = 0;        // samples per call the engine is sized for (max_blocks_per_call * block_size)
 
     // device arena
     char* arena = nullptr;
@@ -187,11 +224,12 @@ struct cpq_engine {
     void* tailState = nullptr;          // device: callback counter + read cursors
     long long* tailSched = nullptr;     // device: [nTail][tMax]
 
-    // FilterSpec plans with tail layers (LTI-valid ones): layer 0 runs in the main path, each tail layer in a SpecTail
-    std::vector<SpecTail> specTails;
-    cpq_nuc_plan specPlan{};
-    void* specState = nullptr;          // device: callback counter + delay-line read cursors of the tail layers
-    long long* specSched = nullptr;     // device: [2][callbacks per call] read positions (-1 = the reader skips)
+    // plan groups (engine_native.cpp): streams run on the reference's own layer plan with its Add / Get bookkeeping
+    std::vector<PlanGroup*> groups;
+    std::vector<int> groupOf;           // per stream: index into groups, -1 = main (uniform) path
+    bool mainActive = false;            // some loaded stream runs on the main path
+    int lastCallSamples = 0;
+    PinnedRing pinned;                  // small per-call host -> device tables
 
     // processor-level wrapper (N1)
     int convLevel = CPQ_LEVEL_NUC;
@@ -266,20 +304,29 @@ struct ProfScope {
 };
 
 
-int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples, int* T);
+int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples);
 int zeroRuntimeState(cpq_engine* e, bool conv, bool eq);
 
+// engine_native.cpp
+int stageUpload(cpq_engine* e, void* dst, const void* src, size_t bytes);
+void freePinnedRing(cpq_engine* e);
+void freeGroups(cpq_engine* e);
+int resetGroups(cpq_engine* e);
+int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double* irR, int irLen, double scale, int headTaps,
+                     const cpq_filter_spec* spec, const cpq_nuc_plan& pl);
+int leaveNativeGroup(cpq_engine* e, int stream);
+int groupsAppend(cpq_engine* e, const double* dIn, int n);
+int groupsRunLayer0(cpq_engine* e, double* dOut, int n);
+int groupsRunTails(cpq_engine* e, double* dOut, int n);
 // engine_conv.cpp
-void freeSpecTails(cpq_engine* e);
-int resetSpecTails(cpq_engine* e);
-int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int T);
+int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n);
 // engine_proc.cpp
 int uploadProcParams(cpq_engine* e);
-int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T);
+int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n);
 // engine_eq.cpp
 void syncEqBypass(cpq_engine* e);
-int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int T);
-int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T);
+int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n);
+int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int n);
 
 // Host-pointer entry points: H2D, the kernel sequence and D2H.  Long calls are cut into four time chunks (each a complete
 // engine call: the state carries over on the engine's stream) so that the upload of chunk i+1 and the download of chunk
@@ -288,11 +335,11 @@ int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int T);
 template <typename F>
 int viaStaging(cpq_engine* e, const double* in, double* out, int nSamples, F&& body)
 {
-    int T = 0;
-    int rc = checkCall(e, in, out, nSamples, &T);
+    int rc = checkCall(e, in, out, nSamples);
     if (rc != CPQ_OK) return rc;
     CPQ_HIP(e, hipSetDevice(e->device));
     constexpr int kChunks = 4;
+    const int T = nSamples / e->P;                                      // partitions in the call (whole ones outside CPQ_CALLS_ANY)
     auto pinned = [](const void* p) {
         hipPointerAttribute_t a{};
         if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory
@@ -300,10 +347,10 @@ int viaStaging(cpq_engine* e, const double* in, double* out, int nSamples, F&& b
     };
     // pageable buffers: the runtime stages every copy and blocks the host, so chunking only adds strided copies
     // (measured 1157 vs 1230 M samples/s); one upload, one download
-    if (T < 32 || T % kChunks != 0 || !pinned(in) || !pinned(out)) {
+    if (e->anyCalls || T < 32 || T % kChunks != 0 || !pinned(in) || !pinned(out)) {
         const size_t bytes = (size_t)e->nCh * nSamples * sizeof(double);
         CPQ_HIP(e, hipMemcpyAsync(e->stageIn, in, bytes, hipMemcpyHostToDevice, e->stream));
-        rc = body(e->stageIn, e->stageOut, T);
+        rc = body(e->stageIn, e->stageOut, nSamples);
         if (rc != CPQ_OK) return rc;
         CPQ_HIP(e, hipMemcpyAsync(out, e->stageOut, bytes, hipMemcpyDeviceToHost, e->stream));
         CPQ_HIP(e, hipStreamSynchronize(e->stream));
@@ -333,7 +380,7 @@ int viaStaging(cpq_engine* e, const double* in, double* out, int nSamples, F&& b
                                     e->copyIn));
         CPQ_HIP(e, hipEventRecord(e->evIn[i], e->copyIn));
         CPQ_HIP(e, hipStreamWaitEvent(e->stream, e->evIn[i], 0));
-        rc = body(dIn, dOut, chunkT);
+        rc = body(dIn, dOut, (int)chunkLen);
         if (rc != CPQ_OK) { (void)hipDeviceSynchronize(); return rc; }
         CPQ_HIP(e, hipEventRecord(e->evDone[i], e->stream));
         if (i > 0) { rc = download(i - 1); if (rc != CPQ_OK) return rc; }

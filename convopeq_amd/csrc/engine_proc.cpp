@@ -18,7 +18,7 @@ int procDelayOf(const cpq_engine* e, int s)
 {
     // algorithmLatency = conv->latency (layer-0 partSize == block size; direct head unsupported),
     // irPeakLatency clamped like :266-277 (MAX_BLOCK_SIZE 524288, MAX_IR_LATENCY 2^21)
-    const int alg = e->directHead ? 0 : std::min(e->B, 524288);     // storedDirectHeadEnabled ? 0 : latency (:266)
+    const int alg = e->directHead ? 0 : std::min(e->P0, 524288);    // storedDirectHeadEnabled ? 0 : latency (:266); latency = layer-0 partSize
     const int peak = std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152);
     return alg + peak;
 }
@@ -47,7 +47,7 @@ int uploadProcParams(cpq_engine* e)
     }
     // delay ring: the longest delay in sight (any IR that fits the engine: irPeakLatency < irLen) plus one call; a larger
     // request later grows it, keeping what it holds
-    const int64_t need = (int64_t)std::max(maxDelay, e->B + e->desc.max_ir_len) + (int64_t)e->tMax * e->P + 1;
+    const int64_t need = (int64_t)std::max(maxDelay, e->P0 + e->desc.max_ir_len) + (int64_t)e->tMax * e->P + 1;
     if (need > e->dryRingSize) {
         const int size = nextPow2((int)std::min<int64_t>(need, (int64_t)1 << 30));
         double* ring = nullptr;
@@ -72,10 +72,9 @@ int uploadProcParams(cpq_engine* e)
     return CPQ_OK;
 }
 
-int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
+int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
 {
     if (!e->procGains) { const int rc = uploadProcParams(e); if (rc != CPQ_OK) return rc; }
-    const int n = T * e->P;
     // mix smoothing: per callback the reference moves the ramp's target to the current mix (:366-371) and, while the ramp
     // is running at the START of a callback, mixes that whole callback with per-sample gains equalPowerSin(getNextValue())
     // (:591-607).  Parameters only change between calls, so the smoothed region is a prefix of the call.
@@ -138,14 +137,15 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
     }
     e->dryPos += n;
     if (!skipConv) {
-        const int rc = enqueueConv(e, dIn, dOut, T);
+        const int rc = enqueueConv(e, dIn, dOut, n);
         if (rc != CPQ_OK) return rc;
     }
     // Latency compensation per callback and stream (:263-290): a total latency that moved by >= 2 samples starts, unless
     // one is running, a 20 ms cross-fade of the dry read from the delay in use to the new one; the callbacks that start
     // while it runs blend sample by sample until the ramp ends (:394-540).  The bypass reads at the present latency
     // (:141-145).  Ranges of the call between the callbacks where some stream starts a fade go to one launch each.
-    const int cbs = n / e->B;
+    const int cbs = (n + e->B - 1) / e->B;                  // callbacks (chunks of the call quantum; the last one may be shorter)
+    auto lenOf = [&](int t) { return std::min(e->B, n - t * e->B); };
     const int xTotal = std::max(1, (int)(e->sampleRate * 0.02 + 0.5));
     struct Range { int c0, c1; };
     std::vector<Range> ranges;
@@ -159,7 +159,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
                 auto f = e->latFade[s];
                 const double total = (double)procDelayOf(e, s);
                 if (!f.primed || firstCall) {             // prepareToPlay: latency + irLatency, fade gain at 1 (Lifecycle.cpp:377-388)
-                    f.latCurrent = f.latTarget = f.oldDelay = (double)std::min(e->B + std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152), 2097152 + 524288);
+                    f.latCurrent = f.latTarget = f.oldDelay = (double)std::min(e->P0 + std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152), 2097152 + 524288);
                     f.current = f.target = 1.0; f.remaining = 0; f.primed = true;
                 }
                 for (int t = 0; t < cbs; ++t) {
@@ -169,7 +169,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
                         if (t > 0) starts[t] = 1;
                     }
                     if (f.remaining > 0) {
-                        f.remaining = std::max(0, f.remaining - e->B);
+                        f.remaining = std::max(0, f.remaining - lenOf(t));
                         if (f.remaining <= 0) { f.latCurrent = f.latTarget; f.oldDelay = f.latCurrent; }
                     }
                 }
@@ -191,7 +191,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
             continue;
         }
         if (!f.primed || firstCall) {
-            f.latCurrent = f.latTarget = f.oldDelay = (double)std::min(e->B + std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152), 2097152 + 524288);
+            f.latCurrent = f.latTarget = f.oldDelay = (double)std::min(e->P0 + std::min(std::max(0, (int)e->procParams[s].ir_peak_latency), 2097152), 2097152 + 524288);
             f.current = f.target = 1.0; f.step = 0.0; f.remaining = 0; f.primed = true;
         }
         for (int r = 0; r < R; ++r) {
@@ -211,7 +211,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
                     dOld[(size_t)r * S + s] = (int)f.oldDelay;
                 }
                 if (f.remaining > 0) {
-                    for (int i = 0; i < e->B; ++i) {                     // getNextValue until the ramp has ended
+                    for (int i = 0; i < lenOf(t); ++i) {                 // getNextValue until the ramp has ended
                         f.current += f.step;
                         if (--f.remaining <= 0) f.current = f.target;
                         vals.push_back(f.current);
@@ -237,7 +237,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int T)
         e->latCap = xTotal + e->B;
     }
     for (int r = 0; r < R; ++r) {
-        const int off = ranges[r].c0 * e->B, len = (ranges[r].c1 - ranges[r].c0) * e->B;
+        const int off = ranges[r].c0 * e->B, len = std::min(ranges[r].c1 * e->B, n) - off;
         const bool fade = !xg[r].empty();
         const std::vector<int> rn(dNew.begin() + (size_t)r * S, dNew.begin() + (size_t)(r + 1) * S);
         const std::vector<int> ro(dOld.begin() + (size_t)r * S, dOld.begin() + (size_t)(r + 1) * S);
@@ -310,16 +310,15 @@ int32_t cpq_engine_set_conv_level(cpq_engine* e, int32_t level)
 
 int32_t cpq_convproc_process_device(cpq_engine* e, const double* dIn, double* dOut, int32_t nSamples)
 {
-    int T = 0;
-    const int rc = checkCall(e, dIn, dOut, nSamples, &T);
+    const int rc = checkCall(e, dIn, dOut, nSamples);
     if (rc != CPQ_OK) return rc;
     CPQ_HIP(e, hipSetDevice(e->device));
-    return enqueueConvProc(e, dIn, dOut, T);
+    return enqueueConvProc(e, dIn, dOut, nSamples);
 }
 
 int32_t cpq_convproc_process(cpq_engine* e, const double* in, double* out, int32_t nSamples)
 {
-    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int T) { return enqueueConvProc(e, a, b, T); });
+    return viaStaging(e, in, out, nSamples, [e](const double* a, double* b, int n) { return enqueueConvProc(e, a, b, n); });
 }
 
 }  // extern "C"

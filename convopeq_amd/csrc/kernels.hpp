@@ -114,6 +114,17 @@ void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, 
 void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,
                           int pl2, int ol2, int d2);
 
+// Plan groups (engine_native.cpp): chMap[local channel] = row of the call's buffers (-1 = unused slot); q = chunk length
+// (one Add / Get pair of the reference per chunk); pos / cnt / sched: per chunk, replayed on the host.
+void launch_rows_gather(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, double* dst,
+                        int64_t dstStride, int64_t dstOff, int n, int nCh);
+void launch_ring_put_blocks(hipStream_t stream, const double* z, int64_t zStride, int P, int nb, double* ring, int ringSize,
+                            const long long* pos, int nCh);
+void launch_ring_get_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                            const double* ring, int ringSize, const long long* pos, const long long* cnt, int nCh);
+void launch_ring_add_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                            const double* ring, int ringSize, const long long* sched, double gain, int nCh);
+
 // EQ bypass cross-fade for the streams flagged in `on`: out = out * g + dry * (1 - g); g = gains[s][i] for i < len[s], gEnd[s] after
 void launch_bypass_blend(hipStream_t stream, double* out, int64_t outStride, const double* dry, int64_t dryStride, int n,
                          int nCh, const int* on, const int* len, const double* gEnd, const double* gains, int cap);

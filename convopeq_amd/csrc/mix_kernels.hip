@@ -271,6 +271,74 @@ __global__ __launch_bounds__(256) void k_ring_add(double* out, int64_t outStride
 }
 
 
+// ---- plan groups (engine_native.cpp): a group's channels are rows chMap[local] of the call's buffers (-1 = unused slot);
+// every Add / Get pair of the reference is one CHUNK of the call (q samples, the last one possibly shorter), whose read
+// positions the host replays (ringRead :1376-1402, delayLineReadAdd :1653-1688) and uploads per call.
+// acc[local][dstOff + i] = in[chMap[local]][i]: input accumulation of one layer (inputAccBuf, NUC.cpp:1431-1446)
+__global__ __launch_bounds__(256) void k_rows_gather(const double* __restrict__ src, int64_t srcStride,
+                                                     const int* __restrict__ chMap, double* __restrict__ dst,
+                                                     int64_t dstStride, int64_t dstOff, int n)
+{
+    const int g = chMap[blockIdx.y];
+    if (g < 0) return;
+    const double* s = src + (int64_t)g * srcStride;
+    double* d = dst + (int64_t)blockIdx.y * dstStride + dstOff;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// ring[c][(pos[j] + i) & mask] = z[c][j P + i]: the blocks a layer finished in this call go to its output ring / delay
+// line at the position each one has in the reference (ringWrite :1341-1371, delayLineWrite :1639-1648)
+__global__ __launch_bounds__(256) void k_ring_put_blocks(const double* __restrict__ z, int64_t zStride, int P, int nb,
+                                                         double* __restrict__ ring, int mask,
+                                                         const long long* __restrict__ pos)
+{
+    const double* s = z + (int64_t)blockIdx.y * zStride;
+    double* r = ring + (int64_t)blockIdx.y * (mask + 1);
+    const int n = nb * P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = i / P;
+        const long long p = pos[j];
+        if (p >= 0) r[(p + (i - j * P)) & mask] = s[i];
+    }
+}
+
+// Get() of layer 0 per chunk: cnt[cb] samples from ring position pos[cb], zero-filled to the chunk's end (:1376-1402)
+__global__ __launch_bounds__(256) void k_ring_get_chunks(double* __restrict__ out, int64_t outStride,
+                                                         const int* __restrict__ chMap, int n, int q,
+                                                         const double* __restrict__ ring, int mask,
+                                                         const long long* __restrict__ pos, const long long* __restrict__ cnt)
+{
+    const int g = chMap[blockIdx.y];
+    if (g < 0) return;
+    double* o = out + (int64_t)g * outStride;
+    const double* r = ring + (int64_t)blockIdx.y * (mask + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cb = i / q, j = i - cb * q;
+        o[i] = (j < cnt[cb]) ? r[(pos[cb] + j) & mask] : 0.0;
+    }
+}
+
+// delayLineReadAdd per chunk (sched[cb] < 0: the writer is not far enough ahead, nothing is added)
+__global__ __launch_bounds__(256) void k_ring_add_chunks(double* __restrict__ out, int64_t outStride,
+                                                         const int* __restrict__ chMap, int n, int q,
+                                                         const double* __restrict__ ring, int mask,
+                                                         const long long* __restrict__ sched, double gain)
+{
+    const int g = chMap[blockIdx.y];
+    if (g < 0) return;
+    double* o = out + (int64_t)g * outStride;
+    const double* r = ring + (int64_t)blockIdx.y * (mask + 1);
+    const bool unity = fabs(gain - 1.0) < 1.0e-12;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cb = i / q, j = i - cb * q;
+        const long long s0 = sched[cb];
+        if (s0 < 0) continue;
+        const double v = r[(s0 + j) & mask];
+        o[i] = unity ? (o[i] + v) : (o[i] + v * gain);
+    }
+}
+
+
 // ---- direct head (processDirectBlock, src/MKLNonUniformConvolver.cpp:1169-1232): the first <= 32 taps run as a
 // time-domain FIR over [history | block]; same accumulation pattern as the AVX2 loop (two 4-lane FMA accumulators over
 // blocks of 8 taps, lanes summed as (0+2)+(1+3), scalar tail), result flushed to 0 when non-finite or below 1e-20.
@@ -479,6 +547,36 @@ void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, 
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_ring_add, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, n, B, ring, ringSize - 1, sched, gain);
+}
+
+void launch_rows_gather(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, double* dst,
+                        int64_t dstStride, int64_t dstOff, int n, int nCh)
+{
+    if (n <= 0 || nCh <= 0) return;
+    hipLaunchKernelGGL(k_rows_gather, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, chMap, dst, dstStride, dstOff, n);
+}
+
+void launch_ring_put_blocks(hipStream_t stream, const double* z, int64_t zStride, int P, int nb, double* ring, int ringSize,
+                            const long long* pos, int nCh)
+{
+    if (nb <= 0 || nCh <= 0) return;
+    hipLaunchKernelGGL(k_ring_put_blocks, rowsGrid(nb * P, nCh), dim3(256), 0, stream, z, zStride, P, nb, ring, ringSize - 1, pos);
+}
+
+void launch_ring_get_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                            const double* ring, int ringSize, const long long* pos, const long long* cnt, int nCh)
+{
+    if (n <= 0 || nCh <= 0) return;
+    hipLaunchKernelGGL(k_ring_get_chunks, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, chMap, n, q, ring,
+                       ringSize - 1, pos, cnt);
+}
+
+void launch_ring_add_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                            const double* ring, int ringSize, const long long* sched, double gain, int nCh)
+{
+    if (n <= 0 || nCh <= 0) return;
+    hipLaunchKernelGGL(k_ring_add_chunks, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, chMap, n, q, ring,
+                       ringSize - 1, sched, gain);
 }
 
 void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,

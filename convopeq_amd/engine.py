@@ -155,11 +155,11 @@ def ir_estimate_peak_latency(ir):
 class BatchedEngine:
     def __init__(self, n_streams, block_size=512, max_ir_len=131072, max_blocks_per_call=64,
                  semantics=K.CPQ_SEM_REFERENCE, device=0, sample_rate=48000.0, mac_tile=0, partition_size=0,
-                 schedule=K.CPQ_SCHED_UNIFORM):
+                 schedule=K.CPQ_SCHED_UNIFORM, call_mode=K.CPQ_CALLS_WHOLE_BLOCKS):
         self._lib = K.load()
         self._h = K._E()
         d = K.EngineDesc(C.sizeof(K.EngineDesc), device, n_streams, block_size, max_ir_len, max_blocks_per_call,
-                         semantics, mac_tile, sample_rate, partition_size, schedule)
+                         semantics, mac_tile, sample_rate, partition_size, schedule, call_mode, 0)
         rc = self._lib.cpq_engine_create(C.byref(d), C.byref(self._h))
         if rc != 0:
             raise CpqError(rc, self._lib.cpq_last_error(None).decode())
@@ -259,6 +259,9 @@ class BatchedEngine:
 
     def latency(self):
         return self._lib.cpq_conv_latency(self._h)
+
+    def last_got(self, stream=0):
+        return self._lib.cpq_conv_last_got(self._h, stream)
 
     def plan(self):
         p = K.NucPlan()

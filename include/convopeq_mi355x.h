@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CPQ_ABI_VERSION 1
+#define CPQ_ABI_VERSION 2
 
 typedef enum {
     CPQ_OK               =  0,
@@ -67,6 +67,23 @@ typedef enum {
      * (BASELINE.json configs[3]).  Every IR of the engine must have the same layer plan. */
     CPQ_SCHED_REFERENCE_NUC = 1
 } cpq_schedule;
+
+/* which call sizes the process entry points accept */
+typedef enum {
+    /* n_samples = T * block_size with block_size a power of two (64..4096): every B-sample quantum is one Add + Get
+     * pair of the reference with a full layer-0 partition, the regime in which its output is one linear convolution
+     * (h_eff) and the time-batched uniform schedule applies -- the throughput path */
+    CPQ_CALLS_WHOLE_BLOCKS = 0,
+    /* any block_size from 1 to 4096 (the reference's blockSize / callQuantum: 480, 441, 96 ...) and any n_samples >= 1.
+     * The call is cut into chunks of block_size samples (the last one may be shorter), each chunk is one Add(chunk) +
+     * Get(chunk) of every MKLNonUniformConvolver (StereoConvolver::process, src/convolver/ConvolverProcessor.Runtime.cpp:
+     * 1159-1184; chunking :659-682): input accumulates per layer until a partition of nextPow2(max(block_size, 64)) *
+     * {1, m, m^2} samples is full (src/MKLNonUniformConvolver.cpp:1431-1446), layer 0 goes through the output ring and a
+     * short read is zero-filled at the END of the chunk (:1376-1402), the tail layers follow the distributed MAC's
+     * completion schedule and the delay-line reader per chunk (:1497-1545, :1653-1688) -- including the reference's
+     * start-up gaps and dropped tail blocks at awkward quanta.  Every stream runs on the reference's own layer plan. */
+    CPQ_CALLS_ANY = 1
+} cpq_call_mode;
 
 /* POD mirror of convo::FilterSpec, src/MKLNonUniformConvolver.h:123-133 */
 typedef struct {
@@ -126,11 +143,13 @@ typedef struct {
     int32_t struct_size;             /* sizeof(cpq_engine_desc) */
     int32_t device;                  /* HIP device ordinal */
     int32_t n_streams;               /* S stereo streams -> 2*S channels */
-    int32_t block_size;              /* B: the caller's block / callQuantum; power of two, 64..4096;
-                                        partition size P == B (layer-0 partSize of the reference).  512 has
+    int32_t block_size;              /* B: the caller's block / callQuantum.  CPQ_CALLS_WHOLE_BLOCKS: a power of two,
+                                        64..4096, partition size P == B (layer-0 partSize of the reference);
+                                        CPQ_CALLS_ANY: 1..4096, layer-0 partition nextPow2(max(B, 64)).  512 has
                                         dedicated wave-level FFT kernels, other sizes use generic ones */
     int32_t max_ir_len;              /* longest IR (taps) any stream will be given */
-    int32_t max_blocks_per_call;     /* T_max: a process call carries 1..T_max blocks of B samples
+    int32_t max_blocks_per_call;     /* T_max: a process call carries 1..T_max blocks of B samples (CPQ_CALLS_ANY:
+                                        1..T_max * B samples)
                                         (reference: up to 524288 samples per process(),
                                         src/convolver/ConvolverProcessor.Runtime.cpp:609,667-682) */
     int32_t semantics;               /* cpq_semantics */
@@ -143,6 +162,8 @@ typedef struct {
                                         of P samples (offline / batched use).  The reference itself runs its tail
                                         layers at 8x and 64x the block size (src/MKLNonUniformConvolver.cpp:738-740). */
     int32_t schedule;                /* cpq_schedule (was reserved: 0 = uniform) */
+    int32_t call_mode;               /* cpq_call_mode: 0 = whole power-of-two blocks (default), 1 = any quantum / ragged calls */
+    int32_t reserved;
 } cpq_engine_desc;
 
 typedef struct cpq_engine cpq_engine;
@@ -224,6 +245,11 @@ int32_t cpq_conv_reset(cpq_engine* e);
 int32_t cpq_conv_is_ready(const cpq_engine* e);
 int32_t cpq_conv_latency(const cpq_engine* e);
 int32_t cpq_conv_get_plan(const cpq_engine* e, cpq_nuc_plan* plan);
+/* the return value of Get (src/MKLNonUniformConvolver.cpp:1553-1634) for the last process call of one stream: samples
+ * layer 0's output ring delivered, summed over the call's chunks (n_samples unless the ring ran short: start-up, awkward
+ * quanta -- the missing samples are zero-filled in the output as ringRead does).  Main-path streams always deliver
+ * every sample.  < 0: bad argument. */
+int32_t cpq_conv_last_got(const cpq_engine* e, int32_t stream);
 
 /* ------------------------------------------- convolver, processor level (N1) */
 /* Restatement of ConvolverProcessor::process(AudioBlock<double>&), steady state and the transitions of a live stream,

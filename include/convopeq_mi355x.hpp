@@ -10,7 +10,11 @@
 //           EQProcessor::{prepareToPlay,process(block, params, cache)} (src/eqprocessor/EQProcessor.h:189-205)
 // Same argument meaning and error behaviour as the reference: bool / sample-count returns, never throws on the
 // processing path, a failed call leaves the output zeroed (the reference's fail-closed FFT policy,
-// src/MKLNonUniformConvolver.cpp:75-82).
+// src/MKLNonUniformConvolver.cpp:75-82) -- and, unlike the reference's void returns, every call that can fail also reports
+// it: Add / process / prepareToPlay return false, lastStatus() / lastError() say why.
+// Call sizes: a power-of-two block (64..4096) runs the throughput path (calls of whole blocks); any other block size
+// (480, 441, 96 ...) or CallMode::Any selects CPQ_CALLS_ANY, where every call length is accepted and the reference's
+// inputPos accumulation / ring zero-fill are reproduced chunk by chunk.
 #pragma once
 
 #include <cstring>
@@ -44,12 +48,16 @@ private:
     void* ptr_;
 };
 
+enum class CallMode { Auto, WholeBlocks, Any };      // Auto: whole blocks for a power-of-two block size, else any
+
 class Engine {
 public:
     Engine(int streams, int blockSize, int maxIrLen, int maxBlocksPerCall, double sampleRate = 48000.0,
            cpq_semantics semantics = CPQ_SEM_REFERENCE, int device = 0, int partitionSize = 0,
-           cpq_schedule schedule = CPQ_SCHED_UNIFORM)
+           cpq_schedule schedule = CPQ_SCHED_UNIFORM, CallMode calls = CallMode::Auto)
     {
+        const bool pow2 = blockSize >= 64 && blockSize <= 4096 && (blockSize & (blockSize - 1)) == 0;
+        anyCalls_ = calls == CallMode::Any || (calls == CallMode::Auto && !pow2);
         cpq_engine_desc d{};
         d.struct_size = static_cast<int32_t>(sizeof(d));
         d.device = device;
@@ -62,6 +70,7 @@ public:
         d.sample_rate = sampleRate;
         d.partition_size = partitionSize;
         d.schedule = schedule;
+        d.call_mode = anyCalls_ ? CPQ_CALLS_ANY : CPQ_CALLS_WHOLE_BLOCKS;
         cpq_engine* raw = nullptr;
         const int rc = cpq_engine_create(&d, &raw);
         if (rc != CPQ_OK) throw std::runtime_error(std::string("cpq_engine_create: ") + cpq_last_error(nullptr));
@@ -75,11 +84,14 @@ public:
     int channels() const noexcept { return 2 * streams_; }
     int blockSize() const noexcept { return block_; }
     int maxSamplesPerCall() const noexcept { return maxCall_; }
+    bool acceptsAnyCallSize() const noexcept { return anyCalls_; }
+    const char* lastError() const noexcept { return cpq_last_error(h_.get()); }
 
 private:
     struct Deleter { void operator()(cpq_engine* e) const noexcept { cpq_engine_destroy(e); } };
     std::unique_ptr<cpq_engine, Deleter> h_;
     int streams_ = 0, block_ = 0, maxCall_ = 0;
+    bool anyCalls_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -98,18 +110,24 @@ public:
                                     filterSpec) == CPQ_OK;
     }
 
-    // Add: input planar [channel][numSamples]; nullptr = silence (reference :205-208)
-    void Add(const double* input, int numSamples)
+    // Add: input planar [channel][numSamples]; nullptr = silence (reference :205-208).  false (and lastStatus() != CPQ_OK)
+    // when the engine refused the call -- e.g. a call that is not whole blocks on a CallMode::WholeBlocks engine
+    bool Add(const double* input, int numSamples)
     {
         have_ = 0;
-        if (numSamples <= 0 || numSamples > e_.maxSamplesPerCall()) return;
+        status_ = CPQ_ERR_INVALID_ARG;
+        if (numSamples <= 0 || numSamples > e_.maxSamplesPerCall()) return false;
         const size_t n = static_cast<size_t>(e_.channels()) * numSamples;
         if (input) std::memcpy(pending_.data(), input, n * sizeof(double));
         else std::memset(pending_.data(), 0, n * sizeof(double));
-        if (cpq_conv_process(e_.get(), pending_.data(), result_.data(), numSamples) == CPQ_OK) have_ = numSamples;
+        status_ = cpq_conv_process(e_.get(), pending_.data(), result_.data(), numSamples);
+        if (status_ == CPQ_OK) have_ = numSamples;
+        return status_ == CPQ_OK;
     }
 
-    // Get: returns samples written per channel; output zero-filled when nothing is available (reference :1560-1562)
+    // Get: the block of the preceding Add.  Returns the samples layer 0's ring delivered (the smallest count over the
+    // streams; short reads are zero-filled at the end of every chunk exactly as ringRead does, :1376-1402), 0 and a zeroed
+    // output when nothing is available (reference :1560-1562)
     int Get(double* output, int numSamples)
     {
         if (numSamples <= 0) return 0;
@@ -120,8 +138,16 @@ public:
         }
         if (output) std::memcpy(output, result_.data(), n * sizeof(double));
         have_ = 0;
-        return numSamples;
+        int got = numSamples;
+        for (int s = 0; s < e_.streams(); ++s) {
+            const int g = cpq_conv_last_got(e_.get(), s);
+            if (g >= 0 && g < got) got = g;
+        }
+        return got;
     }
+
+    int lastStatus() const noexcept { return status_; }
+    const char* lastError() const noexcept { return e_.lastError(); }
 
     void Reset() { cpq_conv_reset(e_.get()); }
     bool isReady() const noexcept { return cpq_conv_is_ready(e_.get()) != 0; }
@@ -130,7 +156,7 @@ public:
 private:
     Engine& e_;
     std::vector<double> pending_, result_;
-    int have_ = 0;
+    int have_ = 0, status_ = CPQ_OK;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -138,7 +164,11 @@ class BatchedProcessor {
 public:
     explicit BatchedProcessor(Engine& e) : e_(e), scratch_(static_cast<size_t>(e.channels()) * e.maxSamplesPerCall()) {}
 
-    void prepareToPlay(double sampleRate, int samplesPerBlock) { cpq_engine_prepare(e_.get(), sampleRate, samplesPerBlock); }
+    bool prepareToPlay(double sampleRate, int samplesPerBlock)
+    {
+        status_ = cpq_engine_prepare(e_.get(), sampleRate, samplesPerBlock);
+        return status_ == CPQ_OK;
+    }
 
     bool loadImpulse(int stream, const double* irL, const double* irR, int irLen, double scale = 1.0)
     {
@@ -178,17 +208,24 @@ public:
         cpq_engine_set_gains(e_.get(), stream, convolverInputTrimGain, outputMakeupGain);
     }
 
-    // in-place on the planar block, like ConvolverProcessor::process / EQProcessor::process
-    void process(AudioBlockBatch& block)
+    // in-place on the planar block, like ConvolverProcessor::process / EQProcessor::process; a refused or failed call
+    // clears the block (fail closed) AND returns false with the reason in lastStatus() / lastError()
+    bool process(AudioBlockBatch& block)
     {
         const int n = block.numSamples;
-        if (n <= 0 || block.numChannels != e_.channels() || n > e_.maxSamplesPerCall()) { clear(block); return; }
+        status_ = CPQ_ERR_INVALID_ARG;
+        if (n <= 0 || block.numChannels != e_.channels() || n > e_.maxSamplesPerCall()) { clear(block); return false; }
         for (int c = 0; c < block.numChannels; ++c)
             std::memcpy(scratch_.data() + static_cast<size_t>(c) * n, block.channels[c], sizeof(double) * n);
-        if (cpq_engine_process_block(e_.get(), scratch_.data(), scratch_.data(), n) != CPQ_OK) { clear(block); return; }
+        status_ = cpq_engine_process_block(e_.get(), scratch_.data(), scratch_.data(), n);
+        if (status_ != CPQ_OK) { clear(block); return false; }
         for (int c = 0; c < block.numChannels; ++c)
             std::memcpy(block.channels[c], scratch_.data() + static_cast<size_t>(c) * n, sizeof(double) * n);
+        return true;
     }
+
+    int lastStatus() const noexcept { return status_; }
+    const char* lastError() const noexcept { return e_.lastError(); }
 
 private:
     static void clear(AudioBlockBatch& b)
@@ -197,6 +234,7 @@ private:
     }
     Engine& e_;
     std::vector<double> scratch_;
+    int status_ = CPQ_OK;
 };
 
 }  // namespace cpq

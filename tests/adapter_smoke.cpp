@@ -36,6 +36,34 @@ int main(int argc, char** argv)
             }
         std::printf("adapter max abs err %.3e\n", worst);
         if (!(worst < 1e-13)) return 5;
+        // a call the whole-block engine cannot take is refused out loud, not answered with silent zeros
+        if (conv.Add(in.data(), 480) || conv.lastStatus() == CPQ_OK || conv.Get(out.data(), 480) != 0) return 10;
+        {
+            // a 480-sample device block: the adapter picks CPQ_CALLS_ANY; the first Get has nothing yet (the reference's
+            // ring is empty until 512 samples have come in), the second delivers the convolution's first 480 samples
+            cpq::Engine eng480(S, 480, L, 1);
+            cpq::BatchedConvolver c480(eng480);
+            if (!eng480.acceptsAnyCallSize() || !c480.SetImpulse(CPQ_ALL_STREAMS, ir.data(), ir.data(), L, 480)) return 11;
+            if (c480.getLatency() != 512) return 12;
+            std::vector<double> i2(static_cast<size_t>(2 * S) * 480), o2(i2.size());
+            double w2 = 0.0;
+            for (int call = 0; call < 6; ++call) {
+                for (int c = 0; c < 2 * S; ++c)
+                    for (int i = 0; i < 480; ++i) i2[c * 480 + i] = x[static_cast<size_t>(c) * N + call * 480 + i];
+                if (!c480.Add(i2.data(), 480)) return 13;
+                const int got = c480.Get(o2.data(), 480);
+                if (got != (call == 0 ? 0 : 480)) return 14;
+                for (int c = 0; c < 2 * S && call > 0; ++c)
+                    for (int i = 0; i < 480; i += 37) {
+                        const int nn = (call - 1) * 480 + i;        // one call of latency: output sample nn of the convolution
+                        long double acc = 0;
+                        for (int j = 0; j < L && j <= nn; ++j) acc += (long double)ir[j] * x[static_cast<size_t>(c) * N + nn - j];
+                        w2 = std::fmax(w2, std::fabs((double)acc - o2[c * 480 + i]));
+                    }
+            }
+            std::printf("adapter, 480-sample calls: max abs err %.3e\n", w2);
+            if (!(w2 < 1e-13)) return 15;
+        }
         if (argc > 1) {
             // processor-level adapter: IR file -> loader steps -> engine; EQ bypassed before the first block = pass-through
             // of the EQ stage, so the block is wet * wetG + delayed dry * dryG of the file's IR: finite, not silent

@@ -1,0 +1,195 @@
+"""GPU parity for CPQ_CALLS_ANY: any call quantum and ragged calls.
+
+The reference accepts any blockSize and any n: `Add` accumulates input per layer until a partition of nextPow2(max(bs, 64))
+(x m, x m^2) samples is full (src/MKLNonUniformConvolver.cpp:1431-1446), `Get` reads layer 0 through the output ring and
+zero-fills a short read at the end (:1376-1402), the tail layers follow the distributed MAC (:1497-1545) and the delay-line
+reader per call (:1653-1688); StereoConvolver::process is Add + Get per callQuantum chunk (Runtime.cpp:659-682, 1159-1184).
+The oracle restates exactly that (orc_nuc_add / orc_nuc_get); the HIP path must reproduce it chunk for chunk -- including
+the start-up zeros and the zero gaps the reference produces at quanta like 441.  Tolerance 1e-13 RMS (north_star 1e-12);
+samples the reference zero-fills must be exactly zero.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a))))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import convopeq_amd
+    return convopeq_amd
+
+
+def make_inputs(O, stream_ids, n):
+    x = np.empty((2 * len(stream_ids), n))
+    for i, s in enumerate(stream_ids):
+        for ch in range(2):
+            x[2 * i + ch] = O.gen_pcm(n, stream=s, channel=ch)
+    return x
+
+
+def oracle_calls(O, ir, x, quantum, call_sizes, direct=False, spec=None, scale=1.0):
+    """Add + Get per chunk of `quantum` samples inside every call, as StereoConvolver::process is driven."""
+    nuc = O.Nuc()
+    assert nuc.set_impulse(ir, quantum, scale=scale, direct=direct, spec=spec)
+    y = np.empty_like(x)
+    got_all = []
+    pos = 0
+    for n in call_sizes:
+        o = 0
+        while o < n:
+            m = min(quantum, n - o)
+            nuc.add(x[pos + o:pos + o + m])
+            out, got = nuc.get(m)
+            y[pos + o:pos + o + m] = out
+            got_all.append(got)
+            o += m
+        pos += n
+    nuc.close()
+    return y[:pos], got_all
+
+
+def run_engine(eng, x, call_sizes):
+    ys, pos = [], 0
+    for n in call_sizes:
+        ys.append(eng.conv_process(np.ascontiguousarray(x[:, pos:pos + n])))
+        pos += n
+    return np.concatenate(ys, axis=1)
+
+
+def check(y, ref, tol=1e-13):
+    err = rms(y - ref)
+    assert err <= tol, err
+    zeros = ref == 0.0
+    assert np.array_equal(y[zeros], ref[zeros])           # zero-filled samples stay exactly zero
+    return err
+
+
+@pytest.mark.parametrize("taps", [4096, 131072])
+@pytest.mark.parametrize("quantum", [480, 441, 96, 1000])
+def test_arbitrary_call_quantum(amd, oracle, quantum, taps):
+    """Device block sizes that are not powers of two: 480 / 441 (10 ms at 48 / 44.1 kHz), 96, 1000."""
+    O = oracle
+    S = 2
+    blocks_per_call = 16 if quantum >= 400 else 64
+    calls = 6 if taps == 131072 else 3
+    call_sizes = [blocks_per_call * quantum] * calls
+    n = sum(call_sizes)
+    irs = [O.gen_ir(taps, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, range(S), n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=blocks_per_call, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    assert eng.is_ready()
+    assert eng.latency() == max(64, 1 << (quantum - 1).bit_length())       # getLatency() = layer-0 partition
+    y = run_engine(eng, x, call_sizes)
+    worst = 0.0
+    for c in range(2 * S):
+        ref, _ = oracle_calls(O, irs[c], x[c], quantum, call_sizes)
+        worst = max(worst, check(y[c], ref))
+        assert rms(ref) > 1e-3
+    print(f"quantum {quantum}, {taps} taps: worst rms err {worst:.3e}")
+    # Reset() starts over: the same calls give the same output
+    eng.conv_reset()
+    y2 = run_engine(eng, x, call_sizes[:1])
+    assert np.array_equal(y2, y[:, :call_sizes[0]])
+    eng.close()
+
+
+@pytest.mark.parametrize("quantum,taps", [(512, 20000), (256, 131072), (64, 6000)])
+def test_ragged_call_sequence(amd, oracle, quantum, taps):
+    """Calls of 1 ... 700 samples in a seeded random order (cut into quantum-sized chunks, the last one shorter)."""
+    O = oracle
+    rng = np.random.default_rng(1234 + quantum)
+    call_sizes = [int(v) for v in rng.integers(1, 701, size=90)] + [1, 2, 700, 699, quantum, quantum - 1, quantum + 1]
+    n = sum(call_sizes)
+    S = 2
+    irs = [O.gen_ir(taps, stream=5 + c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, range(5, 5 + S), n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=(700 + quantum - 1) // quantum,
+                            call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    y = run_engine(eng, x, call_sizes)
+    worst = 0.0
+    for c in range(2 * S):
+        ref, _ = oracle_calls(O, irs[c], x[c], quantum, call_sizes)
+        worst = max(worst, check(y[c], ref))
+    print(f"ragged calls, quantum {quantum}, {taps} taps: worst rms err {worst:.3e}")
+    eng.close()
+
+
+def test_single_sample_calls_and_direct_head(amd, oracle):
+    """n = 1 ... 5 samples per call with the direct head on (the head runs per chunk, :1169-1232, added before the tails)."""
+    O = oracle
+    quantum, taps = 128, 9000
+    call_sizes = [1, 2, 3, 4, 5] * 120
+    n = sum(call_sizes)
+    irs = [O.gen_ir(taps, stream=9, channel=ch) for ch in range(2)]
+    x = make_inputs(O, [9], n)
+    eng = amd.BatchedEngine(1, block_size=quantum, max_ir_len=taps, max_blocks_per_call=1, call_mode=amd.CPQ_CALLS_ANY)
+    eng.set_impulse(0, irs[0], irs[1], scale=0.7, direct_head=True)
+    y = run_engine(eng, x, call_sizes)
+    for c in range(2):
+        ref, _ = oracle_calls(O, irs[c], x[c], quantum, call_sizes, direct=True, scale=0.7)
+        assert rms(y[c] - ref) <= 1e-13
+    eng.close()
+
+
+def test_streams_with_their_own_plans(amd, oracle):
+    """One NUC per channel with its own IR length and FilterSpec (src/ConvolverProcessor.h:741-814): four streams, four
+    layer plans -- short single-layer IR, two-layer, three-layer, and a FilterSpec plan whose tail reader is time-varying
+    (air absorption mode: layer 0 ends below the tail partition) -- in one engine, ragged calls, shared call sizes."""
+    O = oracle
+    quantum = 512
+    lens = [3000, 40000, 131072, 60000]
+    specs = [None, None, None, O.FilterSpec.defaults(tailMode=0, applySpectrumFilter=1, hcMode=0, lcMode=1)]
+    S = len(lens)
+    call_sizes = [512 * 8, 700, 512 * 16, 333, 512 * 12] * 3
+    n = sum(call_sizes)
+    x = make_inputs(O, range(20, 20 + S), n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=max(lens), max_blocks_per_call=16, call_mode=amd.CPQ_CALLS_ANY)
+    irs = []
+    for s in range(S):
+        irs.append([O.gen_ir(lens[s], stream=20 + s, channel=ch) for ch in range(2)])
+        spec = None
+        if specs[s] is not None:
+            spec = amd.FilterSpec.defaults(tail_mode=0, hc_mode=0, lc_mode=1)
+        eng.set_impulse(s, irs[s][0], irs[s][1], spec=spec)
+    y = run_engine(eng, x, call_sizes)
+    for s in range(S):
+        for ch in range(2):
+            ref, _ = oracle_calls(O, irs[s][ch], x[2 * s + ch], quantum, call_sizes, spec=specs[s])
+            err = check(y[2 * s + ch], ref)
+            print(f"stream {s} ({lens[s]} taps{', FilterSpec' if specs[s] is not None else ''}) ch {ch}: rms err {err:.3e}")
+    # a stream reloaded while the others keep playing starts from silence like a new NUC; the others do not notice
+    new_ir = [O.gen_ir(10000, stream=77, channel=ch) for ch in range(2)]
+    eng.set_impulse(1, new_ir[0], new_ir[1])
+    tail_calls = [512 * 4, 123, 512 * 6]
+    x2 = make_inputs(O, range(20, 20 + S), n + sum(tail_calls))[:, n:]
+    y2 = run_engine(eng, x2, tail_calls)
+    for ch in range(2):
+        ref, _ = oracle_calls(O, new_ir[ch], x2[2 + ch], quantum, tail_calls)
+        assert rms(y2[2 + ch] - ref) <= 1e-13
+    for s in (0, 2, 3):
+        for ch in range(2):
+            xx = np.concatenate([x[2 * s + ch], x2[2 * s + ch]])
+            ref, _ = oracle_calls(O, irs[s][ch], xx, quantum, call_sizes + tail_calls, spec=specs[s])
+            assert rms(y2[2 * s + ch] - ref[n:]) <= 1e-13
+    eng.close()
+
+
+def test_whole_block_engine_refuses_ragged_calls_loudly(amd, oracle):
+    O = oracle
+    eng = amd.BatchedEngine(1, block_size=512, max_ir_len=4096, max_blocks_per_call=4)
+    eng.set_impulse(0, O.gen_ir(4096), O.gen_ir(4096, channel=1))
+    with pytest.raises(amd.CpqError) as ei:
+        eng.conv_process(np.zeros((2, 480)))
+    assert "CPQ_CALLS_ANY" in str(ei.value)
+    with pytest.raises(amd.CpqError):
+        amd.BatchedEngine(1, block_size=480, max_ir_len=4096, max_blocks_per_call=4)        # non-power-of-two needs CPQ_CALLS_ANY
+    eng.close()

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(amd):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_capi.SYMBOLS) == declared, "python binding table out of sync with the header"
-    assert lib.cpq_abi_version() == 1
+    assert lib.cpq_abi_version() == 2
 
 
 def test_library_contains_gfx950_code_object():
