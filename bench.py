@@ -417,8 +417,12 @@ def parse_args(argv=None):
                          f"{STREAMS_CONFIG5_SHARE} at --gpus N>1 = the per-GPU share of configs[4])")
     ap.add_argument("--ir-len", type=int, default=131072)
     ap.add_argument("--block", type=int, default=512, help="diagnostic: block size")
-    ap.add_argument("--partition", type=int, default=0, help="internal FFT partition size (0 = block size)")
-    ap.add_argument("--blocks-per-call", type=int, default=64)
+    ap.add_argument("--partition", type=int, default=-1,
+                    help="internal FFT partition size; 0 = the block size; default: 4096 when the block is 512 and the call is "
+                         "whole 4096-sample partitions (the throughput path: profiles/r02b_sweep_partition_x_blocks_per_call.txt), else 0")
+    ap.add_argument("--blocks-per-call", type=int, default=1024,
+                    help="blocks of --block samples per process() call (default 1024 = 524288 samples, the reference's largest "
+                         "process() block, ConvolverProcessor.Runtime.cpp:609)")
     ap.add_argument("--mac-tile", type=int, default=0)
     ap.add_argument("--no-eq", action="store_true")
     ap.add_argument("--eq-only", action="store_true", help="diagnostic: time the EQ kernel alone")
@@ -442,6 +446,11 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.streams <= 0:
         args.streams = STREAMS_CONFIG2 if args.gpus <= 1 else STREAMS_CONFIG5_SHARE
+    if args.partition < 0:
+        ok = (args.block == 512 and (args.blocks_per_call * args.block) % 4096 == 0 and args.schedule == "uniform")
+        args.partition = 4096 if ok else 0
+    if args.partition == args.block:
+        args.partition = 0
     return args
 
 
@@ -547,7 +556,7 @@ def main():
 
     # parity of the timed engine (every rank checks its own shard; squared errors are summed over ranks)
     parity = None
-    if not (args.no_parity or args.eq_only or args.host_buffers or args.partition or args.pcm_scale != 1.0) and B == 512:
+    if not (args.no_parity or args.eq_only or args.host_buffers or args.pcm_scale != 1.0) and B == 512:
         parity = parity_of_timed_engine(amd, eng, d_in, d_out, torch, S, n, L, use_eq, args.saturation, args.eq_preset,
                                         ids, args.exact, args.schedule == "nuc")
 
@@ -582,12 +591,14 @@ def main():
             "k_svf_cascade": n_ch * n * 16,
             "k_convproc_mix": n_ch * n * 16 * max(0, len(layers) - 1),      # delay-line write / read-add of the tail layers
         }
-        # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF ~35 fp64 instructions per band-sample
+        # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF: the reference's band kernel is 17 flops of linear
+        # recurrence (10 instructions, 7 of them FMAs) + 16 of output stage (fastTanh blend with one division counted as one,
+        # the guards and clamps) = 33 flops per band-sample
         # the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex MAC (Gauss), the tile kernels 4
         mac_flop = lambda nb: 6.0 if nb >= 48 else 8.0
         n_bands = 20 if args.eq_preset == "bench" else len(load_autoeq_preset()["filters"])
         alg_flops = {"k_fdl_mac": sum(mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb in layers),
-                     "k_svf_cascade_tp": 2.0 * 35 * n_bands * n_ch * n}
+                     "k_svf_cascade_tp": 33.0 * n_bands * n_ch * n}
         per_kernel = {}
         for name, (cnt, ms) in prof.items():
             if cnt == 0:
@@ -628,8 +639,12 @@ def main():
             roof = {"kernel": dominant, "bound": "fp64_vector", "achieved": dk.get("fp64_tflops"),
                     "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round((dk.get("fp64_tflops") or 0.0) / FP64_VECTOR_PEAK_TFLOPS, 4),
-                    "note": "k_svf_cascade_tp is fp64-VALU issue bound, not HBM bound: 20 sequential nonlinear bands per "
-                            "sample (~35 fp64 instructions per band-sample) against 16 B of HBM traffic per sample"}
+                    "note": "k_svf_cascade_tp is fp64-issue bound, not HBM bound: 20 sequential nonlinear bands per sample, "
+                            "33 flops per band-sample in the reference's arithmetic against 16 B of HBM traffic per sample; fp64 "
+                            "MFMA and VALU share one datapath on gfx950 (profiles/r02a_ubench_fp64_valu_mfma_coexec.txt)",
+                    "hbm_kernel": {"kernel": "k_fdl_mac", "achieved": per_kernel["k_fdl_mac"]["achieved_gbs"] if "k_fdl_mac" in per_kernel else None,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(per_kernel["k_fdl_mac"]["achieved_gbs"] / HBM_PEAK_GBS, 4) if "k_fdl_mac" in per_kernel else None}}
         else:
             roof = {"kernel": dominant, "bound": "hbm" if flop_per_byte < ridge else "fp64_vector",
                     "achieved": dk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -504,6 +504,161 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// P = 4096 (8192-point real frames), the partition of the time-batched throughput path: 4096 = 8^4, so with 512 threads
+// thread j owns points j + 512 q of every radix-8 stage's input AND of the last stage's output.  That removes two of the
+// LDS round trips of the generic workgroup kernels above (the frame goes from global memory straight into the first
+// butterflies, the inverse's last butterflies straight to global memory), and a workgroup walks consecutive frames of one
+// channel: the loads of frame t + 1 are issued before the butterflies of frame t (the kernels are pure streaming kernels:
+// load latency was exposed once per frame), and the forward transform reads every input block ONCE -- the second half of
+// frame t is the first half of frame t + 1, in the same registers.
+constexpr int kP4 = 4096;
+
+template <bool INV>
+__device__ __forceinline__ void p4_twiddle(double2 (&v)[8], const double2* __restrict__ twM, int k, int tstep)
+{
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], twM[q * k * tstep]);
+}
+
+// One exchange through LDS: thread j leaves its 8 values at padded elements wr + q wrStep and takes the 8 at rd + q rdStep
+// (every index pattern of the four radix-8 stages is base + q * constant in the padded buffer: wgp(i + 8 m) = wgp(i) + 9 m).
+// Measured and not kept: the real and imaginary parts through a half-size buffer one after the other (36 KB: three or four
+// workgroups per CU at 80 / 64 registers) -- twice the barriers and the spills cost more than the occupancy gave
+// (forward 1.19 / 1.29 ms against 1.04 ms per 512-block call at 256 streams).
+__device__ __forceinline__ void p4_exchange(double2 (&v)[8], double2* lds, int wr, int wrStep, int rd, int rdStep)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lds[wr + q * wrStep] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = lds[rd + q * rdStep];
+    __syncthreads();
+}
+
+// the three LDS exchanges between the four radix-8 stages; in: v = points j + 512 q, out: v = Z[j + 512 q].
+// A rolled loop over the stages: fully unrolled, the compiler hoists every stage's twiddle loads and the kernel no longer
+// fits the register budget of two (let alone three or four) workgroups per CU.
+template <bool INV>
+__device__ __forceinline__ void p4_cfft(double2 (&v)[8], double2* lds, const double2* __restrict__ twM)
+{
+    const int j = threadIdx.x;
+    const int rd = wgp(j);                                      // wgp(j + 512 q) = wgp(j) + 576 q
+#pragma unroll 1
+    for (int st = 0; st < 4; ++st) {
+        const int ns = 1 << (3 * st);
+        const int k = j & (ns - 1);
+        if (st > 0) p4_twiddle<INV>(v, twM, k, kP4 / (8 * ns));
+        dft8<INV>(v);
+        if (st < 3) p4_exchange(v, lds, wgp(((j - k) << 3) + k), ns + (ns >> 3), rd, 576);     // wgp(o + q ns) = wgp(o) + q (ns + ns / 8), ns >= 8; ns = 1: 9 j + q
+    }
+}
+
+// A workgroup walks consecutive frames of one channel and keeps the second half of frame t (= first half of frame t + 1)
+// in registers, so every input block is read once.  Two workgroups per CU (72 KB of LDS each).
+__global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __restrict__ in, int64_t chStride,
+                                                          const double* __restrict__ histOld,
+                                                          double* __restrict__ histNew, double2* __restrict__ X,
+                                                          double2* __restrict__ XDN, FftTables tw, int T, int split,
+                                                          int head, int ringMask)
+{
+    extern __shared__ double2 dyn[];
+    const int j = threadIdx.x;
+    const int c = blockIdx.x / split;
+    const int part = blockIdx.x - c * split;
+    const int per = (T + split - 1) / split;
+    const int t0 = part * per, t1 = min(T, t0 + per);
+    if (t0 >= t1) return;
+    const double* base = in + (int64_t)c * chStride;
+    // frame t = [block t-1 | block t]; thread j holds complex points n = j + 512 q: n < 2048 from the previous block
+    double2 keep[4];
+    {
+        const double* prev = (t0 > 0) ? (base + (int64_t)(t0 - 1) * kP4) : (histOld + (int64_t)c * kP4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] = *reinterpret_cast<const double2*>(prev + 2 * (j + 512 * q));
+    }
+    for (int t = t0; t < t1; ++t) {
+        double2 v[8];
+        const double* cur = base + (int64_t)t * kP4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = keep[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[4 + q] = *reinterpret_cast<const double2*>(cur + 2 * (j + 512 * q));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] = v[4 + q];
+        if (t == T - 1) {       // overlap history for the next call (prevInputBuf, NUC.cpp:1258)
+            double* hn = histNew + (int64_t)c * kP4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(hn + 2 * (j + 512 * q)) = v[4 + q];
+        }
+        p4_cfft<false>(v, dyn, tw.tw512);
+        // real-FFT split: Z[k] with Z[4096 - k], one more trip through LDS; wgp(4096 - j - 512 q) = wgp(4096 - j) - 576 q
+        const int slot = (head + t) & ringMask;
+        const int64_t row = (int64_t)c * (ringMask + 1) + slot;
+        double2* spec = X + row * kP4;
+        const int wr = wgp(j);
+        const int rdm = wgp(kP4 - j);
+        const int rd0 = wgp((kP4 - j) & (kP4 - 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = j + 512 * q;
+            const double2 zk = v[q];
+            const double2 zm = dyn[q == 0 ? rd0 : rdm - 576 * q];
+            const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+            const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+            const double2 o = make_double2(d.y, -d.x);
+            const double2 w = tw.tw1024[k];
+            double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
+            if (k == 0) {
+                xk = make_double2(zk.x + zk.y, zk.x - zk.y);
+                XDN[row] = xk;
+            }
+            __builtin_nontemporal_store(xk.x, reinterpret_cast<double*>(spec + k));
+            __builtin_nontemporal_store(xk.y, reinterpret_cast<double*>(spec + k) + 1);
+        }
+        __syncthreads();                    // the next frame's first exchange reuses the buffer
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __restrict__ Y, double* __restrict__ out,
+                                                              int64_t chStride, FftTables tw, int T, int split)
+{
+    extern __shared__ double2 dyn[];
+    const int j = threadIdx.x;
+    const int c = blockIdx.x / split;
+    const int part = blockIdx.x - c * split;
+    const int per = (T + split - 1) / split;
+    const int t0 = part * per, t1 = min(T, t0 + per);
+    const double2* ybase = Y + (int64_t)c * T * kP4;
+    for (int t = t0; t < t1; ++t) {
+        double2 v[8];
+        const double2* y = ybase + (int64_t)t * kP4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = j + 512 * q;
+            const double2 a = y[k];
+            const double2 b = y[(kP4 - k) & (kP4 - 1)];
+            const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
+            const double2 d = make_double2(0.5 * (a.x - b.x), 0.5 * (a.y + b.y));
+            const double2 w = tw.tw1024[k];
+            const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
+            double2 z = make_double2(e.x - o.y, e.y + o.x);
+            if (k == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
+            v[q] = z;
+        }
+        p4_cfft<true>(v, dyn, tw.tw512);
+        // second half of the 8192-sample frame: x[n], n = j + 512 q, q = 4..7 (NUC.cpp:1332)
+        double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
+        constexpr double s = 1.0 / (double)kP4;
+#pragma unroll
+        for (int q = 4; q < 8; ++q)
+            *reinterpret_cast<double2*>(o + 2 * (j + 512 * (q - 4))) = make_double2(v[q].x * s, v[q].y * s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Partitions above 4096 samples (P = 8192, 16384, 32768: tail layers of a FilterSpec plan run at the reference's own
 // partition size): four-step FFT of the M = P complex points z[n] = x[2n] + i x[2n+1], M = M1 * 512, n = n1 * 512 + n2:
 //   column pass: for every column n2 the M1-point FFT over n1, times W_M^(n2 k1)          -> scratch A[k1][n2]
@@ -771,6 +926,14 @@ void allowLargeLds(K kernel, size_t bytes)
 }  // namespace
 
 static size_t wgLdsBytes(int P) { return (size_t)(P + (P >> 3)) * sizeof(double2); }   // padded buffer of the *_wg kernels
+// frames of one channel are walked by `split` workgroups (contiguous ranges): one per channel when the channels alone
+// fill the chip (2 workgroups per CU), more for few channels
+static int p4Split(int nCh, int T)
+{
+    int split = 1;
+    while (nCh * split < 2048 && split * 2 <= T) split *= 2;
+    return split;
+}
 static int genericThreads(int P) { return P / 2 < 64 ? 64 : (P / 2 > 256 ? 256 : P / 2); }
 
 void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride, const double* histOld,
@@ -788,7 +951,12 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
                            tw, T, head, ringSlots - 1);
-    else if (P >= 1024) {
+    else if (P == kP4) {
+        const int split = p4Split(nCh, T);
+        allowLargeLds(k_rfft_fwd_ols_p4, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_fwd_ols_p4, dim3(nCh * split), dim3(512), wgLdsBytes(P), stream, in, chStride, histOld,
+                           histNew, X, XDN, tw, T, split, head, ringSlots - 1);
+    } else if (P >= 1024) {
         allowLargeLds(k_rfft_fwd_ols_wg, wgLdsBytes(P));
         hipLaunchKernelGGL(k_rfft_fwd_ols_wg, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, in, chStride,
                            histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
@@ -836,7 +1004,12 @@ void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int6
     }
     if (P == kP)
         hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
-    else if (P >= 1024) {
+    else if (P == kP4) {
+        const int split = p4Split(nCh, T);
+        allowLargeLds(k_rfft_inv_ols_p4, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_inv_ols_p4, dim3(nCh * split), dim3(512), wgLdsBytes(P), stream, Y, out, chStride, tw, T,
+                           split);
+    } else if (P >= 1024) {
         allowLargeLds(k_rfft_inv_ols_wg, wgLdsBytes(P));
         hipLaunchKernelGGL(k_rfft_inv_ols_wg, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, Y, out, chStride,
                            tw, P, T);

@@ -36,12 +36,12 @@ def _eq_params(amd, O, sat=0.2):
     return pa, po
 
 
-def _run_fullsize(amd, O, S, L, T, use_eq, schedule, calls=2):
+def _run_fullsize(amd, O, S, L, T, use_eq, schedule, calls=2, partition=0):
     n = T * B
     twin_a, twin_b, twin_id = 3, S - 5, 7777            # two far-apart streams fed the IR + PCM of virtual stream 7777
     ids = list(range(S))
     ids[twin_a] = ids[twin_b] = twin_id
-    eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T, schedule=schedule)
+    eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T, schedule=schedule, partition_size=partition)
     try:
         for s in range(S):
             eng.set_impulse(s, O.gen_ir(L, stream=ids[s], channel=0), O.gen_ir(L, stream=ids[s], channel=1))
@@ -93,6 +93,12 @@ def test_config2_at_benchmark_size(amd, oracle):
     """BASELINE.json configs[1] exactly as bench.py runs it: 256 streams, 131072 taps, 64 blocks per call, conv + EQ."""
     worst = _run_fullsize(amd, oracle, 256, 131072, 64, True, amd.CPQ_SCHED_UNIFORM)
     print("config 2 full size: worst rms err", worst)
+
+
+def test_config2_throughput_path_at_benchmark_size(amd, oracle):
+    """configs[1] on the time-batched throughput path: FFT partition 4096, 512 blocks (262144 samples) per call."""
+    worst = _run_fullsize(amd, oracle, 256, 131072, 512, True, amd.CPQ_SCHED_UNIFORM, partition=4096)
+    print("config 2 full size, P = 4096, 512 blocks per call: worst rms err", worst)
 
 
 def test_config2_convolver_only_at_benchmark_size(amd, oracle):

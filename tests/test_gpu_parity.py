@@ -83,6 +83,31 @@ def test_long_ir_reference_semantics(amd, oracle, blocks_per_call, tile):
     eng.close()
 
 
+@pytest.mark.parametrize("partition,blocks_per_call,tile", [(1024, 16, 0), (2048, 32, 0), (4096, 8, 0), (4096, 64, 0), (4096, 512, 0),
+                                                           (4096, 128, 16), (4096, 64, 4)])
+def test_larger_internal_partition(amd, oracle, partition, blocks_per_call, tile):
+    """cpq_engine_desc.partition_size: the FFT partition P exceeds the caller's block (time-batched calls of whole
+    partitions); h_eff is still the one the reference derives for the 512-sample block, so the output is the oracle's
+    Add/Get emulation at block 512.  P = 4096 is the throughput path of bench.py (persistent 4096-point FFT kernels)."""
+    O = oracle
+    S = 2
+    irs = [O.gen_ir(131072, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    n_call = blocks_per_call * B
+    calls = max(2, (336 * B) // n_call)
+    x = make_inputs(O, S, calls * n_call)
+    ref = oracle_conv(O, irs, x)
+    eng = amd.BatchedEngine(S, max_ir_len=131072, max_blocks_per_call=blocks_per_call, partition_size=partition, mac_tile=tile)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    y = np.concatenate([eng.conv_process(x[:, o:o + n_call]) for o in range(0, calls * n_call, n_call)], axis=1)
+    err = rms(y - ref)
+    print(f"P={partition} T={blocks_per_call} tile={tile}: rms err {err:.3e}")
+    assert err <= 1e-13
+    with pytest.raises(amd.CpqError):            # calls must be whole partitions
+        eng.conv_process(x[:, :B])
+    eng.close()
+
+
 def test_shared_ir_and_exact_semantics(amd, oracle):
     O = oracle
     from scipy.signal import fftconvolve

@@ -105,7 +105,7 @@ def test_bench_self_launches_two_ranks_and_reduces(tmp_path):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--stub-step",
-                        "--steps", "4", "--warmup", "1", "--streams", "8"], env=env, capture_output=True, text=True, timeout=300)
+                        "--steps", "4", "--warmup", "1", "--streams", "8", "--blocks-per-call", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                              # rank 0 only
