@@ -482,7 +482,7 @@ static int enqueueBoth(cpq_engine* e, const double* a, double* b, int n)
             if (pass == e->ofPass[s] || !e->ofModesSet[s]) continue;
             int flags[2 * kBands] = {};
             if (!pass) for (int ch = 0; ch < 2; ++ch) for (int k = 0; k < 3; ++k) flags[ch * kBands + k] = 1 | 4;
-            CPQ_HIP(e, hipMemcpyAsync(e->ofFlags + (size_t)2 * s * kBands, flags, sizeof(flags), hipMemcpyHostToDevice, e->stream));
+            { const int rcUp = stageUpload(e, e->ofFlags + (size_t)2 * s * kBands, flags, sizeof(flags)); if (rcUp != CPQ_OK) return rcUp; }
             e->ofPass[s] = pass;
         }
         if (anyActive) rc = enqueueOutFilter(e, b, b, n);

@@ -99,8 +99,8 @@ int setEqStreamMode(cpq_engine* e, int s, int mode)
     if (mode == 2) {
         int zeros[2 * kBands] = {};
         const double sg[4] = { 0.0, 1.0, 0.0, 1.0 };
-        CPQ_HIP(e, hipMemcpyAsync(e->svfFlags + c0 * kBands, zeros, sizeof(zeros), hipMemcpyHostToDevice, e->stream));
-        CPQ_HIP(e, hipMemcpyAsync(e->svfSatGain + c0 * 2, sg, sizeof(sg), hipMemcpyHostToDevice, e->stream));
+        { const int rcUp = stageUpload(e, e->svfFlags + c0 * kBands, zeros, sizeof(zeros)); if (rcUp != CPQ_OK) return rcUp; }
+        { const int rcUp = stageUpload(e, e->svfSatGain + c0 * 2, sg, sizeof(sg)); if (rcUp != CPQ_OK) return rcUp; }
         e->eqTpSafe[s] = 1;
         e->eqMidSide[s] = 0;
         e->gainRamp[s].devUnity = true;
@@ -109,18 +109,17 @@ int setEqStreamMode(cpq_engine* e, int s, int mode)
         EqDesign d;
         designEqStream(e, e->eqParamsHost[s], mode == 1, d);
         double sg[4] = { d.satGain[0], d.satGain[1], d.satGain[0], d.satGain[1] };
-        CPQ_HIP(e, hipMemcpyAsync(e->svfCoef + c0 * kBands * 6, d.coef, sizeof(d.coef), hipMemcpyHostToDevice, e->stream));
-        CPQ_HIP(e, hipMemcpyAsync(e->svfFlags + c0 * kBands, d.flags, sizeof(d.flags), hipMemcpyHostToDevice, e->stream));
-        CPQ_HIP(e, hipMemcpyAsync(e->svfSatGain + c0 * 2, sg, sizeof(sg), hipMemcpyHostToDevice, e->stream));
-        CPQ_HIP(e, hipMemcpyAsync(e->svfTp + (size_t)s * d.tp.size(), d.tp.data(), d.tp.size() * sizeof(double),
-                                  hipMemcpyHostToDevice, e->stream));
+        { const int rcUp = stageUpload(e, e->svfCoef + c0 * kBands * 6, d.coef, sizeof(d.coef)); if (rcUp != CPQ_OK) return rcUp; }
+        { const int rcUp = stageUpload(e, e->svfFlags + c0 * kBands, d.flags, sizeof(d.flags)); if (rcUp != CPQ_OK) return rcUp; }
+        { const int rcUp = stageUpload(e, e->svfSatGain + c0 * 2, sg, sizeof(sg)); if (rcUp != CPQ_OK) return rcUp; }
+        { const int rcUp = stageUpload(e, e->svfTp + (size_t)s * d.tp.size(), d.tp.data(), d.tp.size() * sizeof(double)); if (rcUp != CPQ_OK) return rcUp; }
         e->eqTpSafe[s] = d.tpSafe ? 1 : 0;
         e->eqMidSide[s] = d.midSide ? 1 : 0;
         e->gainRamp[s].devUnity = false;          // the constant gain (or 1.0 with AGC) is on the device again
     }
     if (e->agcOn) {
         const int on = (mode != 2 && e->agcOnHost[s]) ? 1 : 0;
-        CPQ_HIP(e, hipMemcpyAsync(e->agcOn + s, &on, sizeof(int), hipMemcpyHostToDevice, e->stream));
+        { const int rcUp = stageUpload(e, e->agcOn + s, &on, sizeof(int)); if (rcUp != CPQ_OK) return rcUp; }
     }
     bp.mode = mode;
     return CPQ_OK;
@@ -177,7 +176,7 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
             if (needUnity != r.devUnity) {
                 const double g = needUnity ? 1.0 : r.wanted;
                 for (int ch = 0; ch < 2; ++ch)
-                    CPQ_HIP(e, hipMemcpyAsync(e->svfSatGain + (size_t)(2 * s + ch) * 2 + 1, &g, sizeof(double), hipMemcpyHostToDevice, e->stream));
+                    { const int rcUp = stageUpload(e, e->svfSatGain + (size_t)(2 * s + ch) * 2 + 1, &g, sizeof(double)); if (rcUp != CPQ_OK) return rcUp; }
                 r.devUnity = needUnity;
             }
         }
@@ -188,8 +187,8 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
                     hipMalloc((void**)&e->rampGains, sizeof(double) * 2 * S * cbMax) != hipSuccess)
                     return fail(e, CPQ_ERR_OOM, "gain ramp buffers could not be allocated");
             }
-            CPQ_HIP(e, hipMemcpyAsync(e->rampOn, rampOnHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
-            CPQ_HIP(e, hipMemcpyAsync(e->rampGains, rampHost.data(), sizeof(double) * rampHost.size(), hipMemcpyHostToDevice, e->stream));
+            { const int rcUp = stageUpload(e, e->rampOn, rampOnHost.data(), sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
+            { const int rcUp = stageUpload(e, e->rampGains, rampHost.data(), sizeof(double) * rampHost.size()); if (rcUp != CPQ_OK) return rcUp; }
         }
     }
     e->eqProcessed = true;
@@ -387,10 +386,10 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
                 std::memcpy(&gainsHost[(size_t)s * e->blendCap], gains[s].data() + used[s], sizeof(double) * (size_t)lenHost[s]);
                 used[s] += (size_t)lenHost[s];
             }
-            CPQ_HIP(e, hipMemcpyAsync(e->blendOn, onHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
-            CPQ_HIP(e, hipMemcpyAsync(e->blendLen, lenHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
-            CPQ_HIP(e, hipMemcpyAsync(e->blendEnd, endHost.data(), sizeof(double) * S, hipMemcpyHostToDevice, e->stream));
-            CPQ_HIP(e, hipMemcpyAsync(e->blendGains, gainsHost.data(), sizeof(double) * gainsHost.size(), hipMemcpyHostToDevice, e->stream));
+            { const int rcUp = stageUpload(e, e->blendOn, onHost.data(), sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
+            { const int rcUp = stageUpload(e, e->blendLen, lenHost.data(), sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
+            { const int rcUp = stageUpload(e, e->blendEnd, endHost.data(), sizeof(double) * S); if (rcUp != CPQ_OK) return rcUp; }
+            { const int rcUp = stageUpload(e, e->blendGains, gainsHost.data(), sizeof(double) * gainsHost.size()); if (rcUp != CPQ_OK) return rcUp; }
             ProfScope p(e, CPQ_K_MIX);
             cpq::launch_rows_copy(e->stream, dIn, (int64_t)n, off, e->eqDry, (int64_t)nSeg, 0, nSeg, e->nCh);
         }

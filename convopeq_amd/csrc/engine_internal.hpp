@@ -71,13 +71,14 @@ struct PlanGroup {
     int lastGot = 0, lastCall = 0;              // Get()'s return value summed over the chunks of the last call
 };
 
+// pinned staging for the small host -> device tables of a call (chunk schedules, per-stream gains and flags): a byte ring;
+// a region is reused only after the copy that read it has run (one event per upload)
 struct PinnedRing {
-    static constexpr int kSlots = 4;
+    struct Pending { size_t begin, end; hipEvent_t ev; };
     char* host = nullptr;
-    size_t slotBytes = 0;
-    hipEvent_t done[kSlots] = {};
-    bool used[kSlots] = {};
-    int next = 0;
+    size_t cap = 0, head = 0;
+    std::vector<Pending> pending;       // in issue order
+    std::vector<hipEvent_t> freeEvents;
 };
 
 struct cpq_engine {

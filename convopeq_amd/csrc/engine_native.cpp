@@ -199,32 +199,56 @@ int zeroPairState(cpq_engine* e, PlanGroup& g, int pair)
 
 }  // namespace
 
-// small host -> device tables of a call (chunk schedules): staged through a ring of pinned slots so that the copy is
-// stream-ordered and never reads host memory that has gone out of scope
+// Small host -> device uploads on the processing path (chunk schedules, per-stream gains / flags / fade tables): staged
+// through a ring of pinned memory so that the copy is truly stream-ordered, never blocks the host, and never reads host
+// storage that has gone out of scope (a pageable hipMemcpyAsync is only safe because the runtime happens to stage it
+// synchronously).  Uploads larger than a quarter of the ring take the plain copy and wait for it.
 int stageUpload(cpq_engine* e, void* dst, const void* src, size_t bytes)
 {
     if (bytes == 0) return CPQ_OK;
     PinnedRing& r = e->pinned;
     if (!r.host) {
-        r.slotBytes = 1 << 20;
-        if (hipHostMalloc((void**)&r.host, r.slotBytes * PinnedRing::kSlots) != hipSuccess) {
+        r.cap = (size_t)8 << 20;
+        if (hipHostMalloc((void**)&r.host, r.cap) != hipSuccess) {
             (void)hipGetLastError();
+            r.host = nullptr;
             return fail(e, CPQ_ERR_OOM, "pinned staging ring could not be allocated");
         }
-        for (auto& ev : r.done) CPQ_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    if (bytes > r.slotBytes) {          // rare (very long calls at tiny quanta): plain copy, then wait for it
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > r.cap / 4) {
         CPQ_HIP(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
         CPQ_HIP(e, hipStreamSynchronize(e->stream));
         return CPQ_OK;
     }
-    const int s = r.next;
-    r.next = (r.next + 1) % PinnedRing::kSlots;
-    if (r.used[s]) CPQ_HIP(e, hipEventSynchronize(r.done[s]));
-    std::memcpy(r.host + (size_t)s * r.slotBytes, src, bytes);
-    CPQ_HIP(e, hipMemcpyAsync(dst, r.host + (size_t)s * r.slotBytes, bytes, hipMemcpyHostToDevice, e->stream));
-    CPQ_HIP(e, hipEventRecord(r.done[s], e->stream));
-    r.used[s] = true;
+    if (r.head + need > r.cap) r.head = 0;
+    const size_t begin = r.head, end = r.head + need;
+    // uploads still in flight that own bytes of [begin, end) must have run; they retire in issue order
+    size_t done = 0;
+    for (; done < r.pending.size(); ++done) {
+        const PinnedRing::Pending& p = r.pending[done];
+        bool overlapsLater = false;
+        for (size_t k = done; k < r.pending.size() && !overlapsLater; ++k)
+            overlapsLater = r.pending[k].begin < end && begin < r.pending[k].end;
+        if (!overlapsLater) break;
+        CPQ_HIP(e, hipEventSynchronize(p.ev));
+        r.freeEvents.push_back(p.ev);
+    }
+    if (done) r.pending.erase(r.pending.begin(), r.pending.begin() + (long)done);
+    // retire whatever has completed anyway (keeps the list short)
+    while (!r.pending.empty() && hipEventQuery(r.pending.front().ev) == hipSuccess) {
+        r.freeEvents.push_back(r.pending.front().ev);
+        r.pending.erase(r.pending.begin());
+    }
+    (void)hipGetLastError();            // hipEventQuery reports "not ready" as an error code
+    std::memcpy(r.host + begin, src, bytes);
+    CPQ_HIP(e, hipMemcpyAsync(dst, r.host + begin, bytes, hipMemcpyHostToDevice, e->stream));
+    hipEvent_t ev;
+    if (!r.freeEvents.empty()) { ev = r.freeEvents.back(); r.freeEvents.pop_back(); }
+    else CPQ_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CPQ_HIP(e, hipEventRecord(ev, e->stream));
+    r.pending.push_back(PinnedRing::Pending{ begin, end, ev });
+    r.head = end;
     return CPQ_OK;
 }
 
@@ -232,7 +256,10 @@ void freePinnedRing(cpq_engine* e)
 {
     PinnedRing& r = e->pinned;
     if (!r.host) return;
-    for (auto& ev : r.done) (void)hipEventDestroy(ev);
+    for (auto& p : r.pending) (void)hipEventDestroy(p.ev);
+    for (auto& ev : r.freeEvents) (void)hipEventDestroy(ev);
+    r.pending.clear();
+    r.freeEvents.clear();
     (void)hipHostFree(r.host);
     r.host = nullptr;
 }

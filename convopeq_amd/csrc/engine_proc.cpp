@@ -122,9 +122,8 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
                 return fail(e, CPQ_ERR_OOM, "mix-ramp buffers could not be allocated");
             e->mixRampCap = rampStride;
         }
-        CPQ_HIP(e, hipMemcpyAsync(e->mixRampLen, mixRampLenHost.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
-        CPQ_HIP(e, hipMemcpyAsync(e->mixRampGains, rampHost.data(), sizeof(double) * rampHost.size(), hipMemcpyHostToDevice, e->stream));
-        CPQ_HIP(e, hipStreamSynchronize(e->stream));         // the host vectors go out of scope
+        { const int rcUp = stageUpload(e, e->mixRampLen, mixRampLenHost.data(), sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
+        { const int rcUp = stageUpload(e, e->mixRampGains, rampHost.data(), sizeof(double) * rampHost.size()); if (rcUp != CPQ_OK) return rcUp; }
     }
     const bool firstCall = !e->procProcessed;
     e->procProcessed = true;
@@ -242,22 +241,21 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
         const std::vector<int> rn(dNew.begin() + (size_t)r * S, dNew.begin() + (size_t)(r + 1) * S);
         const std::vector<int> ro(dOld.begin() + (size_t)r * S, dOld.begin() + (size_t)(r + 1) * S);
         if (rn != e->latNewHost) {
-            CPQ_HIP(e, hipMemcpyAsync(e->latNew, rn.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            { const int rcUp = stageUpload(e, e->latNew, rn.data(), sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
             e->latNewHost = rn;
         }
         if (ro != e->latOldHost) {
-            CPQ_HIP(e, hipMemcpyAsync(e->latOld, ro.data(), sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
+            { const int rcUp = stageUpload(e, e->latOld, ro.data(), sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
             e->latOldHost = ro;
         }
         if (fade) {
-            CPQ_HIP(e, hipMemcpyAsync(e->latLen, &xLen[(size_t)r * S], sizeof(int) * S, hipMemcpyHostToDevice, e->stream));
-            CPQ_HIP(e, hipMemcpyAsync(e->latGains, xg[r].data(), sizeof(double) * xg[r].size(), hipMemcpyHostToDevice, e->stream));
+            { const int rcUp = stageUpload(e, e->latLen, &xLen[(size_t)r * S], sizeof(int) * S); if (rcUp != CPQ_OK) return rcUp; }
+            { const int rcUp = stageUpload(e, e->latGains, xg[r].data(), sizeof(double) * xg[r].size()); if (rcUp != CPQ_OK) return rcUp; }
         }
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_convproc_mix(e->stream, dOut + off, dOut + off, (int64_t)n, e->nCh, len, e->procGains, e->dryRing,
                                  e->dryRingSize, pos0 + off, e->latNew, e->latOld, fade ? e->latLen : nullptr, e->latGains,
                                  e->latCap, skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, rampStride, off);
-        if (fade || R > 1) CPQ_HIP(e, hipStreamSynchronize(e->stream));      // the host vectors are reused / go out of scope
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;

@@ -632,14 +632,24 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
     const int per = (T + split - 1) / split;
     const int t0 = part * per, t1 = min(T, t0 + per);
     const double2* ybase = Y + (int64_t)c * T * kP4;
+    const int wr = wgp(j);
+    const int rdm = wgp(kP4 - j);
+    const int rd0 = wgp((kP4 - j) & (kP4 - 1));
     for (int t = t0; t < t1; ++t) {
         double2 v[8];
         const double2* y = ybase + (int64_t)t * kP4;
+        // the row is read from memory once; the mirrored element Y[4096 - k] of the real-FFT split comes from LDS
+        // (the generic kernels load it from global memory a second time: twice the load instructions for the same bytes)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = y[j + 512 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = j + 512 * q;
-            const double2 a = y[k];
-            const double2 b = y[(kP4 - k) & (kP4 - 1)];
+            const double2 a = v[q];
+            const double2 b = dyn[q == 0 ? rd0 : rdm - 576 * q];
             const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
             const double2 d = make_double2(0.5 * (a.x - b.x), 0.5 * (a.y + b.y));
             const double2 w = tw.tw1024[k];
@@ -648,6 +658,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
             if (k == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
             v[q] = z;
         }
+        __syncthreads();                    // every mirrored read is done before the first exchange writes
         p4_cfft<true>(v, dyn, tw.tw512);
         // second half of the 8192-sample frame: x[n], n = j + 512 q, q = 4..7 (NUC.cpp:1332)
         double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
