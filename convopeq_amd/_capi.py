@@ -4,7 +4,9 @@ The library is the product; this module only loads it.  There is no Python or CP
 shared object is missing or a symbol is absent, import fails loudly.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libconvopeq_mi355x.so")
@@ -169,6 +171,30 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process, one HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as the system one
+    this library links).  If this library is loaded first it pulls in /opt/rocm's copy, a later `import torch` maps the
+    bundled copy as a second runtime, and torch.cuda then reports "No HIP GPUs are available".  When a torch installation
+    is present (found WITHOUT importing it) its runtime is mapped first, so both sides resolve libamdhip64.so.7 to the
+    same object whatever the import order.  No torch: nothing happens and the system runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for root in spec.submodule_search_locations:
+        cand = os.path.join(root, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     """Load the shared library and bind every declared symbol; raises if anything is missing."""
     global _lib
@@ -178,6 +204,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C convopeq_amd/csrc` (or __graft_entry__.build()). "
             "convopeq_amd has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)        # AttributeError if the export is missing

@@ -315,6 +315,8 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->ofModesHost.assign(d->n_streams, cpq_engine::OfModes{ 0, 1, 0, 1 });
     e->ofModesSet.assign(d->n_streams, 0);
     e->procParams.assign(d->n_streams, cpq_convproc_params{ 1.0f, 0, 0, 0.0f });
+    e->procBypass.assign(d->n_streams, 0);
+    e->procDryOnly.assign(d->n_streams, 0);
     e->mixRamp.assign(d->n_streams, cpq_engine::MixRamp{});
     e->agcOnHost.assign(d->n_streams, 0);
     e->gainRamp.assign(d->n_streams, cpq_engine::GainRamp{});
@@ -351,6 +353,7 @@ void cpq_engine_destroy(cpq_engine* e)
     if (e->tailSched) (void)hipFree(e->tailSched);
     if (e->procGains) (void)hipFree(e->procGains);
     if (e->procDelay) (void)hipFree(e->procDelay);
+    if (e->procWetOn) (void)hipFree(e->procWetOn);
     for (int* p : { e->latNew, e->latOld, e->latLen }) if (p) (void)hipFree(p);
     if (e->eqDry) (void)hipFree(e->eqDry);
     if (e->silentDev) (void)hipFree(e->silentDev);

@@ -56,6 +56,7 @@ struct NativeLayer {
 struct PlanGroup {
     cpq_nuc_plan plan{};
     bool hasSpec = false, shared = false;       // shared: CPQ_ALL_STREAMS (one stereo IR for every member)
+    bool frozen = false;                        // processor-level bypass / dry-only of its (single) member: not processed
     cpq_filter_spec spec{};
     int capCh = 0, usedCh = 0;                  // allocated / launched local channels (2 per pair slot)
     std::vector<int> streamOfPair;              // pair slot -> stream, -1 = free
@@ -235,7 +236,9 @@ struct cpq_engine {
     // processor-level wrapper (N1)
     int convLevel = CPQ_LEVEL_NUC;
     std::vector<cpq_convproc_params> procParams;   // per stream
-    bool procBypassed = false, procDryOnly = false;
+    std::vector<char> procBypass, procDryOnly;      // per stream: bypassed / mix <= 0.001 (the convolver is not called)
+    std::vector<int> procWetOnHost;                 // per stream: what the device flags hold
+    int* procWetOn = nullptr;                       // [streams] device: 0 = the stream's output is the delayed dry signal
     // mix smoothing (LinearRamp mixSmoother, src/ConvolverProcessor.h:945; Runtime.cpp:340-375, 591-607): per stream
     struct MixRamp { double current = 1.0, target = 1.0, step = 0.0; int remaining = 0, totalSteps = 4800; };
     std::vector<MixRamp> mixRamp;
@@ -316,6 +319,7 @@ int resetGroups(cpq_engine* e);
 int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double* irR, int irLen, double scale, int headTaps,
                      const cpq_filter_spec* spec, const cpq_nuc_plan& pl);
 int leaveNativeGroup(cpq_engine* e, int stream);
+int setStreamFrozen(cpq_engine* e, int stream, bool frozen);
 int groupsAppend(cpq_engine* e, const double* dIn, int n);
 int groupsRunLayer0(cpq_engine* e, double* dOut, int n);
 int groupsRunTails(cpq_engine* e, double* dOut, int n);

@@ -310,6 +310,70 @@ int leaveNativeGroup(cpq_engine* e, int stream)
     return uploadGroupMaps(e, g);
 }
 
+// The stream gets a plan group of its own with its state and phase as they are (rows copied, host replay state copied):
+// what a processor-level bypass needs, which stops ONE stream's Add / Get while the others go on (the reference's
+// ConvolverProcessor does not call its convolver while bypassed or dry-only, Runtime.cpp:123-186, 573-585; on release the
+// NUC resumes with the history it had).
+static int isolateStream(cpq_engine* e, int stream)
+{
+    const int gi = e->groupOf[(size_t)stream];
+    if (gi < 0) return CPQ_ERR_INVALID_ARG;
+    PlanGroup& g = *e->groups[(size_t)gi];
+    int members = 0, pair = -1;
+    for (size_t p = 0; p < g.streamOfPair.size(); ++p) {
+        if (g.streamOfPair[p] >= 0) ++members;
+        if (g.streamOfPair[p] == stream) pair = (int)p;
+    }
+    if (members <= 1 || pair < 0) return CPQ_OK;
+    PlanGroup* n = new (std::nothrow) PlanGroup();
+    if (!n) return fail(e, CPQ_ERR_OOM, "host allocation failed");
+    n->plan = g.plan;
+    n->hasSpec = g.hasSpec;
+    n->spec = g.spec;
+    n->shared = g.shared;
+    n->samplesSinceReset = std::max<long long>(g.samplesSinceReset, 1);        // not fresh: nobody else may join its phase
+    n->lastGot = g.lastGot;
+    n->lastCall = g.lastCall;
+    int rc = sizeGroup(e, *n, 1);
+    if (rc != CPQ_OK) { freeGroupBuffers(*n); delete n; return rc; }
+    for (size_t l = 0; l < g.layers.size(); ++l) {
+        NativeLayer& src = g.layers[l];
+        NativeLayer& dst = n->layers[l];
+        auto si = layerItems(src), di = layerItems(dst);
+        for (size_t i = 0; i < si.size(); ++i) {
+            const int64_t rows = 2, from = si[i].perSlot ? (g.shared ? 0 : 2 * pair) : 2 * pair;
+            CPQ_HIP(e, hipMemcpyAsync(*di[i].ptr, (char*)*si[i].ptr + from * si[i].rowBytes, (size_t)(rows * si[i].rowBytes),
+                                      hipMemcpyDeviceToDevice, e->stream));
+        }
+        dst.head = src.head; dst.histSel = src.histSel; dst.accSel = src.accSel; dst.fill = src.fill;
+        dst.distributing = src.distributing; dst.nextPart = src.nextPart; dst.wPos = src.wPos; dst.rPos = src.rPos;
+    }
+    n->streamOfPair[0] = stream;
+    g.streamOfPair[(size_t)pair] = -1;
+    rc = zeroPairState(e, g, pair);
+    if (rc != CPQ_OK) return rc;
+    e->groups.push_back(n);
+    e->groupOf[(size_t)stream] = (int)e->groups.size() - 1;
+    rc = uploadGroupMaps(e, g);
+    if (rc == CPQ_OK) rc = uploadGroupMaps(e, *n);
+    return rc;
+}
+
+// frozen: the stream's convolver is not called (bypass / dry-only at the processor level); its state waits as it is
+int setStreamFrozen(cpq_engine* e, int stream, bool frozen)
+{
+    int gi = e->groupOf[(size_t)stream];
+    if (gi < 0) return fail(e, CPQ_ERR_UNSUPPORTED, "a per-stream bypass needs the stream on the reference's own layer plan "
+                                                   "(CPQ_CALLS_ANY, CPQ_SCHED_REFERENCE_NUC or a FilterSpec plan with tail layers); "
+                                                   "on the uniform path set it for CPQ_ALL_STREAMS");
+    if (e->groups[(size_t)gi]->frozen == frozen) return CPQ_OK;      // (a frozen group has one member: it was isolated first)
+    const int rc = isolateStream(e, stream);
+    if (rc != CPQ_OK) return rc;
+    gi = e->groupOf[(size_t)stream];
+    e->groups[(size_t)gi]->frozen = frozen;
+    return CPQ_OK;
+}
+
 // SetImpulse of one stream (or of all streams with one shared stereo IR) on the reference's own layer plan
 int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double* irR, int irLen, double scale, int headTaps,
                      const cpq_filter_spec* spec, const cpq_nuc_plan& pl)
@@ -464,6 +528,7 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
+        if (g.frozen) continue;
         for (NativeLayer& t : g.layers)
             cpq::launch_rows_gather(e->stream, dIn, n, g.chMapDev, t.acc[t.accSel], t.accCap, t.fill, n, g.usedCh);
     }
@@ -517,6 +582,7 @@ int groupsRunLayer0(cpq_engine* e, double* dOut, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
+        if (g.frozen) continue;
         const long long w0 = g.layers[0].wPos;
         replayCall(e, g, n, g.tabHost, g.tabOffs, g.nbOf);
         if ((int)g.tabHost.size() > g.tabCap) return fail(e, CPQ_ERR_INVALID_ARG, "call of %d samples exceeds the engine's call capacity", n);
@@ -539,6 +605,7 @@ int groupsRunTails(cpq_engine* e, double* dOut, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
+        if (g.frozen) continue;
         for (size_t l = 1; l < g.layers.size(); ++l) {
             NativeLayer& t = g.layers[l];
             { const int rc = runLayerBlocks(e, g, t, n, g.tabDev + g.tabOffs[2 * l + 1], 0); if (rc != CPQ_OK) return rc; }

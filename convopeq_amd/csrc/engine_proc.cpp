@@ -83,8 +83,9 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
     std::vector<double> rampHost;
     bool anyRamp = false;
     int rampStride = 0;                 // samples per stream in rampHost / on the device: the longest smoothed prefix
-    if (!e->procBypassed) {
+    {
         for (int s = 0; s < S; ++s) {
+            if (e->procBypass[s]) continue;             // the bypass path does not touch the smoother (:123-186)
             auto& r = e->mixRamp[s];
             const double tgt = (double)e->procParams[s].mix;
             if (std::fabs(r.target - tgt) > 1.0e-5 && tgt != r.target) {                 // setTargetValue
@@ -127,7 +128,34 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
     }
     const bool firstCall = !e->procProcessed;
     e->procProcessed = true;
-    const bool skipConv = e->procBypassed || (e->procDryOnly && !anyRamp);      // needsConvolution = isSmoothing || mix > 0.001
+    // needsConvolution = isSmoothing || mix > 0.001 (:374); bypassed: the convolver is not called (:123-186).  A stream whose
+    // convolver rests while others run is moved to a plan group of its own and that group is not processed.
+    std::vector<char> rest((size_t)S, 0);
+    bool allRest = true, anyRest = false;
+    for (int s = 0; s < S; ++s) {
+        const bool ramping = anyRamp && mixRampLenHost[s] > 0;
+        rest[s] = e->procBypass[s] || (e->procDryOnly[s] && !ramping);
+        allRest = allRest && rest[s];
+        anyRest = anyRest || rest[s];
+    }
+    const bool skipConv = allRest;
+    if (!allRest && (anyRest || !e->groups.empty()))
+        for (int s = 0; s < S; ++s) {
+            if (e->groupOf[(size_t)s] < 0) { if (rest[s]) return setStreamFrozen(e, s, true); continue; }     // reports why not
+            const int rc = setStreamFrozen(e, s, rest[s] != 0);
+            if (rc != CPQ_OK) return rc;
+        }
+    {
+        std::vector<int> wetOn((size_t)S);
+        for (int s = 0; s < S; ++s) wetOn[s] = rest[s] ? 0 : 1;
+        if (wetOn != e->procWetOnHost) {
+            if (!e->procWetOn && hipMalloc((void**)&e->procWetOn, sizeof(int) * S) != hipSuccess)
+                return fail(e, CPQ_ERR_OOM, "processor-level flags could not be allocated");
+            const int rc = stageUpload(e, e->procWetOn, wetOn.data(), sizeof(int) * S);
+            if (rc != CPQ_OK) return rc;
+            e->procWetOnHost = wetOn;
+        }
+    }
     // the call's input goes into the delay ring before the convolver may overwrite it (in-place calls)
     const long long pos0 = e->dryPos;
     {
@@ -153,8 +181,9 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
     {
         std::vector<char> starts((size_t)cbs, 0);
         // pass 1: where do fades start (needs the per-stream replay, so replay on copies)
-        if (!e->procBypassed) {
+        {
             for (int s = 0; s < S; ++s) {
+                if (e->procBypass[s]) continue;
                 auto f = e->latFade[s];
                 const double total = (double)procDelayOf(e, s);
                 if (!f.primed || firstCall) {             // prepareToPlay: latency + irLatency, fade gain at 1 (Lifecycle.cpp:377-388)
@@ -185,7 +214,7 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
     for (int s = 0; s < S; ++s) {
         auto& f = e->latFade[s];
         const int totalI = procDelayOf(e, s);
-        if (e->procBypassed) {
+        if (e->procBypass[s]) {
             for (int r = 0; r < R; ++r) dNew[(size_t)r * S + s] = dOld[(size_t)r * S + s] = totalI;
             continue;
         }
@@ -255,7 +284,8 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
         ProfScope p(e, CPQ_K_MIX);
         cpq::launch_convproc_mix(e->stream, dOut + off, dOut + off, (int64_t)n, e->nCh, len, e->procGains, e->dryRing,
                                  e->dryRingSize, pos0 + off, e->latNew, e->latOld, fade ? e->latLen : nullptr, e->latGains,
-                                 e->latCap, skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, rampStride, off);
+                                 e->latCap, skipConv ? 0 : 1, anyRamp ? e->mixRampLen : nullptr, e->mixRampGains, rampStride, off,
+                                 e->procWetOn);
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
@@ -273,8 +303,10 @@ int32_t cpq_convproc_set_params(cpq_engine* e, int32_t stream, const cpq_convpro
     if (!(p->mix >= 0.0f && p->mix <= 1.0f)) return fail(e, CPQ_ERR_INVALID_ARG, "mix must be in [0, 1]");
     if (p->ir_peak_latency < 0) return fail(e, CPQ_ERR_INVALID_ARG, "ir_peak_latency must be >= 0");
     const bool dryOnly = !((double)p->mix > 0.001);        // needsConvolution, :374
-    if (stream != CPQ_ALL_STREAMS && (p->bypassed || dryOnly || e->procBypassed || e->procDryOnly))
-        return fail(e, CPQ_ERR_UNSUPPORTED, "bypass / dry-only freeze the convolver state and must be set for CPQ_ALL_STREAMS");
+    if (stream != CPQ_ALL_STREAMS && (p->bypassed || dryOnly) && e->groupOf[(size_t)stream] < 0 && e->irLoaded[2 * (size_t)stream])
+        return fail(e, CPQ_ERR_UNSUPPORTED, "a per-stream bypass / dry-only rests ONE convolver: the stream must run on the reference's own "
+                    "layer plan (CPQ_CALLS_ANY, CPQ_SCHED_REFERENCE_NUC or a FilterSpec plan with tail layers); on the uniform path set it "
+                    "for CPQ_ALL_STREAMS");
     const int s0 = (stream == CPQ_ALL_STREAMS) ? 0 : stream;
     const int s1 = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
     if (p->smoothing_time_sec != 0.0f && !(p->smoothing_time_sec >= 0.01f && p->smoothing_time_sec <= 0.5f))
@@ -289,7 +321,7 @@ int32_t cpq_convproc_set_params(cpq_engine* e, int32_t stream, const cpq_convpro
         // the mix applies at once; afterwards it is the ramp's new target
         if (!e->procProcessed) { r.current = r.target = (double)p->mix; r.step = 0.0; r.remaining = 0; }
     }
-    if (stream == CPQ_ALL_STREAMS) { e->procBypassed = p->bypassed != 0; e->procDryOnly = dryOnly; }
+    for (int s = s0; s < s1; ++s) { e->procBypass[s] = p->bypassed != 0; e->procDryOnly[s] = dryOnly; }
     return uploadProcParams(e);
 }
 

@@ -80,7 +80,8 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
 void launch_convproc_mix(hipStream_t stream, const double* wet, double* out, int64_t chStride, int nCh, int nSamples,
                          const double* gains, const double* ring, int ringSize, long long pos0, const int* dNew,
                          const int* dOld, const int* xLen, const double* xGains, int xCap, int wetValid,
-                         const int* rampLen = nullptr, const double* rampGains = nullptr, int rampCap = 0, int rampOff = 0);
+                         const int* rampLen = nullptr, const double* rampGains = nullptr, int rampCap = 0, int rampOff = 0,
+                         const int* wetOn = nullptr);       // wetOn[stream] == 0: that stream's convolver rests (delayed dry only)
 void launch_ring_regrow(hipStream_t stream, const double* oldRing, int oldSize, double* newRing, int newSize, long long end,
                         int nCh);
 

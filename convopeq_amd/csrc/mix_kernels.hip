@@ -20,10 +20,12 @@ __global__ __launch_bounds__(256) void k_convproc_mix(const double* wet, double*
                                                       const int* __restrict__ dNew, const int* __restrict__ dOld,
                                                       const int* __restrict__ xLen, const double* __restrict__ xGains,
                                                       int xCap, int wetValid, const int* __restrict__ rampLen,
-                                                      const double* __restrict__ rampGains, int rampCap, int rampOff)
+                                                      const double* __restrict__ rampGains, int rampCap, int rampOff,
+                                                      const int* __restrict__ wetOn)
 {
     const int c = blockIdx.y;
     const int s = c >> 1;
+    if (wetOn && !wetOn[s]) wetValid = 0;         // this stream's convolver rests (bypass / dry-only): delayed dry signal only
     const double wetG = gains[2 * s], dryG = gains[2 * s + 1];
     // mix smoothing (:591-607, mixSmoothingSmall :611-632): the first rampLen[s] samples of the call carry per-sample
     // gains (equalPowerSin of the LinearRamp's values, formed on the host); rampOff = first sample of this range
@@ -489,13 +491,13 @@ void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const
 void launch_convproc_mix(hipStream_t stream, const double* wet, double* out, int64_t chStride, int nCh, int nSamples,
                          const double* gains, const double* ring, int ringSize, long long pos0, const int* dNew,
                          const int* dOld, const int* xLen, const double* xGains, int xCap, int wetValid,
-                         const int* rampLen, const double* rampGains, int rampCap, int rampOff)
+                         const int* rampLen, const double* rampGains, int rampCap, int rampOff, const int* wetOn)
 {
     if (nSamples <= 0) return;
     int bx = (nSamples + 255) / 256;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(k_convproc_mix, dim3(bx, nCh), dim3(256), 0, stream, wet, out, chStride, nSamples, gains, ring,
-                       ringSize - 1, pos0, dNew, dOld, xLen, xGains, xCap, wetValid, rampLen, rampGains, rampCap, rampOff);
+                       ringSize - 1, pos0, dNew, dOld, xLen, xGains, xCap, wetValid, rampLen, rampGains, rampCap, rampOff, wetOn);
 }
 
 void launch_ring_regrow(hipStream_t stream, const double* oldRing, int oldSize, double* newRing, int newSize, long long end,

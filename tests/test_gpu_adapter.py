@@ -24,3 +24,17 @@ def test_adapter_add_get_matches_direct_form(tmp_path):
     r = subprocess.run([str(exe), os.path.join(HERE, "golden", "impulse_room_correction_hpf_lpf.wav")], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_library_loaded_before_torch_shares_one_hip_runtime():
+    """Import order must not matter: PyTorch-ROCm bundles its own libamdhip64; loaded second beside the system copy this
+    library links, it used to leave torch.cuda with "No HIP GPUs are available" (convopeq_amd/_capi.py maps torch's copy
+    first when a torch installation exists)."""
+    import sys
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import convopeq_amd as amd; "
+            "e = amd.BatchedEngine(1, max_ir_len=512, max_blocks_per_call=1); import torch; "
+            "assert torch.cuda.is_available(); t = torch.ones(8, dtype=torch.float64).cuda(); torch.cuda.synchronize(); "
+            "assert float(t.sum()) == 8.0; e.close(); print('one runtime')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "one runtime" in r.stdout, r.stdout + r.stderr

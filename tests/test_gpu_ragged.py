@@ -193,3 +193,45 @@ def test_whole_block_engine_refuses_ragged_calls_loudly(amd, oracle):
     with pytest.raises(amd.CpqError):
         amd.BatchedEngine(1, block_size=480, max_ir_len=4096, max_blocks_per_call=4)        # non-power-of-two needs CPQ_CALLS_ANY
     eng.close()
+
+
+def test_per_stream_bypass_rests_one_convolver(amd, oracle):
+    """ConvolverProcessor bypass of ONE stream (src/convolver/ConvolverProcessor.Runtime.cpp:123-186): its output is the
+    delayed dry signal and its convolver is not called -- the NUC keeps the state it had and resumes with it on release --
+    while the other streams go on.  Processor level, three streams with their own IRs, the middle one bypassed for two
+    calls and released again.  (Dry-only, mix <= 0.001, rests the convolver through the same mechanism once its mix ramp
+    has ended.)"""
+    O = oracle
+    L = O.lib()
+    quantum, T, taps, S = 512, 8, 20000, 3
+    n_call = T * quantum
+    mode = ["on", "on", "bypass", "bypass", "on", "on", "bypass", "on"]      # of stream 1, per call
+    n = n_call * len(mode)
+    irs = [[O.gen_ir(taps, stream=30 + s, channel=ch) for ch in range(2)] for s in range(S)]
+    x = make_inputs(O, range(30, 30 + S), n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=T, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[s][0], irs[s][1])
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=1.0)
+    ys = []
+    for c, m in enumerate(mode):
+        eng.set_convproc_params(1, mix=1.0, bypassed=(m == "bypass"))
+        ys.append(eng.convproc_process(np.ascontiguousarray(x[:, c * n_call:(c + 1) * n_call])))
+    y = np.concatenate(ys, axis=1)
+    wet_g = L.orc_equal_power_sin(1.0)
+    for s in range(S):
+        for ch in range(2):
+            xc = x[2 * s + ch]
+            dry = np.concatenate([np.zeros(quantum), xc[:-quantum]])
+            nuc = O.Nuc()
+            assert nuc.set_impulse(irs[s][ch], quantum)
+            ref = np.empty(n)
+            for c, m in enumerate(mode):
+                seg = slice(c * n_call, (c + 1) * n_call)
+                if s == 1 and m != "on":
+                    ref[seg] = dry[seg]                  # the convolver rests: no Add / Get
+                else:
+                    ref[seg] = nuc.run(xc[seg], quantum) * wet_g
+            nuc.close()
+            assert rms(y[2 * s + ch] - ref) <= 1e-13, (s, ch)
+    eng.close()
