@@ -222,7 +222,7 @@ def cpu_baseline(ir_len, use_eq, saturation, preset, target_seconds=6.0):
 
 
 def parity_of_timed_engine(amd, eng, d_in, d_out, torch, S, n, ir_len, use_eq, saturation, preset, stream_ids, exact,
-                           schedule_nuc):
+                           shared_ir):
     """Parity of the TIMED engine itself: its state is reset, two calls of the step's input run from reset, and the output
     rows of a few streams (first, second, middle, last) are read back and compared with the oracle fed the same IR / PCM.
     The oracle is the checker here; nothing of it is timed or shipped."""
@@ -245,7 +245,7 @@ def parity_of_timed_engine(amd, eng, d_in, d_out, torch, S, n, ir_len, use_eq, s
         gid = stream_ids[s]
         ref = []
         for ch in range(2):
-            h = gen_ir(ir_len, gid, ch)
+            h = gen_ir(ir_len, 0 if shared_ir else gid, ch)
             x = gen_pcm(n, gid, ch)
             xx = np.concatenate([x, x])
             if exact:
@@ -558,7 +558,7 @@ def main():
     parity = None
     if not (args.no_parity or args.eq_only or args.host_buffers or args.pcm_scale != 1.0) and B == 512:
         parity = parity_of_timed_engine(amd, eng, d_in, d_out, torch, S, n, L, use_eq, args.saturation, args.eq_preset,
-                                        ids, args.exact, args.schedule == "nuc")
+                                        ids, args.exact, args.shared_ir)
 
     samples = float(S) * n * args.steps          # stereo samples this rank processed
     my_rate = samples / my_elapsed / 1e6

@@ -18,6 +18,8 @@ namespace cpq {
 
 namespace {
 
+typedef double v2d __attribute__((ext_vector_type(2)));      // 16-byte streaming (non-temporal) loads / stores
+
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
@@ -124,8 +126,7 @@ __device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, 
         }
         // streaming store: an FDL row is next read by the MAC of this or a later call, never from cache (the MAC of the
         // same call runs 1 % faster with its L2 left alone)
-        __builtin_nontemporal_store(xk.x, reinterpret_cast<double*>(spec + k));
-        __builtin_nontemporal_store(xk.y, reinterpret_cast<double*>(spec + k) + 1);
+        __builtin_nontemporal_store(v2d{ xk.x, xk.y }, reinterpret_cast<v2d*>(spec + k));      // one 16-byte store per lane
     }
 }
 
@@ -513,11 +514,59 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
 // frame t is the first half of frame t + 1, in the same registers.
 constexpr int kP4 = 4096;
 
-template <bool INV>
-__device__ __forceinline__ void p4_twiddle(double2 (&v)[8], const double2* __restrict__ twM, int k, int tstep)
+// Twiddles of the three later stages without a trip to global memory: W4096^(q k tstep) with k = j mod ns factors over
+// the octal digits of k into entries of three 8 x 8 tables in LDS (3 KB, filled once per workgroup from the engine's
+// extended-precision table):  T1[d][q] = W64^(q d),  T2[d][q] = W512^(q d),  T3[d][q] = W4096^(q d).
+//   ns = 8   (k = d0):              T1[d0][q]
+//   ns = 64  (k = d0 + 8 d1):       T2[d0][q] T1[d1][q]
+//   ns = 512 (k = d0 + 8 d1 + 64 d2): T3[d0][q] T2[d1][q] T1[d2][q]
+// The table loads (21 per thread and frame, each a dependent L2 round trip right before its butterfly, behind a
+// barrier) were what the kernel waited for; the products cost 4 / 8 flops per point and ~2 ulp in the twiddle.
+// exp(-2 pi i q / 16), q < 8 (correctly rounded constants)
+__device__ __forceinline__ double2 p4_w16(int q)
 {
+    constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, r = 0.70710678118654752440;
+    switch (q) {
+        case 0: return make_double2(1.0, 0.0);
+        case 1: return make_double2(c1, -s1);
+        case 2: return make_double2(r, -r);
+        case 3: return make_double2(s1, -c1);
+        case 4: return make_double2(0.0, -1.0);
+        case 5: return make_double2(-s1, -c1);
+        case 6: return make_double2(-r, -r);
+        default: return make_double2(-c1, -s1);
+    }
+}
+
+struct P4Tables { double2 t[3][8][8]; };
+
+__device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __restrict__ twM)
+{
+    for (int i = threadIdx.x; i < 3 * 64; i += blockDim.x) {
+        const int tb = i >> 6, d = (i >> 3) & 7, q = i & 7;
+        const int step = tb == 0 ? 64 : (tb == 1 ? 8 : 1);
+        T->t[tb][d][q] = twM[step * q * d];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+
+template <bool INV>
+__device__ __forceinline__ void p4_twiddle(double2 (&v)[8], const P4Tables* T, int st, int j)
+{
+    const int d0 = j & 7, d1 = (j >> 3) & 7, d2 = (j >> 6) & 7;
 #pragma unroll
-    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], twM[q * k * tstep]);
+    for (int q = 1; q < 8; ++q) {
+        double2 w;
+        if (st == 1) w = T->t[0][d0][q];
+        else if (st == 2) w = cmul(T->t[1][d0][q], T->t[0][d1][q]);
+        else w = cmul(cmul(T->t[2][d0][q], T->t[1][d1][q]), T->t[0][d2][q]);
+        v[q] = cmulw<INV>(v[q], w);
+    }
 }
 
 // One exchange through LDS: thread j leaves its 8 values at padded elements wr + q wrStep and takes the 8 at rd + q rdStep
@@ -539,7 +588,7 @@ __device__ __forceinline__ void p4_exchange(double2 (&v)[8], double2* lds, int w
 // A rolled loop over the stages: fully unrolled, the compiler hoists every stage's twiddle loads and the kernel no longer
 // fits the register budget of two (let alone three or four) workgroups per CU.
 template <bool INV>
-__device__ __forceinline__ void p4_cfft(double2 (&v)[8], double2* lds, const double2* __restrict__ twM)
+__device__ __forceinline__ void p4_cfft(double2 (&v)[8], double2* lds, const P4Tables* T)
 {
     const int j = threadIdx.x;
     const int rd = wgp(j);                                      // wgp(j + 512 q) = wgp(j) + 576 q
@@ -547,7 +596,7 @@ __device__ __forceinline__ void p4_cfft(double2 (&v)[8], double2* lds, const dou
     for (int st = 0; st < 4; ++st) {
         const int ns = 1 << (3 * st);
         const int k = j & (ns - 1);
-        if (st > 0) p4_twiddle<INV>(v, twM, k, kP4 / (8 * ns));
+        if (st > 0) p4_twiddle<INV>(v, T, st, j);
         dft8<INV>(v);
         if (st < 3) p4_exchange(v, lds, wgp(((j - k) << 3) + k), ns + (ns >> 3), rd, 576);     // wgp(o + q ns) = wgp(o) + q (ns + ns / 8), ns >= 8; ns = 1: 9 j + q
     }
@@ -562,12 +611,16 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
                                                           int head, int ringMask)
 {
     extern __shared__ double2 dyn[];
+    __shared__ P4Tables tabs;
     const int j = threadIdx.x;
     const int c = blockIdx.x / split;
     const int part = blockIdx.x - c * split;
     const int per = (T + split - 1) / split;
     const int t0 = part * per, t1 = min(T, t0 + per);
     if (t0 >= t1) return;
+    p4_load_tables(&tabs, tw.tw512);
+    // split twiddle exp(-2 pi i (j + 512 q) / 8192) = exp(-2 pi i j / 8192) W16^q: one load per thread for the whole walk
+    const double2 wj = tw.tw1024[j];
     const double* base = in + (int64_t)c * chStride;
     // frame t = [block t-1 | block t]; thread j holds complex points n = j + 512 q: n < 2048 from the previous block
     double2 keep[4];
@@ -590,7 +643,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(hn + 2 * (j + 512 * q)) = v[4 + q];
         }
-        p4_cfft<false>(v, dyn, tw.tw512);
+        p4_cfft<false>(v, dyn, &tabs);
         // real-FFT split: Z[k] with Z[4096 - k], one more trip through LDS; wgp(4096 - j - 512 q) = wgp(4096 - j) - 576 q
         const int slot = (head + t) & ringMask;
         const int64_t row = (int64_t)c * (ringMask + 1) + slot;
@@ -609,14 +662,14 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
             const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
             const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
             const double2 o = make_double2(d.y, -d.x);
-            const double2 w = tw.tw1024[k];
+            const double2 w = cmul(wj, p4_w16(q));
             double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
             if (k == 0) {
                 xk = make_double2(zk.x + zk.y, zk.x - zk.y);
                 XDN[row] = xk;
             }
-            __builtin_nontemporal_store(xk.x, reinterpret_cast<double*>(spec + k));
-            __builtin_nontemporal_store(xk.y, reinterpret_cast<double*>(spec + k) + 1);
+            // one 16-byte streaming store per lane (two 8-byte ones leave half-written lines to the write combiner)
+            __builtin_nontemporal_store(v2d{ xk.x, xk.y }, reinterpret_cast<v2d*>(spec + k));
         }
         __syncthreads();                    // the next frame's first exchange reuses the buffer
     }
@@ -626,11 +679,15 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
                                                               int64_t chStride, FftTables tw, int T, int split)
 {
     extern __shared__ double2 dyn[];
+    __shared__ P4Tables tabs;
     const int j = threadIdx.x;
     const int c = blockIdx.x / split;
     const int part = blockIdx.x - c * split;
     const int per = (T + split - 1) / split;
     const int t0 = part * per, t1 = min(T, t0 + per);
+    if (t0 >= t1) return;
+    p4_load_tables(&tabs, tw.tw512);
+    const double2 wj = tw.tw1024[j];
     const double2* ybase = Y + (int64_t)c * T * kP4;
     const int wr = wgp(j);
     const int rdm = wgp(kP4 - j);
@@ -639,9 +696,13 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
         double2 v[8];
         const double2* y = ybase + (int64_t)t * kP4;
         // the row is read from memory once; the mirrored element Y[4096 - k] of the real-FFT split comes from LDS
-        // (the generic kernels load it from global memory a second time: twice the load instructions for the same bytes)
+        // (the generic kernels load it from global memory a second time: twice the load instructions for the same bytes).
+        // Requesting the next frame's row (or block, in the forward kernel) one frame ahead measured no faster.
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = y[j + 512 * q];
+        for (int q = 0; q < 8; ++q) {
+            const v2d r = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(y + j + 512 * q));     // read once, written past the cache by the MAC
+            v[q] = make_double2(r.x, r.y);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
         __syncthreads();
@@ -652,14 +713,14 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
             const double2 b = dyn[q == 0 ? rd0 : rdm - 576 * q];
             const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
             const double2 d = make_double2(0.5 * (a.x - b.x), 0.5 * (a.y + b.y));
-            const double2 w = tw.tw1024[k];
+            const double2 w = cmul(wj, p4_w16(q));
             const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
             double2 z = make_double2(e.x - o.y, e.y + o.x);
             if (k == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
             v[q] = z;
         }
         __syncthreads();                    // every mirrored read is done before the first exchange writes
-        p4_cfft<true>(v, dyn, tw.tw512);
+        p4_cfft<true>(v, dyn, &tabs);
         // second half of the 8192-sample frame: x[n], n = j + 512 q, q = 4..7 (NUC.cpp:1332)
         double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
         constexpr double s = 1.0 / (double)kP4;
