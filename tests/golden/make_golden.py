@@ -5,6 +5,8 @@ and oracle/_ref are only available there).  Fixtures are DATA (inputs + expected
   fasttanh_ref.json        outputs of the reference's own src/dsp/math/FastTanhApprox.h (scalar and SSE2 paths),
                            obtained by compiling that stand-alone header where it lies (oracle/ref_probe.cpp)
   eq_params_default_ref.json  a default-constructed convo::EQParameters (src/core/EQParameters.h) via the same probe
+  svf_display_biquad_ref.json  the reference's own svfToDisplayBiquad (src/tests/EQProcessorMaxGainTests.cpp:67-87, compiled
+                           unmodified via oracle/ref_probe_eqmath.cpp) applied to SVF coefficient sets: the biquad each band IS
   survey_observations.json hand-transcribed observations of the RUNNING reference recorded in SURVEY.md
                            (section 0 findings 2-4, section 8(a) row A6, section 8(c)); provenance: survey session
   nuc_oracle_vectors.npz   outputs of this repo's oracle for fixed seeded inputs (regression pin of the oracle
@@ -43,6 +45,23 @@ def main():
           "source": "reference src/core/EQParameters.h compiled unmodified via oracle/ref_probe.cpp"}
     with open(os.path.join(HERE, "eq_params_default_ref.json"), "w") as f:
         json.dump(eq, f, indent=0)
+
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("t_ref_eq", os.path.join(os.path.dirname(HERE), "test_ref_eq_math_cpu.py"))
+    t = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(t)
+    cases = []
+    for btype, freq, gain, q in t.CASES:
+        c = O.svf_design(btype, freq, gain, q, 48000.0)
+        svf = [c.a1, c.a2, c.a3, c.m0, c.m1, c.m2]
+        b, a = O.ref_svf_to_display_biquad(svf)
+        cases.append({"type": btype, "freq": freq, "gain_db": gain, "q": q, "svf": [float(v).hex() for v in svf],
+                      "biquad": [float(v).hex() for v in np.concatenate([b, a])]})
+    with open(os.path.join(HERE, "svf_display_biquad_ref.json"), "w") as f:
+        json.dump({"source": "reference src/tests/EQProcessorMaxGainTests.cpp svfToDisplayBiquad compiled unmodified via "
+                             "oracle/ref_probe_eqmath.cpp; svf = a1 a2 a3 m0 m1 m2 (this repo's design, hex doubles), "
+                             "biquad = b0 b1 b2 a0 a1 a2 (the reference's equivalent biquad, hex doubles); sample rate 48000",
+                   "cases": cases}, f, indent=0)
 
     survey = {
         "source": "SURVEY.md: values observed from the unmodified reference sources running in the survey session",

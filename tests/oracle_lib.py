@@ -131,6 +131,12 @@ def ref_probe():
         getattr(R, n).restype = C.c_double
         getattr(R, n).argtypes = [C.c_double]
     R.ref_eq_params_default.argtypes = [C.POINTER(EqParams)]
+    if hasattr(R, "ref_svf_to_display_biquad"):       # the reference's pure-math EQ test (oracle/ref_probe_eqmath.cpp)
+        R.ref_eq_math_selftest.restype = C.c_int
+        R.ref_svf_to_display_biquad.argtypes = [c_double_p, c_double_p]
+        R.ref_calc_lpf_svf.argtypes = [C.c_double, C.c_double, C.c_double, c_double_p]
+        R.ref_biquad_magnitude_squared.restype = C.c_double
+        R.ref_biquad_magnitude_squared.argtypes = [c_double_p, C.c_double, C.c_double]
     _REF = R
     return R
 
@@ -138,6 +144,20 @@ def ref_probe():
 def dp(a):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(c_double_p)
+
+
+def ref_svf_to_display_biquad(svf6):
+    """(b, a) of the biquad the reference's own svfToDisplayBiquad assigns to SVF coefficients (a1 a2 a3 m0 m1 m2)."""
+    s = np.ascontiguousarray(svf6, dtype=np.float64)
+    out = np.empty(6)
+    ref_probe().ref_svf_to_display_biquad(dp(s), dp(out))
+    return out[:3].copy(), out[3:].copy()
+
+
+def ref_calc_lpf_svf(freq, q, sr):
+    out = np.empty(6)
+    ref_probe().ref_calc_lpf_svf(freq, q, sr, dp(out))
+    return out
 
 
 # ------------------------------------------------------------------ helpers

@@ -157,6 +157,43 @@ def test_eq_cascade_matches_oracle(amd, oracle, sat, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+def test_svf_band_matches_the_reference_display_biquad(amd, oracle, mode):
+    """External anchor for the band kernel (A11 / A12): the reference's own svfToDisplayBiquad
+    (src/tests/EQProcessorMaxGainTests.cpp:67-87, compiled unmodified; fixture tests/golden/svf_display_biquad_ref.json) says
+    which biquad an SVF band with given coefficients is.  With saturation 0 one enabled band of the HIP EQ must filter like
+    scipy.signal.lfilter with that biquad -- for every band type, on both kernels (lane-skewed sequential, time-parallel)."""
+    import json
+    from scipy.signal import lfilter
+    O = oracle
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "svf_display_biquad_ref.json")) as f:
+        cases = json.load(f)["cases"]
+    n = 32 * B
+    x = make_inputs(O, 1, n)
+    eng = amd.BatchedEngine(1, max_ir_len=512, max_blocks_per_call=32)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    worst = 0.0
+    for case in cases:
+        p = amd.eq_params_default()
+        for i in range(20):
+            p.bands[i].enabled = 0
+        b0 = p.bands[0]
+        b0.enabled, b0.type, b0.frequency, b0.gain, b0.q, b0.channel_mode = 1, case["type"], case["freq"], case["gain_db"], case["q"], 0
+        p.nonlinear_saturation = 0.0
+        p.total_gain_db = 0.0
+        eng.set_eq_params(amd.CPQ_ALL_STREAMS, p)
+        eng.eq_reset()
+        y = eng.eq_process(x)
+        bq = np.array([float.fromhex(v) for v in case["biquad"]])
+        for c in range(2):
+            ref = lfilter(bq[:3] / bq[3], bq[3:] / bq[3], x[c])
+            err = np.abs(y[c] - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, err)
+            assert err <= 2e-12, (case["type"], case["freq"], err)
+    print("SVF band vs the reference's display biquad,", mode, "kernel: worst relative error", worst)
+    eng.close()
+
+
 def test_conv_then_eq_whole_path(amd, oracle):
     O = oracle
     S = 2
