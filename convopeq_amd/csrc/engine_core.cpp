@@ -56,6 +56,20 @@ int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples)
 }
 
 
+// Call-sized buffers that only some entry points need are allocated when first used: the staging pair of the host-pointer
+// entry points, the hand-off buffer of the EQ -> convolver order (3 x 2 GB at 256 streams and 524288-sample calls).
+int ensureCallBuffer(cpq_engine* e, double** buf, const char* what)
+{
+    if (*buf) return CPQ_OK;
+    const size_t bytes = (size_t)e->nCh * e->tMax * e->P * sizeof(double);
+    if (hipMalloc((void**)buf, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        *buf = nullptr;
+        return fail(e, CPQ_ERR_OOM, "%s buffer of %zu bytes could not be allocated", what, bytes);
+    }
+    return CPQ_OK;
+}
+
 int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
 {
     CPQ_HIP(e, hipSetDevice(e->device));
@@ -239,7 +253,6 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     // ---- arena layout
     struct Item { void** ptr; int64_t bytes; };
     const int64_t nCh = e->nCh;
-    const int64_t callSamples = (int64_t)e->tMax * e->P;
     Item items[] = {
         { (void**)&e->X, nCh * e->ringSlots * e->P * (int64_t)sizeof(double2) },
         { (void**)&e->XDN, nCh * e->ringSlots * (int64_t)sizeof(double2) },
@@ -248,9 +261,6 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->Y, nCh * e->tMax * e->P * (int64_t)sizeof(double2) },
         { (void**)&e->hist[0], nCh * e->P * (int64_t)sizeof(double) },
         { (void**)&e->hist[1], nCh * e->P * (int64_t)sizeof(double) },
-        { (void**)&e->stageIn, nCh * callSamples * (int64_t)sizeof(double) },
-        { (void**)&e->stageOut, nCh * callSamples * (int64_t)sizeof(double) },
-        { (void**)&e->mid, nCh * callSamples * (int64_t)sizeof(double) },
         { (void**)&e->heffDev, e->heffCap * (int64_t)sizeof(double) },
         { (void**)&e->gainDev, (e->P + 1) * (int64_t)sizeof(double) },
         { (void**)&e->tw512, e->P * (int64_t)sizeof(double2) },
@@ -345,7 +355,7 @@ void cpq_engine_destroy(cpq_engine* e)
         for (int i = 0; i < 4; ++i) { (void)hipEventDestroy(e->evIn[i]); (void)hipEventDestroy(e->evDone[i]); }
     }
     if (e->arena) (void)hipFree(e->arena);
-    for (double* p : { e->dryRing, e->latGains, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
+    for (double* p : { e->stageIn, e->stageOut, e->mid, e->dryRing, e->latGains, e->layerOut, e->tailRing, e->agcState, e->agcRmsIn, e->agcRmsOut, e->agcGains }) if (p) (void)hipFree(p);
     if (e->agcOn) (void)hipFree(e->agcOn);
     if (e->rampOn) (void)hipFree(e->rampOn);
     if (e->rampGains) (void)hipFree(e->rampGains);
@@ -468,7 +478,8 @@ static int enqueueBoth(cpq_engine* e, const double* a, double* b, int n)
     } else if (e->convBypassed) {
         rc = enqueueEq(e, a, b, n);
     } else {
-        rc = enqueueEq(e, a, e->mid, n);
+        rc = ensureCallBuffer(e, &e->mid, "EQ -> convolver hand-off");
+        if (rc == CPQ_OK) rc = enqueueEq(e, a, e->mid, n);
         if (rc == CPQ_OK && e->anyTrim) {       // scaleBlockFallback(block, convolverInputTrimGain) (:440-447)
             ProfScope p(e, CPQ_K_MIX);
             cpq::launch_rows_scale(e->stream, e->mid, n, n, e->nCh, e->trimDev);

@@ -112,7 +112,7 @@ struct cpq_engine {
     double2* HDN = nullptr;     // [nCh][hRows]
     double2* Y = nullptr;       // [nCh][tMax][e->P]            accumulated output spectra of the call
     double* hist[2] = { nullptr, nullptr };   // [nCh][e->P]    overlap history, ping-pong
-    double* stageIn = nullptr;  // [nCh][tMax*e->P]             staging for the host-pointer entry points
+    double* stageIn = nullptr;  // [nCh][tMax*e->P]             staging for the host-pointer entry points (allocated on first use)
     double* stageOut = nullptr;
     double* mid = nullptr;      // [nCh][tMax*e->P]             conv <-> EQ hand-off (not used when in place)
     double* heffDev = nullptr;  // staging for one h_eff upload
@@ -309,6 +309,7 @@ struct ProfScope {
 
 
 int checkCall(cpq_engine* e, const void* in, const void* out, int nSamples);
+int ensureCallBuffer(cpq_engine* e, double** buf, const char* what);
 int zeroRuntimeState(cpq_engine* e, bool conv, bool eq);
 
 // engine_native.cpp
@@ -343,6 +344,9 @@ int viaStaging(cpq_engine* e, const double* in, double* out, int nSamples, F&& b
     int rc = checkCall(e, in, out, nSamples);
     if (rc != CPQ_OK) return rc;
     CPQ_HIP(e, hipSetDevice(e->device));
+    rc = ensureCallBuffer(e, &e->stageIn, "upload staging");
+    if (rc == CPQ_OK) rc = ensureCallBuffer(e, &e->stageOut, "download staging");
+    if (rc != CPQ_OK) return rc;
     constexpr int kChunks = 4;
     const int T = nSamples / e->P;                                      // partitions in the call (whole ones outside CPQ_CALLS_ANY)
     auto pinned = [](const void* p) {

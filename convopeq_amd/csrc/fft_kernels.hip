@@ -629,15 +629,13 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) keep[q] = *reinterpret_cast<const double2*>(prev + 2 * (j + 512 * q));
     }
+    double2 nxt[4];             // the next block: requested ahead of this frame's spectrum stores (see the inverse kernel)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const double2*>(base + (int64_t)t0 * kP4 + 2 * (j + 512 * q));
     for (int t = t0; t < t1; ++t) {
         double2 v[8];
-        const double* cur = base + (int64_t)t * kP4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = keep[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[4 + q] = *reinterpret_cast<const double2*>(cur + 2 * (j + 512 * q));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) keep[q] = v[4 + q];
+        for (int q = 0; q < 4; ++q) { v[q] = keep[q]; v[4 + q] = nxt[q]; keep[q] = nxt[q]; }
         if (t == T - 1) {       // overlap history for the next call (prevInputBuf, NUC.cpp:1258)
             double* hn = histNew + (int64_t)c * kP4;
 #pragma unroll
@@ -654,6 +652,11 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
 #pragma unroll
         for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
         __syncthreads();
+        if (t + 1 < t1) {
+            const double* nb = base + (int64_t)(t + 1) * kP4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const double2*>(nb + 2 * (j + 512 * q));
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = j + 512 * q;
@@ -692,17 +695,24 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
     const int wr = wgp(j);
     const int rdm = wgp(kP4 - j);
     const int rd0 = wgp((kP4 - j) & (kP4 - 1));
-    for (int t = t0; t < t1; ++t) {
-        double2 v[8];
+    // the row is read from memory once (the mirrored element Y[4096 - k] of the real-FFT split comes from LDS; the generic
+    // kernels load it from global memory a second time).  The NEXT frame's row is requested at the end of a frame, ahead of
+    // that frame's output stores: memory operations retire in issue order, so loads issued behind the stores would wait for
+    // them as well; the prefetched registers are live across the loop edge only, not during the butterflies.
+    double2 nxt[8];
+    auto fetch = [&](int t) {
         const double2* y = ybase + (int64_t)t * kP4;
-        // the row is read from memory once; the mirrored element Y[4096 - k] of the real-FFT split comes from LDS
-        // (the generic kernels load it from global memory a second time: twice the load instructions for the same bytes).
-        // Requesting the next frame's row (or block, in the forward kernel) one frame ahead measured no faster.
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const v2d r = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(y + j + 512 * q));     // read once, written past the cache by the MAC
-            v[q] = make_double2(r.x, r.y);
+            nxt[q] = make_double2(r.x, r.y);
         }
+    };
+    fetch(t0);
+    for (int t = t0; t < t1; ++t) {
+        double2 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = nxt[q];
 #pragma unroll
         for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
         __syncthreads();
@@ -724,6 +734,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
         // second half of the 8192-sample frame: x[n], n = j + 512 q, q = 4..7 (NUC.cpp:1332)
         double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
         constexpr double s = 1.0 / (double)kP4;
+        if (t + 1 < t1) fetch(t + 1);
 #pragma unroll
         for (int q = 4; q < 8; ++q)
             *reinterpret_cast<double2*>(o + 2 * (j + 512 * (q - 4))) = make_double2(v[q].x * s, v[q].y * s);

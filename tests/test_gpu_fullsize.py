@@ -96,9 +96,9 @@ def test_config2_at_benchmark_size(amd, oracle):
 
 
 def test_config2_throughput_path_at_benchmark_size(amd, oracle):
-    """configs[1] on the time-batched throughput path: FFT partition 4096, 512 blocks (262144 samples) per call."""
-    worst = _run_fullsize(amd, oracle, 256, 131072, 512, True, amd.CPQ_SCHED_UNIFORM, partition=4096)
-    print("config 2 full size, P = 4096, 512 blocks per call: worst rms err", worst)
+    """configs[1] exactly as `python bench.py` times it: FFT partition 4096, 1024 blocks (524288 samples) per call."""
+    worst = _run_fullsize(amd, oracle, 256, 131072, 1024, True, amd.CPQ_SCHED_UNIFORM, partition=4096)
+    print("config 2 full size, P = 4096, 1024 blocks per call: worst rms err", worst)
 
 
 def test_config2_convolver_only_at_benchmark_size(amd, oracle):
@@ -121,3 +121,10 @@ def test_config5_share_at_benchmark_size(amd, oracle):
     """The per-GPU share of BASELINE.json configs[4]: 1024 streams, 131072 taps, conv + EQ (~14 GB arena)."""
     worst = _run_fullsize(amd, oracle, 1024, 131072, 64, True, amd.CPQ_SCHED_UNIFORM)
     print("config 5 share full size: worst rms err", worst)
+
+
+def test_config5_share_on_the_throughput_path(amd, oracle):
+    """The same share as `python bench.py --gpus N` runs it on every rank: P = 4096, 256 blocks per call here (the bench's
+    1024 would need 34 GB of host arrays for the two calls of this test; the engine's addressing is the same)."""
+    worst = _run_fullsize(amd, oracle, 1024, 131072, 256, True, amd.CPQ_SCHED_UNIFORM, partition=4096)
+    print("config 5 share, P = 4096: worst rms err", worst)
