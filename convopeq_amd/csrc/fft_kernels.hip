@@ -24,6 +24,27 @@ __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
 // a * w (INV = false) or a * conj(w) (INV = true)
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+
+// exp(-2 pi i q / 16), q < 8 (correctly rounded constants)
+__device__ __forceinline__ double2 w16(int q)
+{
+    constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, r = 0.70710678118654752440;
+    switch (q) {
+        case 0: return make_double2(1.0, 0.0);
+        case 1: return make_double2(c1, -s1);
+        case 2: return make_double2(r, -r);
+        case 3: return make_double2(s1, -c1);
+        case 4: return make_double2(0.0, -1.0);
+        case 5: return make_double2(-s1, -c1);
+        case 6: return make_double2(-r, -r);
+        default: return make_double2(-c1, -s1);
+    }
+}
+
 template <bool INV>
 __device__ __forceinline__ double2 cmulw(double2 a, double2 w)
 {
@@ -77,13 +98,21 @@ constexpr int kLdsPerWave = 72 * 8;   // complex elements
 //   pass 3 over c.
 // twStride: tw512[m * twStride] = exp(-2 pi i m / 512) (1 for the 512-entry table; P / 512 when the table is the
 // P-entry one of a larger partition)
+// tab (optional, LDS): 128 entries filled by wave_fill_tables -- the twiddles of both passes factor over the octal digits
+// of the lane: W512^(lane p) = W512^(p (lane & 7)) W64^(p (lane >> 3)), W64^(c q) -- so no pass waits for a dependent
+// trip to L2 behind an exchange (7 + 7 loads of 16 bytes per lane and frame otherwise)
 template <bool INV>
 __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, const double2* __restrict__ tw512,
-                                             int lane, int twStride = 1)
+                                             int lane, int twStride = 1, const double2* tab = nullptr)
 {
     dft8<INV>(v);
+    if (tab) {
 #pragma unroll
-    for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], tw512[lane * p * twStride]);
+        for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], cmul(tab[64 + (lane & 7) * 8 + p], tab[(lane >> 3) * 8 + p]));
+    } else {
+#pragma unroll
+        for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], tw512[lane * p * twStride]);
+    }
 #pragma unroll
     for (int p = 0; p < 8; ++p) lds[72 * p + lane] = v[p];
     __syncthreads();
@@ -92,8 +121,13 @@ __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, cons
     for (int b = 0; b < 8; ++b) v[b] = lds[72 * pp + 8 * b + cc];
     __syncthreads();
     dft8<INV>(v);
+    if (tab) {
 #pragma unroll
-    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tw512[8 * cc * q * twStride]);
+        for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tab[cc * 8 + q]);
+    } else {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tw512[8 * cc * q * twStride]);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) lds[66 * cc + pp + 8 * q] = v[q];
     __syncthreads();
@@ -102,8 +136,18 @@ __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, cons
     dft8<INV>(v);
 }
 
+// tab[d * 8 + p] = W64^(p d), tab[64 + d * 8 + p] = W512^(p d) from the 512-entry table (one wave: two loads per lane,
+// issued with the frame's own loads)
+__device__ __forceinline__ void wave_fill_tables(double2* tab, const double2* __restrict__ tw512, int lane)
+{
+    const int d = lane >> 3, p = lane & 7;
+    tab[lane] = tw512[8 * p * d];
+    tab[64 + lane] = tw512[p * d];
+    __syncthreads();            // one-wave workgroups: a wave barrier
+}
+
 // real-FFT split: Z (512-pt FFT of even+i*odd samples) -> packed spectrum of the 1024-pt real frame
-__device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, const double2* __restrict__ tw1024,
+__device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, double2 wl,
                                                  int lane, double2* __restrict__ spec, double2* __restrict__ dcnyq)
 {
     __syncthreads();
@@ -118,7 +162,7 @@ __device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, 
         const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Z[k] + conj Z[512-k]) / 2
         const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));   // (Z[k] - conj Z[512-k]) / 2
         const double2 o = make_double2(d.y, -d.x);                                  // -i d
-        const double2 w = tw1024[k];
+        const double2 w = cmul(wl, w16(r));                                         // exp(-2 pi i (lane + 64 r) / 1024)
         double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
         if (k == 0) {
             xk = make_double2(zk.x + zk.y, zk.x - zk.y);   // (DC, Nyquist)
@@ -137,11 +181,14 @@ __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ 
                                                      int ringMask)
 {
     __shared__ double2 lds[kLdsPerWave];
+    __shared__ double2 tab[128];
     const int lane = threadIdx.x;
     const int c = blockIdx.x / T;
     const int t = blockIdx.x - c * T;
     const double* cur = in + (int64_t)c * chStride + (int64_t)t * kP;
     const double* prev = (t > 0) ? (cur - kP) : (histOld + (int64_t)c * kP);
+    wave_fill_tables(tab, tw.tw512, lane);
+    const double2 wl = tw.tw1024[lane];
 
     double2 v[8];
 #pragma unroll
@@ -153,18 +200,21 @@ __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(hn + 2 * (lane + 64 * j)) = v[4 + j];
     }
-    wave_cfft512<false>(v, lds, tw.tw512, lane);
+    wave_cfft512<false>(v, lds, tw.tw512, lane, 1, tab);
     const int slot = (head + t) & ringMask;
     const int64_t row = (int64_t)c * (ringMask + 1) + slot;
-    wave_split_store(v, lds, tw.tw1024, lane, X + row * kP, XDN + row);
+    wave_split_store(v, lds, wl, lane, X + row * kP, XDN + row);
 }
 
 __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ heff, int heffLen,
                                                    double2* __restrict__ H, double2* __restrict__ HDN, FftTables tw)
 {
     __shared__ double2 lds[kLdsPerWave];
+    __shared__ double2 tab[128];
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
+    wave_fill_tables(tab, tw.tw512, lane);
+    const double2 wl = tw.tw1024[lane];
     double2 v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -173,18 +223,21 @@ __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ he
     }
 #pragma unroll
     for (int j = 4; j < 8; ++j) v[j] = make_double2(0.0, 0.0);   // zero-padded second half (NUC.cpp:921-928)
-    wave_cfft512<false>(v, lds, tw.tw512, lane);
-    wave_split_store(v, lds, tw.tw1024, lane, H + (int64_t)k * kP, HDN + k);
+    wave_cfft512<false>(v, lds, tw.tw512, lane, 1, tab);
+    wave_split_store(v, lds, wl, lane, H + (int64_t)k * kP, HDN + k);
 }
 
 __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__ Y, double* __restrict__ out,
                                                      int64_t chStride, FftTables tw, int T)
 {
     __shared__ double2 lds[kLdsPerWave];
+    __shared__ double2 tab[128];
     const int lane = threadIdx.x;
     const int c = blockIdx.x / T;
     const int t = blockIdx.x - c * T;
     const double2* y = Y + (int64_t)blockIdx.x * kP;
+    wave_fill_tables(tab, tw.tw512, lane);
+    const double2 wl = tw.tw1024[lane];
 
     double2 v[8];
     const double2 y0 = y[0];
@@ -195,13 +248,13 @@ __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__
         const double2 ym = y[(512 - k) & 511];
         const double2 e = make_double2(0.5 * (yk.x + ym.x), 0.5 * (yk.y - ym.y));
         const double2 d = make_double2(0.5 * (yk.x - ym.x), 0.5 * (yk.y + ym.y));
-        const double2 w = tw.tw1024[k];
+        const double2 w = cmul(wl, w16(j));                                                     // exp(-2 pi i (lane + 64 j) / 1024)
         const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));   // d * conj(w)
         double2 z = make_double2(e.x - o.y, e.y + o.x);                                          // E + i O
         if (k == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
         v[j] = z;
     }
-    wave_cfft512<true>(v, lds, tw.tw512, lane);
+    wave_cfft512<true>(v, lds, tw.tw512, lane, 1, tab);
     // second half of the 1024-sample frame: z[n], n = lane + 64 r, r = 4..7  (NUC.cpp:1332)
     double* o = out + (int64_t)c * chStride + (int64_t)t * kP;
     constexpr double s = 1.0 / 512.0;
@@ -522,22 +575,6 @@ constexpr int kP4 = 4096;
 //   ns = 512 (k = d0 + 8 d1 + 64 d2): T3[d0][q] T2[d1][q] T1[d2][q]
 // The table loads (21 per thread and frame, each a dependent L2 round trip right before its butterfly, behind a
 // barrier) were what the kernel waited for; the products cost 4 / 8 flops per point and ~2 ulp in the twiddle.
-// exp(-2 pi i q / 16), q < 8 (correctly rounded constants)
-__device__ __forceinline__ double2 p4_w16(int q)
-{
-    constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, r = 0.70710678118654752440;
-    switch (q) {
-        case 0: return make_double2(1.0, 0.0);
-        case 1: return make_double2(c1, -s1);
-        case 2: return make_double2(r, -r);
-        case 3: return make_double2(s1, -c1);
-        case 4: return make_double2(0.0, -1.0);
-        case 5: return make_double2(-s1, -c1);
-        case 6: return make_double2(-r, -r);
-        default: return make_double2(-c1, -s1);
-    }
-}
-
 struct P4Tables { double2 t[3][8][8]; };
 
 __device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __restrict__ twM)
@@ -548,11 +585,6 @@ __device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __res
         T->t[tb][d][q] = twM[step * q * d];
     }
     __syncthreads();
-}
-
-__device__ __forceinline__ double2 cmul(double2 a, double2 b)
-{
-    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
 
 template <bool INV>
@@ -665,7 +697,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
             const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
             const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
             const double2 o = make_double2(d.y, -d.x);
-            const double2 w = cmul(wj, p4_w16(q));
+            const double2 w = cmul(wj, w16(q));
             double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
             if (k == 0) {
                 xk = make_double2(zk.x + zk.y, zk.x - zk.y);
@@ -723,7 +755,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
             const double2 b = dyn[q == 0 ? rd0 : rdm - 576 * q];
             const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
             const double2 d = make_double2(0.5 * (a.x - b.x), 0.5 * (a.y + b.y));
-            const double2 w = cmul(wj, p4_w16(q));
+            const double2 w = cmul(wj, w16(q));
             const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
             double2 z = make_double2(e.x - o.y, e.y + o.x);
             if (k == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
