@@ -101,10 +101,22 @@ constexpr int kLdsPerWave = 72 * 8;   // complex elements
 // tab (optional, LDS): 128 entries filled by wave_fill_tables -- the twiddles of both passes factor over the octal digits
 // of the lane: W512^(lane p) = W512^(p (lane & 7)) W64^(p (lane >> 3)), W64^(c q) -- so no pass waits for a dependent
 // trip to L2 behind an exchange (7 + 7 loads of 16 bytes per lane and frame otherwise)
-template <bool INV>
+// LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the compiler
+// from moving them across each other
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// WAVE: the wave is part of a larger workgroup and `lds` is its private slice: wave-level synchronisation instead of
+// workgroup barriers
+template <bool INV, bool WAVE = false>
 __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, const double2* __restrict__ tw512,
                                              int lane, int twStride = 1, const double2* tab = nullptr)
 {
+    auto sync = [] { if (WAVE) wave_sync(); else __syncthreads(); };
     dft8<INV>(v);
     if (tab) {
 #pragma unroll
@@ -115,11 +127,11 @@ __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, cons
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) lds[72 * p + lane] = v[p];
-    __syncthreads();
+    sync();
     const int pp = lane >> 3, cc = lane & 7;
 #pragma unroll
     for (int b = 0; b < 8; ++b) v[b] = lds[72 * pp + 8 * b + cc];
-    __syncthreads();
+    sync();
     dft8<INV>(v);
     if (tab) {
 #pragma unroll
@@ -130,7 +142,7 @@ __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, cons
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) lds[66 * cc + pp + 8 * q] = v[q];
-    __syncthreads();
+    sync();
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = lds[66 * c + lane];
     dft8<INV>(v);
@@ -558,23 +570,28 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// P = 4096 (8192-point real frames), the partition of the time-batched throughput path: 4096 = 8^4, so with 512 threads
-// thread j owns points j + 512 q of every radix-8 stage's input AND of the last stage's output.  That removes two of the
-// LDS round trips of the generic workgroup kernels above (the frame goes from global memory straight into the first
-// butterflies, the inverse's last butterflies straight to global memory), and a workgroup walks consecutive frames of one
-// channel: the loads of frame t + 1 are issued before the butterflies of frame t (the kernels are pure streaming kernels:
-// load latency was exposed once per frame), and the forward transform reads every input block ONCE -- the second half of
-// frame t is the first half of frame t + 1, in the same registers.
+// P = 4096 (8192-point real frames), the partition of the time-batched throughput path.  Four-step transform of the
+// 4096 complex points z[n], n = n2 + 512 n1, inside ONE workgroup of eight waves, built on the wave-level 512-point
+// transform above (which streams at 5-6 TB/s, twice what a Stockham pipeline with a workgroup barrier behind every stage
+// reached at this size):
+//   1. thread j = n2 holds z[j + 512 q], q < 8 (coalesced loads): 8-point DFT over n1 in registers, times W4096^(j k1)
+//   2. ONE workgroup-level exchange hands row k1 (512 values) to wave k1
+//   3. wave k1: 512-point transform over n2 in its own 9 KB slice of the exchange buffer (wave-local exchanges only)
+//      -> Z[k1 + 8 k2]
+// The spectrum is stored PERMUTED, element k1 * 512 + k2 = bin k1 + 8 k2 (contiguous per wave: coalesced stores), like
+// the larger partitions below: the MAC is element-wise and the forward, IR and inverse transforms agree on it; element 0
+// is still the packed (DC, Nyquist).  The real-FFT split pairs (k1, k2) with (8 - k1, 511 - k2) for k1 > 0 and with
+// (0, (512 - k2) mod 512) for k1 = 0: a second exchange between partner waves.  Three workgroup barriers per frame
+// (four in the inverse) instead of eight: forward 1.38 -> 1.33 ms, inverse 1.88 -> 1.70 ms per 1024-block call of 256 streams
+// (starting the CU's second workgroup half a frame late changed nothing).  A workgroup walks consecutive frames of one channel; the forward transform
+// keeps the half frame that frames t and t + 1 share in registers (every input block is read once).
+// Twiddles never come from global memory inside the loop: W4096^(j k1) factors over the octal digits of j into entries of
+// three 8 x 8 tables in LDS (3 KB, filled once per workgroup from the engine's extended-precision table; the first two
+// are also the tables of the wave-level transform), the split twiddle is one per-thread constant times W16^r.
 constexpr int kP4 = 4096;
+constexpr int kP4Row = kLdsPerWave;     // 576: row stride of the exchange buffer = one wave's scratch slice
 
-// Twiddles of the three later stages without a trip to global memory: W4096^(q k tstep) with k = j mod ns factors over
-// the octal digits of k into entries of three 8 x 8 tables in LDS (3 KB, filled once per workgroup from the engine's
-// extended-precision table):  T1[d][q] = W64^(q d),  T2[d][q] = W512^(q d),  T3[d][q] = W4096^(q d).
-//   ns = 8   (k = d0):              T1[d0][q]
-//   ns = 64  (k = d0 + 8 d1):       T2[d0][q] T1[d1][q]
-//   ns = 512 (k = d0 + 8 d1 + 64 d2): T3[d0][q] T2[d1][q] T1[d2][q]
-// The table loads (21 per thread and frame, each a dependent L2 round trip right before its butterfly, behind a
-// barrier) were what the kernel waited for; the products cost 4 / 8 flops per point and ~2 ulp in the twiddle.
+// t[0][d][q] = W64^(q d), t[1][d][q] = W512^(q d), t[2][d][q] = W4096^(q d)
 struct P4Tables { double2 t[3][8][8]; };
 
 __device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __restrict__ twM)
@@ -587,55 +604,62 @@ __device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __res
     __syncthreads();
 }
 
+// v[k1] *= W4096^(+-j k1)
 template <bool INV>
-__device__ __forceinline__ void p4_twiddle(double2 (&v)[8], const P4Tables* T, int st, int j)
+__device__ __forceinline__ void p4_twiddle(double2 (&v)[8], const P4Tables* T, int j)
 {
     const int d0 = j & 7, d1 = (j >> 3) & 7, d2 = (j >> 6) & 7;
 #pragma unroll
-    for (int q = 1; q < 8; ++q) {
-        double2 w;
-        if (st == 1) w = T->t[0][d0][q];
-        else if (st == 2) w = cmul(T->t[1][d0][q], T->t[0][d1][q]);
-        else w = cmul(cmul(T->t[2][d0][q], T->t[1][d1][q]), T->t[0][d2][q]);
-        v[q] = cmulw<INV>(v[q], w);
-    }
+    for (int q = 1; q < 8; ++q)
+        v[q] = cmulw<INV>(v[q], cmul(cmul(T->t[2][d0][q], T->t[1][d1][q]), T->t[0][d2][q]));
 }
 
-// One exchange through LDS: thread j leaves its 8 values at padded elements wr + q wrStep and takes the 8 at rd + q rdStep
-// (every index pattern of the four radix-8 stages is base + q * constant in the padded buffer: wgp(i + 8 m) = wgp(i) + 9 m).
-// Measured and not kept: the real and imaginary parts through a half-size buffer one after the other (36 KB: three or four
-// workgroups per CU at 80 / 64 registers) -- twice the barriers and the spills cost more than the occupancy gave
-// (forward 1.19 / 1.29 ms against 1.04 ms per 512-block call at 256 streams).
-__device__ __forceinline__ void p4_exchange(double2 (&v)[8], double2* lds, int wr, int wrStep, int rd, int rdStep)
+// partner of element (w, k2) in the real-FFT split, as an index into the exchange buffer
+__device__ __forceinline__ int p4_partner(int w, int k2)
 {
+    return w == 0 ? ((512 - k2) & 511) : (8 - w) * kP4Row + (511 - k2);
+}
+
+// one forward frame: in v = z[j + 512 q]; out: the packed spectrum row (permuted) and its (DC, Nyquist) element
+__device__ __forceinline__ void p4_forward_frame(double2 (&v)[8], double2* dyn, const P4Tables* tabs, double2 wk,
+                                                 double2* __restrict__ spec, double2* __restrict__ dcnyq)
+{
+    const int j = threadIdx.x, w = j >> 6, lane = j & 63;
+    dft8<false>(v);
+    p4_twiddle<false>(v, tabs, j);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) lds[wr + q * wrStep] = v[q];
+    for (int k1 = 0; k1 < 8; ++k1) dyn[k1 * kP4Row + j] = v[k1];
+    __syncthreads();
+    double2* mine = dyn + w * kP4Row;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = mine[lane + 64 * m];
+    wave_sync();                            // this wave's reads before it reuses its slice as scratch
+    wave_cfft512<false, true>(v, mine, nullptr, lane, 1, &tabs->t[0][0][0]);
+    // v[r] = Z[w + 8 (lane + 64 r)]; the split needs the partner wave's row
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mine[lane + 64 * r] = v[r];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = lds[rd + q * rdStep];
-    __syncthreads();
-}
-
-// the three LDS exchanges between the four radix-8 stages; in: v = points j + 512 q, out: v = Z[j + 512 q].
-// A rolled loop over the stages: fully unrolled, the compiler hoists every stage's twiddle loads and the kernel no longer
-// fits the register budget of two (let alone three or four) workgroups per CU.
-template <bool INV>
-__device__ __forceinline__ void p4_cfft(double2 (&v)[8], double2* lds, const P4Tables* T)
-{
-    const int j = threadIdx.x;
-    const int rd = wgp(j);                                      // wgp(j + 512 q) = wgp(j) + 576 q
-#pragma unroll 1
-    for (int st = 0; st < 4; ++st) {
-        const int ns = 1 << (3 * st);
-        const int k = j & (ns - 1);
-        if (st > 0) p4_twiddle<INV>(v, T, st, j);
-        dft8<INV>(v);
-        if (st < 3) p4_exchange(v, lds, wgp(((j - k) << 3) + k), ns + (ns >> 3), rd, 576);     // wgp(o + q ns) = wgp(o) + q (ns + ns / 8), ns >= 8; ns = 1: 9 j + q
+    for (int r = 0; r < 8; ++r) {
+        const int k2 = lane + 64 * r;
+        const double2 zk = v[r];
+        const double2 zm = dyn[p4_partner(w, k2)];
+        const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Z[k] + conj Z[4096-k]) / 2
+        const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));   // (Z[k] - conj Z[4096-k]) / 2
+        const double2 o = make_double2(d.y, -d.x);                                  // -i d
+        const double2 tw = cmul(wk, w16(r));                                        // exp(-2 pi i (w + 8 lane + 512 r) / 8192)
+        double2 xk = make_double2(e.x + fma(o.x, tw.x, -(o.y * tw.y)), e.y + fma(o.x, tw.y, o.y * tw.x));
+        if (w == 0 && k2 == 0) {
+            xk = make_double2(zk.x + zk.y, zk.x - zk.y);   // (DC, Nyquist)
+            *dcnyq = xk;
+        }
+        // one 16-byte streaming store per lane: an FDL row is next read by the MAC, never from cache
+        __builtin_nontemporal_store(v2d{ xk.x, xk.y }, reinterpret_cast<v2d*>(spec + w * 512 + k2));
     }
+    __syncthreads();                        // the partners are done with this wave's slice before the next frame writes
 }
 
-// A workgroup walks consecutive frames of one channel and keeps the second half of frame t (= first half of frame t + 1)
-// in registers, so every input block is read once.  Two workgroups per CU (72 KB of LDS each).
 __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __restrict__ in, int64_t chStride,
                                                           const double* __restrict__ histOld,
                                                           double* __restrict__ histNew, double2* __restrict__ X,
@@ -651,8 +675,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
     const int t0 = part * per, t1 = min(T, t0 + per);
     if (t0 >= t1) return;
     p4_load_tables(&tabs, tw.tw512);
-    // split twiddle exp(-2 pi i (j + 512 q) / 8192) = exp(-2 pi i j / 8192) W16^q: one load per thread for the whole walk
-    const double2 wj = tw.tw1024[j];
+    const double2 wk = tw.tw1024[(j >> 6) + 8 * (j & 63)];
     const double* base = in + (int64_t)c * chStride;
     // frame t = [block t-1 | block t]; thread j holds complex points n = j + 512 q: n < 2048 from the previous block
     double2 keep[4];
@@ -661,112 +684,102 @@ __global__ __launch_bounds__(512, 4) void k_rfft_fwd_ols_p4(const double* __rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) keep[q] = *reinterpret_cast<const double2*>(prev + 2 * (j + 512 * q));
     }
-    double2 nxt[4];             // the next block: requested ahead of this frame's spectrum stores (see the inverse kernel)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const double2*>(base + (int64_t)t0 * kP4 + 2 * (j + 512 * q));
     for (int t = t0; t < t1; ++t) {
         double2 v[8];
+        const double* cur = base + (int64_t)t * kP4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v[q] = keep[q]; v[4 + q] = nxt[q]; keep[q] = nxt[q]; }
+        for (int q = 0; q < 4; ++q) v[q] = keep[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[4 + q] = *reinterpret_cast<const double2*>(cur + 2 * (j + 512 * q));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] = v[4 + q];
         if (t == T - 1) {       // overlap history for the next call (prevInputBuf, NUC.cpp:1258)
             double* hn = histNew + (int64_t)c * kP4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(hn + 2 * (j + 512 * q)) = v[4 + q];
         }
-        p4_cfft<false>(v, dyn, &tabs);
-        // real-FFT split: Z[k] with Z[4096 - k], one more trip through LDS; wgp(4096 - j - 512 q) = wgp(4096 - j) - 576 q
         const int slot = (head + t) & ringMask;
         const int64_t row = (int64_t)c * (ringMask + 1) + slot;
-        double2* spec = X + row * kP4;
-        const int wr = wgp(j);
-        const int rdm = wgp(kP4 - j);
-        const int rd0 = wgp((kP4 - j) & (kP4 - 1));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
-        __syncthreads();
-        if (t + 1 < t1) {
-            const double* nb = base + (int64_t)(t + 1) * kP4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const double2*>(nb + 2 * (j + 512 * q));
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = j + 512 * q;
-            const double2 zk = v[q];
-            const double2 zm = dyn[q == 0 ? rd0 : rdm - 576 * q];
-            const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-            const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
-            const double2 o = make_double2(d.y, -d.x);
-            const double2 w = cmul(wj, w16(q));
-            double2 xk = make_double2(e.x + fma(o.x, w.x, -(o.y * w.y)), e.y + fma(o.x, w.y, o.y * w.x));
-            if (k == 0) {
-                xk = make_double2(zk.x + zk.y, zk.x - zk.y);
-                XDN[row] = xk;
-            }
-            // one 16-byte streaming store per lane (two 8-byte ones leave half-written lines to the write combiner)
-            __builtin_nontemporal_store(v2d{ xk.x, xk.y }, reinterpret_cast<v2d*>(spec + k));
-        }
-        __syncthreads();                    // the next frame's first exchange reuses the buffer
+        p4_forward_frame(v, dyn, &tabs, wk, X + row * kP4, XDN + row);
     }
 }
 
-__global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __restrict__ Y, double* __restrict__ out,
-                                                              int64_t chStride, FftTables tw, int T, int split)
+// IR partition spectra at P = 4096: frames [h[k P .. (k+1) P) | 0], same permuted layout
+__global__ __launch_bounds__(512, 4) void k_ir_spectra_p4(const double* __restrict__ heff, int heffLen,
+                                                        double2* __restrict__ H, double2* __restrict__ HDN, FftTables tw)
 {
     extern __shared__ double2 dyn[];
     __shared__ P4Tables tabs;
     const int j = threadIdx.x;
+    const int k = blockIdx.x;
+    p4_load_tables(&tabs, tw.tw512);
+    const double2 wk = tw.tw1024[(j >> 6) + 8 * (j & 63)];
+    double2 v[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = k * kP4 + 2 * (j + 512 * q);
+        v[q] = make_double2(i < heffLen ? heff[i] : 0.0, (i + 1) < heffLen ? heff[i + 1] : 0.0);
+        v[4 + q] = make_double2(0.0, 0.0);          // zero-padded second half (NUC.cpp:921-928)
+    }
+    p4_forward_frame(v, dyn, &tabs, wk, H + (int64_t)k * kP4, HDN + k);
+}
+
+__global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __restrict__ Y, double* __restrict__ out,
+                                                          int64_t chStride, FftTables tw, int T, int split)
+{
+    extern __shared__ double2 dyn[];
+    __shared__ P4Tables tabs;
+    const int j = threadIdx.x, w = j >> 6, lane = j & 63;
     const int c = blockIdx.x / split;
     const int part = blockIdx.x - c * split;
     const int per = (T + split - 1) / split;
     const int t0 = part * per, t1 = min(T, t0 + per);
     if (t0 >= t1) return;
     p4_load_tables(&tabs, tw.tw512);
-    const double2 wj = tw.tw1024[j];
+    const double2 wk = tw.tw1024[w + 8 * lane];
     const double2* ybase = Y + (int64_t)c * T * kP4;
-    const int wr = wgp(j);
-    const int rdm = wgp(kP4 - j);
-    const int rd0 = wgp((kP4 - j) & (kP4 - 1));
-    // the row is read from memory once (the mirrored element Y[4096 - k] of the real-FFT split comes from LDS; the generic
-    // kernels load it from global memory a second time).  The NEXT frame's row is requested at the end of a frame, ahead of
-    // that frame's output stores: memory operations retire in issue order, so loads issued behind the stores would wait for
-    // them as well; the prefetched registers are live across the loop edge only, not during the butterflies.
-    double2 nxt[8];
-    auto fetch = [&](int t) {
-        const double2* y = ybase + (int64_t)t * kP4;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const v2d r = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(y + j + 512 * q));     // read once, written past the cache by the MAC
-            nxt[q] = make_double2(r.x, r.y);
-        }
-    };
-    fetch(t0);
+    double2* mine = dyn + w * kP4Row;
     for (int t = t0; t < t1; ++t) {
         double2 v[8];
+        const double2* y = ybase + (int64_t)t * kP4 + w * 512;
+        // wave w reads its row of the permuted spectrum once (streaming: the MAC wrote it past the cache); the partner
+        // element Y[4096 - k] of the real-FFT split comes through LDS
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = nxt[q];
+        for (int r = 0; r < 8; ++r) {
+            const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(y + lane + 64 * r));
+            v[r] = make_double2(a.x, a.y);
+        }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dyn[wr + 576 * q] = v[q];
+        for (int r = 0; r < 8; ++r) mine[lane + 64 * r] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = j + 512 * q;
-            const double2 a = v[q];
-            const double2 b = dyn[q == 0 ? rd0 : rdm - 576 * q];
+        for (int r = 0; r < 8; ++r) {
+            const int k2 = lane + 64 * r;
+            const double2 a = v[r];
+            const double2 b = dyn[p4_partner(w, k2)];
             const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
             const double2 d = make_double2(0.5 * (a.x - b.x), 0.5 * (a.y + b.y));
-            const double2 w = cmul(wj, w16(q));
-            const double2 o = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -(d.x * w.y)));
-            double2 z = make_double2(e.x - o.y, e.y + o.x);
-            if (k == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
-            v[q] = z;
+            const double2 tk = cmul(wk, w16(r));
+            const double2 o = make_double2(fma(d.x, tk.x, d.y * tk.y), fma(d.y, tk.x, -(d.x * tk.y)));   // d * conj(w)
+            double2 z = make_double2(e.x - o.y, e.y + o.x);                                              // E + i O
+            if (w == 0 && k2 == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
+            v[r] = z;
         }
-        __syncthreads();                    // every mirrored read is done before the first exchange writes
-        p4_cfft<true>(v, dyn, &tabs);
-        // second half of the 8192-sample frame: x[n], n = j + 512 q, q = 4..7 (NUC.cpp:1332)
+        __syncthreads();                    // every partner read is done before a wave reuses its slice as scratch
+        wave_cfft512<true, true>(v, mine, nullptr, lane, 1, &tabs.t[0][0][0]);
+        // v[m] = C[w][lane + 64 m]: hand column n2 = j to thread j
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mine[lane + 64 * m] = v[m];
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) v[k1] = dyn[k1 * kP4Row + j];
+        __syncthreads();                    // the next frame's row writes reuse the buffer
+        p4_twiddle<true>(v, &tabs, j);
+        dft8<true>(v);
+        // second half of the 8192-sample frame: x[n], n = j + 512 n1, n1 = 4..7 (NUC.cpp:1332)
         double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
         constexpr double s = 1.0 / (double)kP4;
-        if (t + 1 < t1) fetch(t + 1);
 #pragma unroll
         for (int q = 4; q < 8; ++q)
             *reinterpret_cast<double2*>(o + 2 * (j + 512 * (q - 4))) = make_double2(v[q].x * s, v[q].y * s);
@@ -1012,13 +1025,13 @@ __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict_
 
 // H[k][bin] *= gain[bin] for the IR partition spectra of one IR slot (the HC/LC spectral shaping of a non-NULL
 // FilterSpec, src/MKLNonUniformConvolver.cpp:433-441); packed bin 0 = (DC * gain[0], Nyquist * gain[P])
-// Above P = 4096 the spectra are stored permuted (element k1 * 512 + k2 holds bin k1 + (P / 512) k2, see k_big_*).
+// From P = 4096 up the spectra are stored permuted (element k1 * 512 + k2 holds bin k1 + (P / 512) k2, see k_*_p4 / k_big_*).
 __global__ __launch_bounds__(256) void k_spectrum_gain(double2* __restrict__ H, double2* __restrict__ HDN,
                                                        const double* __restrict__ gain, int P)
 {
     const int k = blockIdx.x;
     double2* row = H + (int64_t)k * P;
-    const int M1 = (P > 4096) ? (P >> 9) : 0;
+    const int M1 = (P >= 4096) ? (P >> 9) : 0;
     for (int e = threadIdx.x; e < P; e += blockDim.x) {
         const int b = M1 ? ((e >> 9) + M1 * (e & 511)) : e;      // bin of element e
         double2 v = row[e];
@@ -1093,7 +1106,10 @@ void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, doub
     }
     if (P == kP)
         hipLaunchKernelGGL(k_ir_spectra, dim3(nParts), dim3(64), 0, stream, heff, heffLen, H, HDN, tw);
-    else if (P >= 1024) {
+    else if (P == kP4) {
+        allowLargeLds(k_ir_spectra_p4, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_ir_spectra_p4, dim3(nParts), dim3(512), wgLdsBytes(P), stream, heff, heffLen, H, HDN, tw);
+    } else if (P >= 1024) {
         allowLargeLds(k_ir_spectra_wg, wgLdsBytes(P));
         hipLaunchKernelGGL(k_ir_spectra_wg, dim3(nParts), dim3(P / 8), wgLdsBytes(P), stream, heff, heffLen, H, HDN,
                            tw, P);
