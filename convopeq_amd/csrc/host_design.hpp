@@ -9,7 +9,7 @@ namespace cpq {
 
 // geometry of the time-parallel SVF kernel (svf_kernels.hip), shared with buildSvfTpTables()
 #ifndef CPQ_TP_WAVES
-#define CPQ_TP_WAVES 4          // waves per channel in k_svf_cascade_tp (4096-sample spans of 64*W chunks)
+#define CPQ_TP_WAVES 4          // waves per channel in k_svf_cascade_tp (512-sample spans of 64*W chunks; table slot 1)
 #endif
 constexpr int kSvfTpWaves = CPQ_TP_WAVES;
 constexpr int kSvfTpLc[2] = { 4096 / (64 * kSvfTpWaves), 512 / (64 * kSvfTpWaves) };

@@ -463,18 +463,18 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     s0x = dpp_f64<kDppWaveShr1, 0xF>(sx);
     s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
     if (lane == 0) { s0x = bx; s0y = by; }
-    if (tid == NTHREADS - 1) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }     // end of the span
+    if (tid == (NTHREADS ? NTHREADS : (int)blockDim.x) - 1) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }     // end of the span
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
 // with every guard, used when the span input or the carried state is outside the proven-safe range.
 template <int KIND>
-__device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sat, double* sState)
+__device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sat, double* sState, int nChunks = kTpChunks)
 {
     const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
     const double oneMinusSat = 1.0 - sat;
     double ic1 = sState[0], ic2 = sState[1];
-    for (int c = 0; c < kTpChunks; ++c)
+    for (int c = 0; c < nChunks; ++c)
         for (int i = 0; i < lc; ++i) {
             double y[1] = { buf[c * kTpStride + i] };
             tp_recur<KIND, 1>(y, ic1, ic2, a1, a2, a3, m0, m1, m2);
@@ -666,27 +666,27 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// tables of the matrix form -> LDS (nThreads = threads of the workgroup); the caller synchronises
 __device__ __forceinline__ void tp_load_tables_m(TpLdsM* L, const double* __restrict__ cf,
-                                                 const TpBandTables* __restrict__ tb, int tid)
+                                                 const TpBandTables* __restrict__ tb, int tid, int nThreads)
 {
-    for (int i = tid; i < kBands * 6; i += kTpChunks) L->cf[i / 6][i % 6] = cf[i];
-    for (int i = tid; i < kBands * 28; i += kTpChunks) {
+    for (int i = tid; i < kBands * 6; i += nThreads) L->cf[i / 6][i % 6] = cf[i];
+    for (int i = tid; i < kBands * 28; i += nThreads) {
         const int b = i / 28, q = i % 28;
         L->M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
     }
-    for (int i = tid; i < kBands * 64; i += kTpChunks) {
+    for (int i = tid; i < kBands * 64; i += nThreads) {
         const int b = i / 64, r = (i % 64) / 4, q = i % 4;
         L->Gq[b][r][q] = (q < 2) ? tb[b].t[0].G[r][q] : 0.0;
     }
-    for (int i = tid; i < kBands * 32; i += kTpChunks) {
+    for (int i = tid; i < kBands * 32; i += nThreads) {
         L->ht[i / 32][i % 32] = tb[i / 32].mm.ht[i % 32];
         L->e[i / 32][(i % 32) / 16][i % 16] = tb[i / 32].mm.e[(i % 32) / 16][i % 16];
     }
-    __syncthreads();
 }
 
 // The band loop of the matrix form: x = the wave's 64 chunks in the MFMA layout (in and out); red / s0q = the wave's LDS
-// scratch (256 double2 / 256 doubles); NTHREADS = threads of the workgroup (64 per wave of the span).
+// scratch (256 double2 / 256 doubles); NTHREADS = threads of the workgroup (64 per wave of the span; 0 = blockDim.x).
 // wtot: two parities of [2 * waves] wave totals (one workgroup barrier per band, see tp_scan).  A barrier-free variant
 // (totals published with per-band flags, waves polling only their predecessors) measured slower: 0.59 vs 0.58 ms.
 template <bool SAT, int NTHREADS>
@@ -705,9 +705,7 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
             if (!(flag & 1)) continue;                    // uniform
             const int kind = (flag >> 1) & 3;
             // tables of the band
-            constexpr bool kEarly = (NTHREADS == 256);        // four waves per channel: 256 registers, per-lane powers hoisted
-            TpLanePowers pw = {};
-            if (kEarly) pw = tp_load_powers(&tb[b].t[0].P[0][0], lane);
+            const TpLanePowers pw = {};                       // register-tight: tp_scan loads the per-lane powers where it uses them
             double a[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
@@ -792,8 +790,8 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
 #if defined(CPQ_ABL) && (CPQ_ABL & 2)
             s0x = ic1 * e0[1]; s0y = ic2 * e1[0];
 #else
-            tp_scan<NTHREADS>(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * (NTHREADS / 64), sState, sNext, tid,
-                              kEarly ? nullptr : &tb[b].t[0].P[0][0]);
+            tp_scan<NTHREADS>(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * ((NTHREADS ? NTHREADS : (int)blockDim.x) / 64), sState, sNext, tid,
+                              &tb[b].t[0].P[0][0]);
             par ^= 1;
 #endif
             // (4) the state response G s0 completes the product (k-step 4: rows 16 + g of [x ; s0], staged through the
@@ -826,72 +824,6 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
         }
 }
 
-template <bool SAT>
-__device__ __forceinline__ void tp_span_mfma(const double* in, double* out, double* buf, double* wtot, double*& sState,
-                                             double*& sNext, int* sFlag, const TpLdsM* L, int tid, const int* __restrict__ fl,
-                                             const TpBandTables* __restrict__ tb, double sat, double gain)
-{
-    constexpr int LC = 16;
-    static_assert(kTpLcMain == LC && kTpWaves == 4, "MFMA path: 4 waves x 64 chunks of 16 samples");
-    // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
-    bool bad = false;
-#pragma unroll 4
-    for (int it = 0; it < LC; ++it) {
-        const int j = it * kTpChunks + tid;
-        const double x = in[j];
-        bad |= !(fabs(x) < kTpInputBound);
-        buf[(j / LC) * kTpStride + (j % LC)] = x;
-    }
-    if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
-    if (tid == 0) *sFlag = 0;
-    __syncthreads();
-    if (__any(bad) && (tid & 63) == 0) atomicOr(sFlag, 1);
-    __syncthreads();
-    const bool unsafe = (*sFlag != 0);
-    if (unsafe) {
-        for (int b = 0; b < kBands; ++b) {
-            const int flag = fl[b];
-            if (!(flag & 1)) continue;
-            if (tid == 0) {
-                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b);
-                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b);
-                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b);
-            }
-            __syncthreads();
-        }
-    } else {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int m = lane & 15, g = lane >> 4;
-        // registers <- LDS in the MFMA layout
-        v4d x[4];
-#pragma unroll
-        for (int tau = 0; tau < 4; ++tau) {
-            const double* row = buf + (wave * 64 + tau * 16 + m) * kTpStride + g;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[tau][j] = row[4 * j];
-        }
-        __syncthreads();                                  // buf is scratch from here to the write-back
-        double2* red = reinterpret_cast<double2*>(buf) + wave * 256;      // [tau * 4 + g][m]: partial end states
-        double* s0q = buf + 2048 + wave * 256;                            // [chunk of the wave][4]: s0x, s0y, 0, 0
-        tp_bands_mfma<SAT, kTpChunks>(x, red, s0q, wtot, sState, sNext, L, tid, fl, tb, sat);
-        __syncthreads();                                  // every wave is done with the scratch view of buf
-#pragma unroll
-        for (int tau = 0; tau < 4; ++tau) {
-            double* row = buf + (wave * 64 + tau * 16 + m) * kTpStride + g;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) row[4 * j] = x[tau][j];
-        }
-        __syncthreads();
-        { double* t = sState; sState = sNext; sNext = t; }      // the span's end states become the next span's start states
-    }
-#pragma unroll 4
-    for (int it = 0; it < LC; ++it) {
-        const int j = it * kTpChunks + tid;
-        out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
-    }
-    __syncthreads();
-}
-
 __device__ __forceinline__ void tp_load_tables(TpLds* L, const double* __restrict__ cf,
                                                const TpBandTables* __restrict__ tb, int lci, int tid)
 {
@@ -904,6 +836,8 @@ __device__ __forceinline__ void tp_load_tables(TpLds* L, const double* __restric
     __syncthreads();
 }
 
+// Spans of 512 samples (256 chunks of 2) in VALU form: the last block of a call with an odd block count, and calls of
+// one block.
 __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, double* out, int64_t chStride,
                                                               int nSamples, const double* __restrict__ coef,
                                                               const int* __restrict__ flags,
@@ -912,9 +846,7 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
                                                               const TpBandTables* __restrict__ tables)
 {
     __shared__ double buf[kTpChunks * kTpStride];
-    __shared__ __align__(16) unsigned char ltab[sizeof(TpLdsM) > sizeof(TpLds) ? sizeof(TpLdsM) : sizeof(TpLds)];
-    TpLds& L = *reinterpret_cast<TpLds*>(ltab);             // tables of the 512-sample remainder path
-    TpLdsM& LM = *reinterpret_cast<TpLdsM*>(ltab);          // tables of the MFMA main path (one at a time)
+    __shared__ TpLds L;
     __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];     // start / end states of the current span (swapped per span)
     __shared__ double wtot[2 * 2 * kTpWaves];                        // wave totals, two parities
     double* sState = sStateA;
@@ -930,23 +862,10 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
 
     const double* src = in + (int64_t)c * chStride;
     double* dst = out + (int64_t)c * chStride;
-    int done = 0;
-    if (nSamples >= kTpChunks * kTpLcMain) {
-        tp_load_tables_m(&LM, cf, tb, tid);
-        while (nSamples - done >= kTpChunks * kTpLcMain) {
-            if (sat > 0.0) tp_span_mfma<true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &LM, tid, fl, tb, sat, gain);
-            else           tp_span_mfma<false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &LM, tid, fl, tb, sat, gain);
-            done += kTpChunks * kTpLcMain;
-        }
-    }
-    if (nSamples - done >= kTpChunks * kTpLcTail) {            // remaining whole 512-sample blocks
-        __syncthreads();
-        tp_load_tables(&L, cf, tb, 1, tid);
-        while (nSamples - done >= kTpChunks * kTpLcTail) {
-            if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
-            else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
-            done += kTpChunks * kTpLcTail;
-        }
+    tp_load_tables(&L, cf, tb, 1, tid);
+    for (int done = 0; nSamples - done >= kTpChunks * kTpLcTail; done += kTpChunks * kTpLcTail) {
+        if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
+        else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
     }
     __syncthreads();
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
@@ -988,20 +907,7 @@ __global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double
     double* sState = sStateA;
     double* sNext = sStateB;
     if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
-    // tables (same content as tp_load_tables_m, 512 threads)
-    for (int i = tid; i < kBands * 6; i += kTp8Threads) LM.cf[i / 6][i % 6] = cf[i];
-    for (int i = tid; i < kBands * 28; i += kTp8Threads) {
-        const int b = i / 28, q = i % 28;
-        LM.M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
-    }
-    for (int i = tid; i < kBands * 64; i += kTp8Threads) {
-        const int b = i / 64, r = (i % 64) / 4, q = i % 4;
-        LM.Gq[b][r][q] = (q < 2) ? tb[b].t[0].G[r][q] : 0.0;
-    }
-    for (int i = tid; i < kBands * 32; i += kTp8Threads) {
-        LM.ht[i / 32][i % 32] = tb[i / 32].mm.ht[i % 32];
-        LM.e[i / 32][(i % 32) / 16][i % 16] = tb[i / 32].mm.e[(i % 32) / 16][i % 16];
-    }
+    tp_load_tables_m(&LM, cf, tb, tid, kTp8Threads);
     __syncthreads();
 
     for (int sp = 0; sp < nSpans; ++sp) {
@@ -1068,6 +974,96 @@ __global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// One to seven waves per channel, ONE span of waves x 1024 samples in the same matrix form: what a call leaves after
+// its whole 8192-sample spans (and all of a call of 2 ... 15 blocks of 512).  The cost of a span is the latency of the
+// 20-band chain, whatever its length, so the remainder is split over as many waves as it has 1024-sample pieces rather
+// than walked through span by span; before, it ran as 4096-sample spans on four waves and then as 512-sample spans in
+// VALU form (chunk length 2) at three times the cost per block.
+constexpr int kTpwMaxWaves = 7;
+constexpr int kTpwScratchDoubles = kTpwMaxWaves * (512 + 256);      // per wave: red (256 double2) + s0q (256 doubles)
+
+__global__ __launch_bounds__(kTpwMaxWaves * 64, 4) void k_svf_cascade_tpw(const double* in, double* out, int64_t chStride,
+                                                                       const double* __restrict__ coef,
+                                                                       const int* __restrict__ flags,
+                                                                       const double* __restrict__ satGain,
+                                                                       double* __restrict__ state,
+                                                                       const TpBandTables* __restrict__ tables)
+{
+    static_assert(kTpwScratchDoubles >= 256 * kTpStride, "the guarded path stages up to 4096 samples in the scratch area");
+    __shared__ __align__(16) double scratch[kTpwScratchDoubles];
+    __shared__ TpLdsM LM;
+    __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];
+    __shared__ double wtot[2 * 2 * kTpwMaxWaves];
+    __shared__ int sFlag;
+    const int tid = threadIdx.x, nThreads = blockDim.x;
+    const int nWaves = nThreads >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int c = blockIdx.x;
+    const double* cf = coef + (int64_t)c * kBands * 6;
+    const int* fl = flags + c * kBands;
+    const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;
+    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
+    if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
+    tp_load_tables_m(&LM, cf, tb, tid, nThreads);
+    if (tid == 0) sFlag = 0;
+    __syncthreads();
+
+    const double* src = in + (int64_t)c * chStride;
+    double* dst = out + (int64_t)c * chStride;
+    v4d x[4];
+    bool bad = false;
+#pragma unroll
+    for (int tau = 0; tau < 4; ++tau) {
+        const double* p = src + (wave * 64 + tau * 16 + m) * 16 + g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[tau][j] = p[4 * j];
+            bad |= !(fabs(x[tau][j]) < kTpInputBound);
+        }
+    }
+    if (tid < kBands * 2) bad |= !(fabs(sStateA[tid]) < kTpInputBound);
+    if (__any(bad) && lane == 0) atomicOr(&sFlag, 1);
+    __syncthreads();
+    if (sFlag != 0) {
+        // guarded path: pieces of up to 4096 samples through the one-thread reference recurrence, staged in the scratch
+        // area as [chunk][sample]; in and out may alias, every sample of a piece is read before the piece is written
+        const int nSamples = nWaves * 1024;
+        for (int base = 0; base < nSamples; base += 4096) {
+            const int cnt = (nSamples - base < 4096) ? nSamples - base : 4096;
+            for (int j = tid; j < cnt; j += nThreads) scratch[(j / 16) * kTpStride + (j % 16)] = src[base + j];
+            __syncthreads();
+            for (int b = 0; b < kBands; ++b) {
+                const int flag = fl[b];
+                if (!(flag & 1)) continue;
+                if (tid == 0) {
+                    if (flag & 4)      tp_band_guarded<2>(scratch, 16, LM.cf[b], sat, sStateA + 2 * b, cnt / 16);
+                    else if (flag & 2) tp_band_guarded<1>(scratch, 16, LM.cf[b], sat, sStateA + 2 * b, cnt / 16);
+                    else               tp_band_guarded<0>(scratch, 16, LM.cf[b], sat, sStateA + 2 * b, cnt / 16);
+                }
+                __syncthreads();
+            }
+            for (int j = tid; j < cnt; j += nThreads) dst[base + j] = scratch[(j / 16) * kTpStride + (j % 16)] * gain;
+            __syncthreads();
+        }
+        if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sStateA[tid];
+        return;
+    }
+    double2* red = reinterpret_cast<double2*>(scratch) + wave * 256;
+    double* s0q = scratch + kTpwMaxWaves * 512 + wave * 256;
+    if (sat > 0.0) tp_bands_mfma<true, 0>(x, red, s0q, wtot, sStateA, sStateB, &LM, tid, fl, tb, sat);
+    else           tp_bands_mfma<false, 0>(x, red, s0q, wtot, sStateA, sStateB, &LM, tid, fl, tb, sat);
+#pragma unroll
+    for (int tau = 0; tau < 4; ++tau) {
+        double* p = dst + (wave * 64 + tau * 16 + m) * 16 + g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[4 * j] = x[tau][j] * gain;
+    }
+    __syncthreads();                          // the span's end states are in sStateB
+    if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sStateB[tid];
+}
+
 }  // namespace
 
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
@@ -1089,14 +1085,22 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
                            const void* tables)
 {
     static_assert(sizeof(TpBandTables) == kSvfTpTableDoubles * sizeof(double), "host/device table layout");
-    // whole 8192-sample spans on the eight-wave kernel, the rest (multiples of 512) on the four-wave one
-    const int nSpans8 = (kTpLcMain == 16 && kTpWaves == 4) ? nSamples / kTp8Span : 0;
+    // whole 8192-sample spans on the eight-wave kernel, what is left as one span of 1 ... 7 waves x 1024 samples, and a
+    // last block of 512 on the chunk-length-2 path of the four-wave kernel
+    const TpBandTables* tb = reinterpret_cast<const TpBandTables*>(tables);
+    const int nSpans8 = nSamples / kTp8Span;
     if (nSpans8 > 0)
         hipLaunchKernelGGL(k_svf_cascade_tp8, dim3(nCh), dim3(kTp8Threads), 0, stream, in, out, chStride, nSpans8, coef, flags,
-                           satGain, state, reinterpret_cast<const TpBandTables*>(tables));
-    const int done = nSpans8 * kTp8Span;
+                           satGain, state, tb);
+    int done = nSpans8 * kTp8Span;
+    const int nWaves = (nSamples - done) / 1024;
+    if (nWaves > 0) {
+        hipLaunchKernelGGL(k_svf_cascade_tpw, dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, coef,
+                           flags, satGain, state, tb);
+        done += nWaves * 1024;
+    }
     if (nSamples > done)
         hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in + done, out + done, chStride,
-                           nSamples - done, coef, flags, satGain, state, reinterpret_cast<const TpBandTables*>(tables));
+                           nSamples - done, coef, flags, satGain, state, tb);
 }
 }  // namespace cpq

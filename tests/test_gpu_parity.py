@@ -920,9 +920,10 @@ def test_ragged_call_lengths_across_ring_wraps(amd, oracle, schedule):
 
 @pytest.mark.parametrize("sat", [0.0, 0.2])
 def test_eq_time_parallel_kernels_hand_over_state(amd, oracle, sat):
-    """One call of 43 blocks = two 8192-sample spans (eight-wave matrix-form kernel) + one 4096-sample span (four-wave
-    matrix form) + three 512-sample spans (VALU form, chunk length 2); band states pass between the three through the
-    state array.  A later call injects a NaN into the second 8192-sample span (guarded path in two staged halves)."""
+    """One call of 43 blocks = two 8192-sample spans (eight-wave matrix-form kernel) + one span of five waves x 1024
+    samples (k_svf_cascade_tpw) + one 512-sample span (VALU form, chunk length 2); band states pass between the three
+    through the state array.  A later call injects a NaN into the second 8192-sample span (guarded path in two staged
+    halves)."""
     O = oracle
     S, T = 2, 43
     x = make_inputs(O, S, 3 * T * B)
@@ -940,6 +941,35 @@ def test_eq_time_parallel_kernels_hand_over_state(amd, oracle, sat):
         yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po)
         worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
     print("tp hand-over sat", sat, "max abs diff", worst)
+    assert np.all(np.isfinite(y)) and worst <= 1e-13
+    eng.close()
+
+
+@pytest.mark.parametrize("sat", [0.0, 0.2])
+def test_eq_short_calls_one_span_of_one_to_seven_waves(amd, oracle, sat):
+    """Calls of 2 ... 15 blocks (and 23 = one 8192-sample span + 7 blocks): the remainder after the whole 8192-sample spans
+    runs as ONE span of 1 ... 7 waves x 1024 samples in matrix form, an odd block count leaves one 512-sample span in VALU
+    form.  A NaN in a 7-block call and an Inf in an 11-block call send those spans through the guarded path (pieces of
+    3072 and of 4096 + 1024 samples)."""
+    O = oracle
+    S = 2
+    calls = [2, 3, 5, 7, 9, 11, 15, 1, 23, 4, 6, 7, 11, 2]
+    x = make_inputs(O, S, sum(calls) * B)
+    starts = np.cumsum([0] + calls) * B
+    x[0, starts[11] + 2500] = np.nan              # the second 7-block call
+    x[3, starts[12] + 4500] = np.inf              # the second 11-block call
+    po = O.eq_params_bench(sat)
+    po.bands[3].channelMode = 2
+    po.bands[9].type = 3
+    po.totalGainDb = -1.25
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=max(calls))
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    y = np.concatenate([eng.eq_process(x[:, starts[i]:starts[i + 1]]) for i in range(len(calls))], axis=1)
+    worst = 0.0
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po)
+        worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+    print("short calls sat", sat, "max abs diff", worst)
     assert np.all(np.isfinite(y)) and worst <= 1e-13
     eng.close()
 

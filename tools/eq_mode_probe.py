@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which EQ kernel for short calls?  Times cpq_eq_process_device for calls of 1, 2, 4, 8, 16 blocks in the automatic
+"""Which EQ kernel for short calls?  Times cpq_eq_process_device for calls of 1 ... 23 blocks in the automatic
 (time-parallel) and the sequential (lane-skewed) mode; 256 streams, bench EQ preset."""
 import os
 import sys
@@ -13,7 +13,7 @@ import bench
 import convopeq_amd as amd
 
 S, B = 256, 512
-for T in (1, 2, 4, 8, 16):
+for T in (1, 2, 3, 4, 6, 7, 8, 12, 15, 16, 23):
     n = T * B
     x = torch.from_numpy(np.tile(bench.gen_pcm(n, 0, 0), (2 * S, 1))).cuda()
     y = torch.empty_like(x)
