@@ -418,8 +418,9 @@ def parse_args(argv=None):
     ap.add_argument("--ir-len", type=int, default=131072)
     ap.add_argument("--block", type=int, default=512, help="diagnostic: block size")
     ap.add_argument("--partition", type=int, default=-1,
-                    help="internal FFT partition size; 0 = the block size; default: 4096 when the block is 512 and the call is "
-                         "whole 4096-sample partitions (the throughput path: profiles/r02b_sweep_partition_x_blocks_per_call.txt), else 0")
+                    help="internal FFT partition size; 0 = the block size; default -1 = CPQ_PARTITION_AUTO, the engine's own "
+                         "choice: 4096 when the calls are whole 4096-sample partitions (the throughput path: "
+                         "profiles/r02b_sweep_partition_x_blocks_per_call.txt), else 512, else the block")
     ap.add_argument("--blocks-per-call", type=int, default=1024,
                     help="blocks of --block samples per process() call (default 1024 = 524288 samples, the reference's largest "
                          "process() block, ConvolverProcessor.Runtime.cpp:609)")
@@ -446,9 +447,6 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.streams <= 0:
         args.streams = STREAMS_CONFIG2 if args.gpus <= 1 else STREAMS_CONFIG5_SHARE
-    if args.partition < 0:
-        ok = (args.block == 512 and (args.blocks_per_call * args.block) % 4096 == 0 and args.schedule == "uniform")
-        args.partition = 4096 if ok else 0
     if args.partition == args.block:
         args.partition = 0
     return args
@@ -510,7 +508,7 @@ def main():
     d_in = torch.from_numpy(host).cuda()
     d_out = torch.empty_like(d_in)
     plan = eng.plan()
-    P = args.partition if args.partition else B          # internal FFT partition size
+    P = eng.partition_size()                             # internal FFT partition size (the engine's choice at --partition -1)
     Tp = n // P                                          # partitions per call
     taps = L if args.exact else plan.heff_len
     k_parts = (taps + P - 1) // P
@@ -546,7 +544,7 @@ def main():
     # fp64 ridge.  Measured after the timed region (not part of `value`) to give the roofline object both regimes.
     prof1 = None
     if not (args.eq_only or args.host_buffers or args.schedule == "nuc") and rank == 0:
-        P1 = args.partition if args.partition else B
+        P1 = P
         eng.profile_reset()
         for _ in range(40):
             eng.conv_process_device(d_in.data_ptr(), d_out.data_ptr(), P1)

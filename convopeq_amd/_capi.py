@@ -25,6 +25,7 @@ CPQ_SCHED_UNIFORM = 0
 CPQ_SCHED_REFERENCE_NUC = 1
 CPQ_CALLS_WHOLE_BLOCKS = 0
 CPQ_CALLS_ANY = 1
+CPQ_PARTITION_AUTO = -1
 CPQ_ORDER_CONV_THEN_EQ = 0
 CPQ_ORDER_EQ_THEN_CONV = 1
 KERNEL_IDS = {"k_rfft_fwd_ols": 0, "k_fdl_mac": 1, "k_fdl_mac_dcnyq": 2, "k_rfft_inv_ols": 3, "k_svf_cascade": 4,
@@ -119,6 +120,7 @@ SYMBOLS = {
     "cpq_engine_set_stream": (C.c_int32, [_E, C.c_void_p]),
     "cpq_engine_synchronize": (C.c_int32, [_E]),
     "cpq_engine_arena_bytes": (C.c_int64, [_E]),
+    "cpq_engine_partition_size": (C.c_int32, [_E]),
     "cpq_engine_prepare": (C.c_int32, [_E, C.c_double, C.c_int32]),
     "cpq_engine_set_order": (C.c_int32, [_E, C.c_int32]),
     "cpq_host_register": (C.c_int32, [C.c_void_p, C.c_size_t]),

@@ -37,13 +37,11 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
                                      tables(e), e->P, e->nCh, T, e->head, e->ringSlots);
         }
         for (int l = 0; l < pl.num_layers; ++l) {
-            const int kTile = cpq::fdl_mac_kpad_align(e->macTile, T);
-            const int kPad = (int)alignUp(e->layerK[l], kTile);
             double* dst = (l == 0) ? dOut : e->layerOut + (int64_t)(l - 1) * e->nCh * stride;
             {
                 ProfScope p(e, CPQ_K_FDL_MAC);
                 cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H + (int64_t)e->layerRow[l] * e->P, e->irSlot, e->Y,
-                                    e->P, e->nCh, kPad, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
+                                    e->P, e->nCh, e->layerK[l], e->ringSlots, e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
             }
             if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {
                 ProfScope p(e, CPQ_K_DCNYQ);
@@ -80,8 +78,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
         {
             ProfScope p(e, CPQ_K_FDL_MAC);
             cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh,
-                                (int)alignUp(e->kMaxReal, cpq::fdl_mac_kpad_align(e->macTile, T)), e->ringSlots,
-                                e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
+                                e->kMaxReal, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
         }
         if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {      // the cooperative kernel produces the packed (DC, Nyquist) bin itself
             ProfScope p(e, CPQ_K_DCNYQ);

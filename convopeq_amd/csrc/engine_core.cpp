@@ -188,7 +188,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     if (anyCalls) {
         if (d->block_size < 1 || d->block_size > 4096)
             return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size (the call quantum) must be in [1, 4096]");
-        if (d->semantics != CPQ_SEM_REFERENCE || d->partition_size != 0)
+        if (d->semantics != CPQ_SEM_REFERENCE || (d->partition_size != 0 && d->partition_size != CPQ_PARTITION_AUTO))
             return fail(nullptr, CPQ_ERR_INVALID_ARG, "CPQ_CALLS_ANY runs the reference's own layer plan: reference semantics, partition_size 0");
     } else if (d->block_size < 64 || d->block_size > 4096 || (d->block_size & (d->block_size - 1)))
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "block_size must be a power of two in [64, 4096] (any quantum from 1 to 4096: call_mode = CPQ_CALLS_ANY)");
@@ -199,7 +199,8 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     if (d->schedule != CPQ_SCHED_UNIFORM && d->schedule != CPQ_SCHED_REFERENCE_NUC)
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "schedule must be CPQ_SCHED_UNIFORM or CPQ_SCHED_REFERENCE_NUC");
     if (d->schedule == CPQ_SCHED_REFERENCE_NUC &&
-        (d->semantics != CPQ_SEM_REFERENCE || (d->partition_size != 0 && d->partition_size != d->block_size)))
+        (d->semantics != CPQ_SEM_REFERENCE ||
+         (d->partition_size != 0 && d->partition_size != CPQ_PARTITION_AUTO && d->partition_size != d->block_size)))
         return fail(nullptr, CPQ_ERR_INVALID_ARG, "the non-uniform schedule needs reference semantics and partition_size == block_size");
 
     int nDev = 0;
@@ -225,7 +226,21 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     e->anyCalls = anyCalls;
     e->P0 = nextPow2(std::max(d->block_size, 64));
     e->maxCall = (int)std::min<int64_t>((int64_t)d->max_blocks_per_call * d->block_size, (int64_t)1 << 30);
-    e->P = d->partition_size ? d->partition_size : (anyCalls ? e->P0 : d->block_size);
+    int32_t partition = d->partition_size;
+    if (partition == CPQ_PARTITION_AUTO) {
+        // the larger partition wins wherever the calls allow it (profiles/r02b_sweep_partition_x_blocks_per_call.txt:
+        // K shrinks by P / B, the FFT cost per sample stays): 4096 for calls of at least eight such partitions (below
+        // that the MAC streams the same IR + FDL bytes per call at either size and the 512-point kernels do it faster:
+        // profiles/r02e_small_calls.txt), else 512, else the block itself.  The reference's own
+        // schedule, ragged calls and the block sizes whose reference plan is time-varying (B >= 1024 under reference
+        // semantics: layered mode at P == B) keep the reference's layer-0 partition.
+        partition = 0;
+        if (!anyCalls && d->schedule == CPQ_SCHED_UNIFORM && (d->semantics == CPQ_SEM_EXACT || d->block_size <= 512))
+            for (int32_t cand : { 4096, 512 })
+                if (cand > d->block_size && e->maxCall % cand == 0 && (cand == 512 || e->maxCall >= 8 * cand)) { partition = cand; break; }
+    }
+    e->desc.partition_size = partition;
+    e->P = partition ? partition : (anyCalls ? e->P0 : d->block_size);
     if (!anyCalls && (e->P < e->B || e->P > 4096 || (e->P & (e->P - 1)) || ((int64_t)d->max_blocks_per_call * e->B) % e->P != 0)) {
         const int p = e->P;
         delete e;
@@ -397,6 +412,7 @@ int32_t cpq_engine_synchronize(cpq_engine* e)
 }
 
 int64_t cpq_engine_arena_bytes(const cpq_engine* e) { return e ? e->arenaBytes : 0; }
+int32_t cpq_engine_partition_size(const cpq_engine* e) { return e ? e->P : 0; }
 
 int32_t cpq_engine_prepare(cpq_engine* e, double sampleRate, int32_t maxBlock)
 {

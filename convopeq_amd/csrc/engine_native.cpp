@@ -553,7 +553,7 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
         }
         {
             ProfScope p(e, CPQ_K_FDL_MAC);
-            cpq::launch_fdl_mac(e->stream, e->macTile, t.X, t.H, g.irSlotDev, t.Y, t.P, nCh, t.kPad, t.ringSlots, t.head, nb,
+            cpq::launch_fdl_mac(e->stream, e->macTile, t.X, t.H, g.irSlotDev, t.Y, t.P, nCh, t.K, t.ringSlots, t.head, nb,
                                 (int64_t)t.hRows * t.P, !g.shared);
         }
         if (cpq::fdl_mac_needs_dcnyq(e->macTile, nb)) {

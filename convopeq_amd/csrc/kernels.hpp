@@ -37,8 +37,8 @@ void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const do
 // is overwritten by launch_fdl_mac_dcnyq).
 // hPrivate: every channel has its own IR rows (no CPQ_ALL_STREAMS sharing): single-tile calls may then stream them past the cache
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot,
-                    double2* Y, int P, int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride,
-                    bool hPrivate = false);
+                    double2* Y, int P, int nCh, int K, int ringSlots, int head, int T, int64_t hSlotStride,
+                    bool hPrivate = false);      // K = partitions in use (walked in steps of the variant's tile)
 
 // packed bin 0: DC and Nyquist are two independent real MACs.
 // kernel variant launch_fdl_mac uses for (tile, T) (0 = workgroup-cooperative) and the multiple kPad must be padded to

@@ -25,7 +25,7 @@ template <int TT, int PF, int NT = 0>
 __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) void k_fdl_mac(const double2* __restrict__ X, const double2* __restrict__ H,
                                                  const int* __restrict__ irSlot, double2* __restrict__ Y,
                                                  int nPairs, int kPad, int ringMask, int head, int T, int nTiles,
-                                                 int64_t hSlotStride, int P, int segShift)
+                                                 int64_t hSlotStride, int P, int segShift, int K)
 {
     static_assert(TT % PF == 0, "prefetch depth must divide the tile");
     // XCD-aware decomposition: blocks b and b+8 share an XCD (and its L2) under round-robin dispatch, so the
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
 #pragma unroll
     for (int r = 0; r < PF; ++r) {
         xn[r] = Xc[(int64_t)((base - r - 1) & ringMask) * P];
-        hn[r] = Hc[(int64_t)r * P];
+        hn[r] = Hc[(int64_t)r * P];               // rows >= K of a slot are zero
     }
 
     for (int k0 = 0; k0 < kPad; k0 += TT) {
@@ -70,21 +70,28 @@ __global__ __launch_bounds__(256, (TT >= 32 || (TT == 16 && PF >= 16)) ? 1 : 2) 
             const int k = k0 + r;
             const double2 h = hn[r % PF];
             const double2 xnew = xn[r % PF];
-            if (NT >= 2) {
-                const double* hp = reinterpret_cast<const double*>(Hc + (int64_t)(k + PF) * P);
-                hn[r % PF] = make_double2(__builtin_nontemporal_load(hp), __builtin_nontemporal_load(hp + 1));
-            } else {
-                hn[r % PF] = Hc[(int64_t)(k + PF) * P];                               // IR row k+PF (zero rows past K)
+            // rows that only steps >= K would consume are not fetched (at K = 33, tile 4: 33 + 36 instead of 40 + 43 rows
+            // per output tile): IR row k + PF serves step k + PF, the FDL row entering at step k + PF serves k + PF + 1 on
+            if (k + PF < K) {
+                if (NT >= 2) {
+                    const double* hp = reinterpret_cast<const double*>(Hc + (int64_t)(k + PF) * P);
+                    hn[r % PF] = make_double2(__builtin_nontemporal_load(hp), __builtin_nontemporal_load(hp + 1));
+                } else {
+                    hn[r % PF] = Hc[(int64_t)(k + PF) * P];                               // IR row k+PF
+                }
             }
-            if (NT >= 1) {
-                const double* xp = reinterpret_cast<const double*>(Xc + (int64_t)((base - (k + PF) - 1) & ringMask) * P);
-                xn[r % PF] = make_double2(__builtin_nontemporal_load(xp), __builtin_nontemporal_load(xp + 1));
-            } else {
-                xn[r % PF] = Xc[(int64_t)((base - (k + PF) - 1) & ringMask) * P];      // FDL row entering at step k+PF
+            if (k + PF + 1 < K) {
+                if (NT >= 1) {
+                    const double* xp = reinterpret_cast<const double*>(Xc + (int64_t)((base - (k + PF) - 1) & ringMask) * P);
+                    xn[r % PF] = make_double2(__builtin_nontemporal_load(xp), __builtin_nontemporal_load(xp + 1));
+                } else {
+                    xn[r % PF] = Xc[(int64_t)((base - (k + PF) - 1) & ringMask) * P];      // FDL row entering at step k+PF
+                }
             }
             // keep the two loads HERE: without the fence the scheduler sinks them next to their use PF steps
             // later (to save registers) and the kernel runs with <= 3 loads in flight per wave
             __builtin_amdgcn_sched_barrier(0);
+            if (k < K)                        // uniform; false only in the last pass (kPad - K < TT steps)
 #pragma unroll
             for (int i = 0; i < TT; ++i) {
                 const double2 x = xw[(i - r + TT) % TT];
@@ -140,12 +147,12 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
                                                                   const int* __restrict__ irSlot,
                                                                   double2* __restrict__ Y, int kPad, int ringMask,
                                                                   int head, int T, int nGroups, int64_t hSlotStride,
-                                                                  int P, int nCols, int nWork)
+                                                                  int P, int nCols, int nWork, int K)
 {
     __shared__ double2 ring[kWgRingBlocks * kWgTile * 64];
     __shared__ double2 hst[kWgTile * 64];
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the loop below branches on it
     // workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8): give each XCD a contiguous range of logical ids so
     // that the nGroups workgroups of one (channel, column) -- same IR rows, overlapping FDL rows -- share one L2
     const int perXcd = gridDim.x >> 3;                       // the grid is padded to a multiple of 8
@@ -189,20 +196,32 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
     hst[w * 64 + lane] = hrow(w)[bin];            // IR rows of chunk 0
     __syncthreads();
 
+    // The last chunk holds rem = K - 8 (nChunks - 1) partition steps (1 ... 8): the steps past K are skipped, and so
+    // are the loads that only they would consume -- IR rows >= K, and the FDL rows that enter the register windows
+    // after step rem - 1 (row 7 - r of a ring block refills a window slot at step r for use from step r + 1 on).  At
+    // K = 33 (131072 taps at P = 4096) that is 7 of 40 steps and 15 of 144 row reads per 64 output rows.
     const int nChunks = kPad / kWgTile;
+    const int rem = K - (nChunks - 1) * kWgTile;
     const bool active = t0w < T;                  // wave-uniform
     for (int j = 0; j < nChunks; ++j) {
+        const bool lastChunk = (j == nChunks - 1), nextIsLast = (j == nChunks - 2);
+        const int steps = lastChunk ? rem : kWgTile;
         // row w of block (-j-2): needed by wave 0 in the next chunk; staged in a register, parked at chunk end
         // the FDL rows of a channel are read by this workgroup alone (one group at T <= 64): streaming hint; the IR rows
         // may be shared by every channel (CPQ_ALL_STREAMS) and stay cacheable
-        const double* xp = reinterpret_cast<const double*>(xrow(base + kWgTile * (-j - 2) + w) + bin);
-        const double2 xs = make_double2(__builtin_nontemporal_load(xp), __builtin_nontemporal_load(xp + 1));
-        const double2 hsn = hrow((j + 1) * kWgTile + w)[bin];     // IR row w of the next chunk (zero rows past K)
+        double2 xs = make_double2(0.0, 0.0), hsn = make_double2(0.0, 0.0);
+        if (!lastChunk && (!nextIsLast || w > kWgTile - rem)) {
+            const double* xp = reinterpret_cast<const double*>(xrow(base + kWgTile * (-j - 2) + w) + bin);
+            xs = make_double2(__builtin_nontemporal_load(xp), __builtin_nontemporal_load(xp + 1));
+        }
+        if (!lastChunk && (!nextIsLast || w < rem))
+            hsn = hrow((j + 1) * kWgTile + w)[bin];               // IR row w of the next chunk
         const double2* blk = ring + slotOf(w - j - 1) * kWgTile * 64 + lane;
         // a wave whose 8 outputs lie beyond T only feeds the ring (partial last group: T mod 64 != 0)
         if (active)
 #pragma unroll
         for (int r = 0; r < kWgTile; ++r) {
+            if (r < steps) {                      // uniform; false only in the last chunk
             const double2 h = hst[r * 64 + lane];
             const double hs = h.x + h.y;
             // the slot refilled in the previous step (window slot 8-r, first used now): its sum
@@ -226,7 +245,9 @@ __global__ __launch_bounds__(64 * kWgWaves, 4) void k_fdl_mac_wg(const double2* 
                 m3[i] = fma(xsum[sl], hs, m3[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (lastChunk) break;
         // slot of block (-j-2) == slot of block (7-j), last read by wave 7 in chunk j-1: free since the barrier
         // that ended that chunk
         ring[(slotOf(-j - 2) * kWgTile + w) * 64 + lane] = xs;
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(256) void k_fdl_mac_dcnyq(const double2* __restrict
 
 template <int TT, int PF>
 void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const int* irSlot, double2* Y, int P,
-                  int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride, bool hPrivate = false)
+                  int nCh, int kPad, int K, int ringSlots, int head, int T, int64_t hSlotStride, bool hPrivate = false)
 {
     const int threads = P < 256 ? P : 256;
     int segShift = 0;
@@ -293,15 +314,15 @@ void launch_mac_t(hipStream_t stream, const double2* X, const double2* H, const 
         if (nTiles == 1) {              // every row is read by exactly one workgroup: streaming loads
             if (hPrivate)
                 hipLaunchKernelGGL((k_fdl_mac<TT, PF, 2>), dim3(grid), dim3(threads), 0, stream, X, H, irSlot, Y, nPairs, kPad,
-                                   ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift);
+                                   ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift, K);
             else
                 hipLaunchKernelGGL((k_fdl_mac<TT, PF, 1>), dim3(grid), dim3(threads), 0, stream, X, H, irSlot, Y, nPairs, kPad,
-                                   ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift);
+                                   ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift, K);
             return;
         }
     }
     hipLaunchKernelGGL((k_fdl_mac<TT, PF>), dim3(grid), dim3(threads), 0, stream, X, H, irSlot, Y, nPairs, kPad,
-                       ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift);
+                       ringSlots - 1, head, T, nTiles, hSlotStride, P, segShift, K);
 }
 
 }  // namespace
@@ -328,19 +349,22 @@ int fdl_mac_kpad_align(int tile, int T)
 }
 
 void launch_fdl_mac(hipStream_t stream, int tile, const double2* X, const double2* H, const int* irSlot, double2* Y,
-                    int P, int nCh, int kPad, int ringSlots, int head, int T, int64_t hSlotStride, bool hPrivate)
+                    int P, int nCh, int K, int ringSlots, int head, int T, int64_t hSlotStride, bool hPrivate)
 {
+    // K = partitions in use; the kernels walk it in steps of their tile (rows K ... kPad - 1 of every IR slot are zero)
+    const int kAlign = fdl_mac_kpad_align(tile, T);
+    const int kPad = (K + kAlign - 1) / kAlign * kAlign;
     tile = fdl_mac_variant(tile, T);
     if (tile == 0) {      // long calls: workgroup-cooperative kernel
         const int nGroups = (T + kWgWaves * kWgTile - 1) / (kWgWaves * kWgTile);
         const int nCols = P / 64;
         const int nWork = nCh * nCols * nGroups;
         hipLaunchKernelGGL(k_fdl_mac_wg, dim3((nWork + 7) / 8 * 8), dim3(64 * kWgWaves), 0, stream, X, H,
-                           irSlot, Y, kPad, ringSlots - 1, head, T, nGroups, hSlotStride, P, nCols, nWork);
+                           irSlot, Y, kPad, ringSlots - 1, head, T, nGroups, hSlotStride, P, nCols, nWork, K);
         return;
     }
     const int pf = 4;     // prefetch depth in partition steps (deeper measured slower: register pressure)
-#define CPQ_MAC_CASE(TT_, PF_) launch_mac_t<TT_, PF_>(stream, X, H, irSlot, Y, P, nCh, kPad, ringSlots, head, T, hSlotStride, hPrivate)
+#define CPQ_MAC_CASE(TT_, PF_) launch_mac_t<TT_, PF_>(stream, X, H, irSlot, Y, P, nCh, kPad, K, ringSlots, head, T, hSlotStride, hPrivate)
     switch (tile) {
         case 4:  CPQ_MAC_CASE(4, 4); break;
         case 8:  if (pf >= 8) CPQ_MAC_CASE(8, 8); else CPQ_MAC_CASE(8, 4); break;

@@ -189,6 +189,10 @@ class BatchedEngine:
     def arena_bytes(self):
         return self._lib.cpq_engine_arena_bytes(self._h)
 
+    def partition_size(self):
+        """The internal FFT partition in use (what CPQ_PARTITION_AUTO resolved to)."""
+        return self._lib.cpq_engine_partition_size(self._h)
+
     def prepare_to_play(self, sample_rate, max_block):
         self._ck(self._lib.cpq_engine_prepare(self._h, sample_rate, max_block))
 

@@ -155,7 +155,13 @@ typedef struct {
     int32_t semantics;               /* cpq_semantics */
     int32_t mac_tile;                /* 0 = default; else outputs per lane in the FDL MAC kernel (4/8/16/32) */
     double  sample_rate;
-    int32_t partition_size;          /* internal FFT partition P: 0 = block_size; else a power of two with
+    int32_t partition_size;          /* internal FFT partition P: 0 = block_size; CPQ_PARTITION_AUTO = the fastest P
+                                        for calls of max_blocks_per_call blocks (4096 when block_size *
+                                        max_blocks_per_call is a multiple of it and at least 32768, else 512 when
+                                        a multiple of that, else block_size;
+                                        uniform schedule, whole-block calls, block_size <= 512 or exact
+                                        semantics, plain IRs - a FilterSpec with tail layers needs P == block_size;
+                                        read it back with cpq_engine_partition_size); else a power of two with
                                         block_size <= P <= 4096.  The result is the same convolution (with the
                                         h_eff the reference derives for block_size); larger P trades call
                                         granularity for fewer partitions: every call must then carry a multiple
@@ -165,6 +171,8 @@ typedef struct {
     int32_t call_mode;               /* cpq_call_mode: 0 = whole power-of-two blocks (default), 1 = any quantum / ragged calls */
     int32_t reserved;
 } cpq_engine_desc;
+
+#define CPQ_PARTITION_AUTO (-1)
 
 typedef struct cpq_engine cpq_engine;
 
@@ -199,6 +207,8 @@ int32_t cpq_engine_set_stream(cpq_engine* e, void* hip_stream);
 int32_t cpq_engine_synchronize(cpq_engine* e);
 /* bytes of the device arena */
 int64_t cpq_engine_arena_bytes(const cpq_engine* e);
+/* the internal FFT partition size in use (what CPQ_PARTITION_AUTO resolved to); calls carry multiples of it */
+int32_t cpq_engine_partition_size(const cpq_engine* e);
 
 /* replaces ConvolverProcessor::prepareToPlay(double,int) (src/convolver/ConvolverProcessor.Lifecycle.cpp:211-402)
  * and EQProcessor::prepareToPlay(double,int) (src/eqprocessor/EQProcessor.Core.cpp:679-826):

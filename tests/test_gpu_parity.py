@@ -108,6 +108,38 @@ def test_larger_internal_partition(amd, oracle, partition, blocks_per_call, tile
     eng.close()
 
 
+@pytest.mark.parametrize("block,blocks_per_call,semantics,schedule,expect", [
+    (512, 64, "ref", "uniform", 4096), (512, 3, "ref", "uniform", 512), (128, 256, "ref", "uniform", 4096),
+    (128, 64, "ref", "uniform", 512), (128, 12, "ref", "uniform", 512), (256, 3, "ref", "uniform", 256),
+    (1024, 32, "ref", "uniform", 1024), (1024, 32, "exact", "uniform", 4096), (1024, 8, "exact", "uniform", 1024),
+    (512, 64, "ref", "nuc", 512)])
+def test_automatic_partition_choice(amd, oracle, block, blocks_per_call, semantics, schedule, expect):
+    """CPQ_PARTITION_AUTO: 4096 where the calls are eight or more whole 4096-sample partitions, else 512, else the block; never for
+    the reference's own schedule or for blocks whose reference plan is time-varying.  The output is the oracle's Add/Get
+    emulation at the caller's block size whatever the engine picks."""
+    O = oracle
+    L = 20000
+    irs = [O.gen_ir(L, stream=0, channel=c) for c in range(2)]
+    n_call = blocks_per_call * block
+    calls = max(2, (3 * L) // n_call)
+    x = make_inputs(O, 1, calls * n_call)
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=L, max_blocks_per_call=blocks_per_call,
+                            partition_size=amd.CPQ_PARTITION_AUTO,
+                            semantics=amd.CPQ_SEM_EXACT if semantics == "exact" else amd.CPQ_SEM_REFERENCE,
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if schedule == "nuc" else amd.CPQ_SCHED_UNIFORM)
+    assert eng.partition_size() == expect
+    eng.set_impulse(0, irs[0], irs[1])
+    y = np.concatenate([eng.conv_process(x[:, o:o + n_call]) for o in range(0, calls * n_call, n_call)], axis=1)
+    if semantics == "exact":
+        ref = np.stack([np.convolve(x[c], irs[c])[:x.shape[1]] for c in range(2)])
+        tol = 1e-12
+    else:
+        ref = oracle_conv(O, irs, x, block=block)
+        tol = 1e-13
+    assert rms(y - ref) <= tol
+    eng.close()
+
+
 def test_shared_ir_and_exact_semantics(amd, oracle):
     O = oracle
     from scipy.signal import fftconvolve

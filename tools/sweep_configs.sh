@@ -17,7 +17,7 @@ run --eq-preset autoeq
 run --pcm-scale 64
 run --no-eq
 run --partition 512 --blocks-per-call 64
-for B in 128 256; do run --block $B --partition 4096 --blocks-per-call $((524288 / B)); done
+for B in 128 256; do run --block $B --blocks-per-call $((524288 / B)); done     # the engine picks P = 4096 (CPQ_PARTITION_AUTO)
 for B in 1024 2048; do run --block $B --partition 0 --blocks-per-call $((524288 / B)); done
 for B in 1024 2048; do run --exact --block $B --partition 4096 --blocks-per-call $((524288 / B)); done
 run --streams 64 --ir-len 524288
