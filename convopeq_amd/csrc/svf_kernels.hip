@@ -298,18 +298,18 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 // Output stage when every |y| of the group is below the fastTanh clip threshold (4.5): neither the argument clamp, nor
 // the scalar path's hard +-1, nor the +-100 clamp can act (|out| <= |y| for 0 <= sat <= 1), and the blend folds into
 // one rational function:  y (1 - s) + s y (27 + y^2) / (27 + 9 y^2)  =  y (27 + c1 y^2) / (27 + 9 y^2),  c1 = 9 - 8 s,
-// which in partial fractions is  y (c1 / 9 + (27 - 3 c1) / (27 + 9 y^2)):  one reciprocal of den in [27, 209.25] and a
+// which in partial fractions is  y (c1 / 9 + (3 - c1 / 3) / (3 + y^2)):  one reciprocal of den in [3, 23.25] and a
 // multiply-add instead of a full division.  The reciprocal is refined with one third-order step (r (1 + e + e^2), e = 1 -
 // den r: v_rcp_f64 is good to 4.6e-8 here, e^3 ~ 1e-22), so r is the correctly rounded reciprocal up to 1 ulp and the
 // result is within ~1 ulp of the reference expression (rounding-level, like the rest of the time-parallel evaluation;
-// 8 operations per sample instead of 10).  Both band kinds share it.
+// 7 operations per sample instead of 10).  Both band kinds share it.
 template <int N>
 __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 {
-    const double ca = c1 * (1.0 / 9.0), cb = 27.0 - 3.0 * c1;
+    const double ca = c1 * (1.0 / 9.0), cb = 3.0 - c1 * (1.0 / 3.0);
     double den[N], r[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) den[j] = fma(9.0 * y[j], y[j], 27.0);
+    for (int j = 0; j < N; ++j) den[j] = fma(y[j], y[j], 3.0);
 #pragma unroll
     for (int j = 0; j < N; ++j) r[j] = __builtin_amdgcn_rcp(den[j]);
 #pragma unroll
