@@ -357,7 +357,7 @@ __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic
 }
 
 // per-workgroup LDS copy of the channel's per-band constants (one chunk length at a time)
-struct alignas(16) TpLds {
+struct TpLds {
     double cf[kBands][6];        // a1 a2 a3 m0 m1 m2
     double M[kBands][28];        // Mk[6][4], Mw[4]
     double G[kBands][32];        // G[16][2]
@@ -412,12 +412,10 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     uint32_t mOff = (uint32_t)b * (uint32_t)(28 * sizeof(double));      // Mall = [band][28]
     asm volatile("" : "+v"(mOff));
     const double* Mb = reinterpret_cast<const double*>(reinterpret_cast<const char*>(Mall) + mOff);
-    const double2* Mb2 = reinterpret_cast<const double2*>(Mb);          // rows of 28 doubles: 16-byte aligned (TpLds / TpLdsM)
     double sx = ic1, sy = ic2;
 #define CPQ_ROW_STEP(k)                                                                                       \
     {                                                                                                         \
-        const double2 k01 = Mb2[(k) * 2], k23 = Mb2[(k) * 2 + 1];   /* 16-byte reads: one 16-bit immediate offset each */ \
-        const double k0 = k01.x, k1 = k01.y, k2 = k23.x, k3 = k23.y;                                          \
+        const double k0 = Mb[(k) * 4 + 0], k1 = Mb[(k) * 4 + 1], k2 = Mb[(k) * 4 + 2], k3 = Mb[(k) * 4 + 3];  \
         const double px = dpp_f64<kDppRowShr + (1 << (k)), 0xF>(sx);                                          \
         const double py = dpp_f64<kDppRowShr + (1 << (k)), 0xF>(sy);                                          \
         const double nx = fma(k1, py, fma(k0, px, sx));                                                       \
@@ -452,8 +450,7 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     __syncthreads();
     // state at the start of this wave's segment: the span's start state carried through the totals of the waves before it
     double bx = sCur[2 * b], by = sCur[2 * b + 1];
-    const double2 mw01 = Mb2[12], mw23 = Mb2[13];
-    const double mw0 = mw01.x, mw1 = mw01.y, mw2 = mw23.x, mw3 = mw23.y;
+    const double mw0 = Mb[24], mw1 = Mb[25], mw2 = Mb[26], mw3 = Mb[27];
     for (int w = 0; w < wave; ++w) {
         const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
         const double nx = fma(mw1, by, fma(mw0, bx, tx));
@@ -652,7 +649,7 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 // (k-step s = register s), so the span stays in registers across the 20 bands; the output stage is element-wise.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-struct alignas(16) TpLdsM {
+struct TpLdsM {
     double cf[kBands][6];        // a1 a2 a3 m0 m1 m2 (guarded fallback)
     double M[kBands][28];        // Mk[6][4], Mw[4] (scan)
     double Gq[kBands][16][4];    // (C A^i)_x, (C A^i)_y, 0, 0: A-operand rows of the state response
@@ -816,9 +813,8 @@ __device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double*
 #pragma unroll
                 for (int tau = 0; tau < 4; ++tau) {
                     double v[4] = { x[tau][0], x[tau][1], x[tau][2], x[tau][3] };
-                    // four compares with the |.| modifier (a NaN fails them and takes the guarded code below)
-                    const bool small = (int)(fabs(v[0]) < 4.5) & (int)(fabs(v[1]) < 4.5) & (int)(fabs(v[2]) < 4.5) & (int)(fabs(v[3]) < 4.5);
-                    if (smallOk && __all(small)) {
+                    const double big = fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3])));
+                    if (smallOk && __all(big < 4.5)) {
                         if (SAT) tp_nonlinear_small<4>(v, smallC1);
                     } else if (kind == 1) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
                     else                  tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
