@@ -96,11 +96,6 @@ constexpr int kLdsPerWave = 72 * 8;   // complex elements
 //   pass 1 over a (registers), twiddle W512^((8b+c) p); exchange -> lane (p, c), registers over b
 //   pass 2 over b, twiddle W64^(c q);                   exchange -> lane (p + 8q), registers over c
 //   pass 3 over c.
-// twStride: tw512[m * twStride] = exp(-2 pi i m / 512) (1 for the 512-entry table; P / 512 when the table is the
-// P-entry one of a larger partition)
-// tab (optional, LDS): 128 entries filled by wave_fill_tables -- the twiddles of both passes factor over the octal digits
-// of the lane: W512^(lane p) = W512^(p (lane & 7)) W64^(p (lane >> 3)), W64^(c q) -- so no pass waits for a dependent
-// trip to L2 behind an exchange (7 + 7 loads of 16 bytes per lane and frame otherwise)
 // LDS traffic between the lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the compiler
 // from moving them across each other
 __device__ __forceinline__ void wave_sync()
@@ -110,21 +105,32 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// v[p] *= w^p (INV: conj(w)^p), p = 1..7, the powers formed by multiplication (depth <= 3 products: a few ulp) rather than
+// read from a table: the transforms below are bound by LDS bandwidth (a frame of the P = 4096 kernels moved 106 16-byte
+// LDS accesses per lane, 42 of them twiddle-table reads), not by the VALU
+template <bool INV>
+__device__ __forceinline__ void mul_powers(double2 (&v)[8], double2 w1)
+{
+    const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+    v[1] = cmulw<INV>(v[1], w1);
+    v[2] = cmulw<INV>(v[2], w2);
+    v[3] = cmulw<INV>(v[3], w3);
+    v[4] = cmulw<INV>(v[4], w4);
+    v[5] = cmulw<INV>(v[5], cmul(w4, w1));
+    v[6] = cmulw<INV>(v[6], cmul(w3, w3));
+    v[7] = cmulw<INV>(v[7], cmul(w4, w3));
+}
+
+// 512-point complex FFT of one wave: v[p] = z[lane + 64 p] in, Z[lane + 64 c] out (three radix-8 passes, two exchanges
+// through `lds`).  wa = W512^lane, wb = W64^(lane & 7) (W_N = exp(-2 pi i / N)).
 // WAVE: the wave is part of a larger workgroup and `lds` is its private slice: wave-level synchronisation instead of
 // workgroup barriers
 template <bool INV, bool WAVE = false>
-__device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, const double2* __restrict__ tw512,
-                                             int lane, int twStride = 1, const double2* tab = nullptr)
+__device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, int lane, double2 wa, double2 wb)
 {
     auto sync = [] { if (WAVE) wave_sync(); else __syncthreads(); };
     dft8<INV>(v);
-    if (tab) {
-#pragma unroll
-        for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], cmul(tab[64 + (lane & 7) * 8 + p], tab[(lane >> 3) * 8 + p]));
-    } else {
-#pragma unroll
-        for (int p = 1; p < 8; ++p) v[p] = cmulw<INV>(v[p], tw512[lane * p * twStride]);
-    }
+    mul_powers<INV>(v, wa);
 #pragma unroll
     for (int p = 0; p < 8; ++p) lds[72 * p + lane] = v[p];
     sync();
@@ -133,29 +139,13 @@ __device__ __forceinline__ void wave_cfft512(double2 (&v)[8], double2* lds, cons
     for (int b = 0; b < 8; ++b) v[b] = lds[72 * pp + 8 * b + cc];
     sync();
     dft8<INV>(v);
-    if (tab) {
-#pragma unroll
-        for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tab[cc * 8 + q]);
-    } else {
-#pragma unroll
-        for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], tw512[8 * cc * q * twStride]);
-    }
+    mul_powers<INV>(v, wb);
 #pragma unroll
     for (int q = 0; q < 8; ++q) lds[66 * cc + pp + 8 * q] = v[q];
     sync();
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = lds[66 * c + lane];
     dft8<INV>(v);
-}
-
-// tab[d * 8 + p] = W64^(p d), tab[64 + d * 8 + p] = W512^(p d) from the 512-entry table (one wave: two loads per lane,
-// issued with the frame's own loads)
-__device__ __forceinline__ void wave_fill_tables(double2* tab, const double2* __restrict__ tw512, int lane)
-{
-    const int d = lane >> 3, p = lane & 7;
-    tab[lane] = tw512[8 * p * d];
-    tab[64 + lane] = tw512[p * d];
-    __syncthreads();            // one-wave workgroups: a wave barrier
 }
 
 // real-FFT split: Z (512-pt FFT of even+i*odd samples) -> packed spectrum of the 1024-pt real frame
@@ -193,14 +183,12 @@ __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ 
                                                      int ringMask)
 {
     __shared__ double2 lds[kLdsPerWave];
-    __shared__ double2 tab[128];
     const int lane = threadIdx.x;
     const int c = blockIdx.x / T;
     const int t = blockIdx.x - c * T;
     const double* cur = in + (int64_t)c * chStride + (int64_t)t * kP;
     const double* prev = (t > 0) ? (cur - kP) : (histOld + (int64_t)c * kP);
-    wave_fill_tables(tab, tw.tw512, lane);
-    const double2 wl = tw.tw1024[lane];
+    const double2 wl = tw.tw1024[lane], wa = tw.tw512[lane], wb = tw.tw512[8 * (lane & 7)];
 
     double2 v[8];
 #pragma unroll
@@ -212,7 +200,7 @@ __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(hn + 2 * (lane + 64 * j)) = v[4 + j];
     }
-    wave_cfft512<false>(v, lds, tw.tw512, lane, 1, tab);
+    wave_cfft512<false>(v, lds, lane, wa, wb);
     const int slot = (head + t) & ringMask;
     const int64_t row = (int64_t)c * (ringMask + 1) + slot;
     wave_split_store(v, lds, wl, lane, X + row * kP, XDN + row);
@@ -222,11 +210,9 @@ __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ he
                                                    double2* __restrict__ H, double2* __restrict__ HDN, FftTables tw)
 {
     __shared__ double2 lds[kLdsPerWave];
-    __shared__ double2 tab[128];
     const int lane = threadIdx.x;
     const int k = blockIdx.x;
-    wave_fill_tables(tab, tw.tw512, lane);
-    const double2 wl = tw.tw1024[lane];
+    const double2 wl = tw.tw1024[lane], wa = tw.tw512[lane], wb = tw.tw512[8 * (lane & 7)];
     double2 v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -235,7 +221,7 @@ __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ he
     }
 #pragma unroll
     for (int j = 4; j < 8; ++j) v[j] = make_double2(0.0, 0.0);   // zero-padded second half (NUC.cpp:921-928)
-    wave_cfft512<false>(v, lds, tw.tw512, lane, 1, tab);
+    wave_cfft512<false>(v, lds, lane, wa, wb);
     wave_split_store(v, lds, wl, lane, H + (int64_t)k * kP, HDN + k);
 }
 
@@ -243,13 +229,11 @@ __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__
                                                      int64_t chStride, FftTables tw, int T)
 {
     __shared__ double2 lds[kLdsPerWave];
-    __shared__ double2 tab[128];
     const int lane = threadIdx.x;
     const int c = blockIdx.x / T;
     const int t = blockIdx.x - c * T;
     const double2* y = Y + (int64_t)blockIdx.x * kP;
-    wave_fill_tables(tab, tw.tw512, lane);
-    const double2 wl = tw.tw1024[lane];
+    const double2 wl = tw.tw1024[lane], wa = tw.tw512[lane], wb = tw.tw512[8 * (lane & 7)];
 
     double2 v[8];
     const double2 y0 = y[0];
@@ -266,7 +250,7 @@ __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__
         if (k == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
         v[j] = z;
     }
-    wave_cfft512<true>(v, lds, tw.tw512, lane, 1, tab);
+    wave_cfft512<true>(v, lds, lane, wa, wb);
     // second half of the 1024-sample frame: z[n], n = lane + 64 r, r = 4..7  (NUC.cpp:1332)
     double* o = out + (int64_t)c * chStride + (int64_t)t * kP;
     constexpr double s = 1.0 / 512.0;
@@ -591,27 +575,22 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
 constexpr int kP4 = 4096;
 constexpr int kP4Row = kLdsPerWave;     // 576: row stride of the exchange buffer = one wave's scratch slice
 
-// t[0][d][q] = W64^(q d), t[1][d][q] = W512^(q d), t[2][d][q] = W4096^(q d)
-struct P4Tables { double2 t[3][8][8]; };
+// per-lane first powers; the rest of every twiddle set is formed by multiplication (mul_powers)
+struct P4Tables { double2 w512[64], w4096[64], w64[8]; };      // W512^lane, W4096^lane, W64^k
 
-__device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __restrict__ twM)
+__device__ __forceinline__ void p4_load_tables(P4Tables* T, const double2* __restrict__ twM)     // twM[m] = W4096^m
 {
-    for (int i = threadIdx.x; i < 3 * 64; i += blockDim.x) {
-        const int tb = i >> 6, d = (i >> 3) & 7, q = i & 7;
-        const int step = tb == 0 ? 64 : (tb == 1 ? 8 : 1);
-        T->t[tb][d][q] = twM[step * q * d];
-    }
+    const int i = threadIdx.x;
+    if (i < 64) { T->w512[i] = twM[8 * i]; T->w4096[i] = twM[i]; }
+    if (i < 8) T->w64[i] = twM[64 * i];
     __syncthreads();
 }
 
-// v[k1] *= W4096^(+-j k1)
+// v[k1] *= W4096^(+-j k1), j = lane + 64 w
 template <bool INV>
 __device__ __forceinline__ void p4_twiddle(double2 (&v)[8], const P4Tables* T, int j)
 {
-    const int d0 = j & 7, d1 = (j >> 3) & 7, d2 = (j >> 6) & 7;
-#pragma unroll
-    for (int q = 1; q < 8; ++q)
-        v[q] = cmulw<INV>(v[q], cmul(cmul(T->t[2][d0][q], T->t[1][d1][q]), T->t[0][d2][q]));
+    mul_powers<INV>(v, cmul(T->w4096[j & 63], T->w64[j >> 6]));
 }
 
 // partner of element (w, k2) in the real-FFT split, as an index into the exchange buffer
@@ -634,7 +613,7 @@ __device__ __forceinline__ void p4_forward_frame(double2 (&v)[8], double2* dyn, 
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = mine[lane + 64 * m];
     wave_sync();                            // this wave's reads before it reuses its slice as scratch
-    wave_cfft512<false, true>(v, mine, nullptr, lane, 1, &tabs->t[0][0][0]);
+    wave_cfft512<false, true>(v, mine, lane, tabs->w512[lane], tabs->w64[lane & 7]);
     // v[r] = Z[w + 8 (lane + 64 r)]; the split needs the partner wave's row
     wave_sync();
 #pragma unroll
@@ -766,7 +745,7 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
             v[r] = z;
         }
         __syncthreads();                    // every partner read is done before a wave reuses its slice as scratch
-        wave_cfft512<true, true>(v, mine, nullptr, lane, 1, &tabs.t[0][0][0]);
+        wave_cfft512<true, true>(v, mine, lane, tabs.w512[lane], tabs.w64[lane & 7]);
         // v[m] = C[w][lane + 64 m]: hand column n2 = j to thread j
         wave_sync();
 #pragma unroll
@@ -927,7 +906,7 @@ __global__ __launch_bounds__(128) void k_big_rows_fwd(const double2* __restrict_
     double2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = a[lane + 64 * r];
-    wave_cfft512<false>(v, lds[w], tw.tw512, lane, M1);
+    wave_cfft512<false>(v, lds[w], lane, tw.tw512[lane * M1], tw.tw512[8 * (lane & 7) * M1]);
 #pragma unroll
     for (int r = 0; r < 8; ++r) rows[w][lane + 64 * r] = v[r];
     __syncthreads();
@@ -984,7 +963,7 @@ __global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict_
         if (krow == 0 && k2 == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
         v[r] = z;
     }
-    wave_cfft512<true>(v, lds[w], tw.tw512, lane, M1);
+    wave_cfft512<true>(v, lds[w], lane, tw.tw512[lane * M1], tw.tw512[8 * (lane & 7) * M1]);
     double2* a = A + (int64_t)tr * P + krow * 512;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {

@@ -1,16 +1,17 @@
 #!/bin/bash
-# A/B timing of two versions of one kernel source on the GPU box (same box, alternating):
-#   tools/ab_files.sh convopeq_amd/csrc/svf_kernels.hip <version A> <version B> [rounds]
-# Prints the kernel times of the default bench per build; restores version B at the end.
-TARGET=$1; A=$2; B=$3; ROUNDS=${4:-2}
+# A/B timing of versions of one kernel source on the GPU box (same box, alternating):
+#   tools/ab_files.sh <rounds> convopeq_amd/csrc/svf_kernels.hip <version A> <version B> ...
+# Prints the kernel times of the default bench per build; restores the LAST version at the end.
+ROUNDS=$1; TARGET=$2; shift 2
 for r in $(seq $ROUNDS); do
-  for v in "$A" "$B"; do
+  for v in "$@"; do
     cp "$v" "$TARGET"
     make -C convopeq_amd/csrc >/dev/null 2>&1 || { echo "build failed: $v"; continue; }
-    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$v:', d['value'], 'M/s', {k: v for k, v in d['kernels_ms_per_step'].items() if v}, 'step', d['ms_per_step'])"
   done
 done
-cp "$B" "$TARGET"; make -C convopeq_amd/csrc >/dev/null 2>&1
+for last in "$@"; do :; done
+cp "$last" "$TARGET"; make -C convopeq_amd/csrc >/dev/null 2>&1
