@@ -720,22 +720,22 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
     double2* mine = dyn + w * kP4Row;
     for (int t = t0; t < t1; ++t) {
         double2 v[8];
-        const double2* y = ybase + (int64_t)t * kP4 + w * 512;
-        // wave w reads its row of the permuted spectrum once (streaming: the MAC wrote it past the cache); the partner
-        // element Y[4096 - k] of the real-FFT split comes through LDS
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(y + lane + 64 * r));
-            v[r] = make_double2(a.x, a.y);
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mine[lane + 64 * r] = v[r];
-        __syncthreads();
+        const double2* yrow = ybase + (int64_t)t * kP4;
+        const double2* y = yrow + w * 512;
+        // wave w reads its row of the permuted spectrum and, a second time, the row of its partner wave for the element
+        // Y[4096 - k] of the real-FFT split: the second read is served by the L2 (the workgroup reads each row twice within
+        // microseconds) and spares the LDS -- the bound of this kernel -- 16 accesses per lane and two workgroup barriers
+        double2 pa[8], pb[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int k2 = lane + 64 * r;
-            const double2 a = v[r];
-            const double2 b = dyn[p4_partner(w, k2)];
+            pa[r] = y[k2];
+            pb[r] = yrow[w == 0 ? ((512 - k2) & 511) : (8 - w) * 512 + (511 - k2)];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k2 = lane + 64 * r;
+            const double2 a = pa[r], b = pb[r];
             const double2 e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
             const double2 d = make_double2(0.5 * (a.x - b.x), 0.5 * (a.y + b.y));
             const double2 tk = cmul(wk, w16(r));
@@ -744,7 +744,6 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
             if (w == 0 && k2 == 0) z = make_double2(0.5 * (a.x + a.y), 0.5 * (a.x - a.y));
             v[r] = z;
         }
-        __syncthreads();                    // every partner read is done before a wave reuses its slice as scratch
         wave_cfft512<true, true>(v, mine, lane, tabs.w512[lane], tabs.w64[lane & 7]);
         // v[m] = C[w][lane + 64 m]: hand column n2 = j to thread j
         wave_sync();
