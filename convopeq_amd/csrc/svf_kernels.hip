@@ -883,22 +883,26 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
 // registers of a tile cover the line).  Spans with non-finite / out-of-range input go through the guarded sequential
 // code in two 4096-sample halves staged in the scratch area.  Handles whole 8192-sample spans only; the launcher runs
 // k_svf_cascade_tp on what is left.
+// WAVES = 16 (spans of 16384 samples, one workgroup per CU) is for engines with fewer channels than the chip has CUs:
+// at 128 channels the eight-wave kernel leaves half the CUs idle and the other half at two waves per SIMD.
 constexpr int kTp8Threads = 512;
 constexpr int kTp8Span = kTp8Threads * 16;
-constexpr int kTp8ScratchDoubles = 8 * (512 + 256);        // per wave: red (256 double2) + s0q (256 doubles) = 48 KB
 
-__global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double* in, double* out, int64_t chStride,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 4) void k_svf_cascade_tp8(const double* in, double* out, int64_t chStride,
                                                                 int nSpans, const double* __restrict__ coef,
                                                                 const int* __restrict__ flags,
                                                                 const double* __restrict__ satGain,
                                                                 double* __restrict__ state,
                                                                 const TpBandTables* __restrict__ tables)
 {
-    static_assert(kTp8ScratchDoubles >= 256 * kTpStride, "the guarded path stages 4096 samples in the scratch area");
-    __shared__ __align__(16) double scratch[kTp8ScratchDoubles];
+    constexpr int kThreads = WAVES * 64, kSpan = kThreads * 16;
+    constexpr int kScratchDoubles = WAVES * (512 + 256);     // per wave: red (256 double2) + s0q (256 doubles); 8 waves: 48 KB
+    static_assert(kScratchDoubles >= 256 * kTpStride, "the guarded path stages 4096 samples in the scratch area");
+    __shared__ __align__(16) double scratch[kScratchDoubles];
     __shared__ TpLdsM LM;
     __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];
-    __shared__ double wtot[2 * 2 * 8];
+    __shared__ double wtot[2 * 2 * WAVES];
     __shared__ int sFlag;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -911,12 +915,12 @@ __global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double
     double* sState = sStateA;
     double* sNext = sStateB;
     if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
-    tp_load_tables_m(&LM, cf, tb, tid, kTp8Threads);
+    tp_load_tables_m(&LM, cf, tb, tid, kThreads);
     __syncthreads();
 
     for (int sp = 0; sp < nSpans; ++sp) {
-        const double* src = in + (int64_t)c * chStride + (int64_t)sp * kTp8Span;
-        double* dst = out + (int64_t)c * chStride + (int64_t)sp * kTp8Span;
+        const double* src = in + (int64_t)c * chStride + (int64_t)sp * kSpan;
+        double* dst = out + (int64_t)c * chStride + (int64_t)sp * kSpan;
         v4d x[4];
         bool bad = false;
 #pragma unroll
@@ -934,14 +938,11 @@ __global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double
         if (__any(bad) && lane == 0) atomicOr(&sFlag, 1);
         __syncthreads();
         if (sFlag != 0) {
-            // guarded path: two halves of 4096 samples through the one-thread reference recurrence, staged in the scratch
-            // area in the [chunk][sample] layout of the four-wave kernel; in and out may alias, every sample is read
-            // before the half is written
-            for (int half = 0; half < 2; ++half) {
-                for (int it = 0; it < 8; ++it) {
-                    const int j = it * kTp8Threads + tid;
+            // guarded path: pieces of 4096 samples through the one-thread reference recurrence, staged in the scratch
+            // area as [chunk][sample]; in and out may alias, every sample of a piece is read before the piece is written
+            for (int half = 0; half < kSpan / 4096; ++half) {
+                for (int j = tid; j < 4096; j += kThreads)
                     scratch[(j / 16) * kTpStride + (j % 16)] = src[half * 4096 + j];
-                }
                 __syncthreads();
                 for (int b = 0; b < kBands; ++b) {
                     const int flag = fl[b];
@@ -953,18 +954,16 @@ __global__ __launch_bounds__(kTp8Threads, 4) void k_svf_cascade_tp8(const double
                     }
                     __syncthreads();
                 }
-                for (int it = 0; it < 8; ++it) {
-                    const int j = it * kTp8Threads + tid;
+                for (int j = tid; j < 4096; j += kThreads)
                     dst[half * 4096 + j] = scratch[(j / 16) * kTpStride + (j % 16)] * gain;
-                }
                 __syncthreads();
             }
             continue;
         }
         double2* red = reinterpret_cast<double2*>(scratch) + wave * 256;
-        double* s0q = scratch + 8 * 512 + wave * 256;
-        if (sat > 0.0) tp_bands_mfma<true, kTp8Threads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
-        else           tp_bands_mfma<false, kTp8Threads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
+        double* s0q = scratch + WAVES * 512 + wave * 256;
+        if (sat > 0.0) tp_bands_mfma<true, kThreads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
+        else           tp_bands_mfma<false, kThreads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
 #pragma unroll
         for (int tau = 0; tau < 4; ++tau) {
             double* p = dst + (wave * 64 + tau * 16 + m) * 16 + g;
@@ -1092,11 +1091,25 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
     // whole 8192-sample spans on the eight-wave kernel, what is left as one span of 1 ... 7 waves x 1024 samples, and a
     // last block of 512 on the chunk-length-2 path of the four-wave kernel
     const TpBandTables* tb = reinterpret_cast<const TpBandTables*>(tables);
-    const int nSpans8 = nSamples / kTp8Span;
+    int done = 0;
+    // fewer channels than CUs: sixteen waves per channel on the whole 16384-sample spans
+    static int nCu = 0;
+    if (nCu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        nCu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    if (nCh <= nCu && nSamples >= 2 * kTp8Span) {
+        const int nSpans16 = nSamples / (2 * kTp8Span);
+        hipLaunchKernelGGL(k_svf_cascade_tp8<16>, dim3(nCh), dim3(2 * kTp8Threads), 0, stream, in, out, chStride, nSpans16, coef,
+                           flags, satGain, state, tb);
+        done = nSpans16 * 2 * kTp8Span;
+    }
+    const int nSpans8 = (nSamples - done) / kTp8Span;
     if (nSpans8 > 0)
-        hipLaunchKernelGGL(k_svf_cascade_tp8, dim3(nCh), dim3(kTp8Threads), 0, stream, in, out, chStride, nSpans8, coef, flags,
-                           satGain, state, tb);
-    int done = nSpans8 * kTp8Span;
+        hipLaunchKernelGGL(k_svf_cascade_tp8<8>, dim3(nCh), dim3(kTp8Threads), 0, stream, in + done, out + done, chStride, nSpans8,
+                           coef, flags, satGain, state, tb);
+    done += nSpans8 * kTp8Span;
     const int nWaves = (nSamples - done) / 1024;
     if (nWaves > 0) {
         hipLaunchKernelGGL(k_svf_cascade_tpw, dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, coef,

@@ -952,14 +952,16 @@ def test_ragged_call_lengths_across_ring_wraps(amd, oracle, schedule):
 
 @pytest.mark.parametrize("sat", [0.0, 0.2])
 def test_eq_time_parallel_kernels_hand_over_state(amd, oracle, sat):
-    """One call of 43 blocks = two 8192-sample spans (eight-wave matrix-form kernel) + one span of five waves x 1024
-    samples (k_svf_cascade_tpw) + one 512-sample span (VALU form, chunk length 2); band states pass between the three
-    through the state array.  A later call injects a NaN into the second 8192-sample span (guarded path in two staged
-    halves)."""
+    """One call of 59 blocks = one 16384-sample span (sixteen-wave matrix-form kernel: this engine has fewer channels than
+    the chip has CUs) + one 8192-sample span (eight waves) + one span of five waves x 1024 samples (k_svf_cascade_tpw) +
+    one 512-sample span (VALU form, chunk length 2); band states pass between the four through the state array.  The second
+    call carries an Inf in its 8192-sample span, the third a NaN in its 16384-sample span (guarded path in staged pieces
+    of 4096 samples)."""
     O = oracle
-    S, T = 2, 43
+    S, T = 2, 59
     x = make_inputs(O, S, 3 * T * B)
     x[1, 2 * T * B + 8192 + 5000] = np.nan
+    x[2, T * B + 16384 + 3000] = np.inf
     po = O.eq_params_bench(sat)
     po.bands[6].channelMode = 1
     po.totalGainDb = 0.75
