@@ -128,3 +128,45 @@ def test_config5_share_on_the_throughput_path(amd, oracle):
     1024 would need 34 GB of host arrays for the two calls of this test; the engine's addressing is the same)."""
     worst = _run_fullsize(amd, oracle, 1024, 131072, 256, True, amd.CPQ_SCHED_UNIFORM, partition=4096)
     print("config 5 share, P = 4096: worst rms err", worst)
+
+
+@pytest.mark.parametrize("T,partition", [(64, 0), (128, -1)])
+def test_config2_convolver_is_linear_and_time_invariant_on_every_stream(amd, oracle, T, partition):
+    """Size-independent properties at BASELINE.json configs[1]'s size, checked on ALL 256 streams (the oracle comparison
+    above covers four): conv(a x1 + b x2) = a conv(x1) + b conv(x2), and a signal delayed by whole calls comes out delayed
+    (reference semantics at blk 512 is one LTI system per channel).  P = 512 at 64 blocks per call and the
+    engine's own choice (P = 4096) at 128."""
+    O = oracle
+    S, L = 256, 131072
+    n = T * B
+    eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T, partition_size=partition)
+    try:
+        for s in range(S):
+            eng.set_impulse(s, O.gen_ir(L, stream=s, channel=0), O.gen_ir(L, stream=s, channel=1))
+        x1 = np.empty((2 * S, 2 * n))
+        x2 = np.empty((2 * S, 2 * n))
+        for s in range(S):
+            for ch in range(2):
+                x1[2 * s + ch] = O.gen_pcm(2 * n, stream=s, channel=ch)
+                x2[2 * s + ch] = O.gen_pcm(2 * n, stream=s + 100000, channel=ch)
+
+        def run(x):
+            eng.conv_reset()
+            return np.concatenate([eng.conv_process(np.ascontiguousarray(x[:, c * n:(c + 1) * n])) for c in range(2)], axis=1)
+
+        y1, y2 = run(x1), run(x2)
+        y3 = run(0.5 * x1 - 2.0 * x2)
+        lin = np.abs(y3 - (0.5 * y1 - 2.0 * y2)).max(axis=1)
+        scale = float(np.sqrt(np.mean(np.square(y1))))
+        print(f"T={T} P={eng.partition_size()}: linearity max abs {lin.max():.3e} (signal rms {scale:.3f})")
+        assert lin.max() <= 1e-12 and scale > 0.05
+        # time invariance: one call of silence first
+        xd = np.concatenate([np.zeros((2 * S, n)), x1[:, :n]], axis=1)
+        yd = run(xd)
+        assert np.abs(yd[:, :n]).max() == 0.0
+        assert np.abs(yd[:, n:] - y1[:, :n]).max() <= 1e-13
+        # and no two streams produce the same output
+        sig = y1[:, n - 64:n].round(12)
+        assert len({r.tobytes() for r in sig}) == 2 * S
+    finally:
+        eng.close()
