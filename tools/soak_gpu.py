@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Seeded soak of the random GPU parity sweeps beyond the seeds tests/ runs: the EQ parameter space, the convolver's
+configuration space, random transition sequences through the whole chain, ragged calls at random quanta (CPQ_CALLS_ANY).  Prints one line per failing seed and a summary;
+exit code 1 on any failure.  usage: python tools/soak_gpu.py [first_seed] [n_seeds]   (on the GPU box)"""
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import convopeq_amd as amd          # noqa: E402
+import oracle_lib                   # noqa: E402
+import numpy as np                  # noqa: E402
+import test_gpu_parity as T         # noqa: E402
+import test_gpu_ragged as R         # noqa: E402
+
+
+def ragged_case(seed):
+    """CPQ_CALLS_ANY: random quantum (any integer 1..2048), IR length, scale, direct head, two plans in one engine, calls of
+    random ragged sizes (incl. single samples and the engine's maximum) vs the oracle's Add / Get emulation."""
+    rng = np.random.default_rng(seed)
+    quantum = int(rng.choice([int(rng.integers(1, 2049)), 441, 480, 96, 64, 512, 1000, 37]))
+    max_blocks = int(rng.integers(1, 6))
+    max_call = quantum * max_blocks
+    taps = [int(rng.choice([int(rng.integers(1, 3000)), int(rng.integers(3000, 40000)), 131072])) for _ in range(2)]
+    direct = bool(rng.random() < 0.3)
+    scale = float(rng.choice([1.0, 0.37]))
+    total = int(rng.integers(6000, 30000)) + 3 * max(taps) // 2
+    sizes = []
+    while sum(sizes) < total:
+        r = rng.random()
+        sizes.append(int(max_call if r < 0.15 else (rng.integers(1, 8) if r < 0.3 else rng.integers(1, max_call + 1))))
+    n = sum(sizes)
+    S = 2
+    irs = [R_ORACLE.gen_ir(taps[c // 2], stream=seed % 1000 + c // 2, channel=c % 2) for c in range(2 * S)]
+    x = R.make_inputs(R_ORACLE, [seed % 1000 + s for s in range(S)], n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=max(taps), max_blocks_per_call=max_blocks, call_mode=amd.CPQ_CALLS_ANY)
+    try:
+        for s in range(S):
+            eng.set_impulse(s, irs[2 * s], irs[2 * s + 1], scale=scale, direct_head=direct)
+        y = R.run_engine(eng, x, sizes)
+        for c in range(2 * S):
+            ref, _ = R.oracle_calls(R_ORACLE, irs[c], x[c], quantum, sizes, direct=direct, scale=scale)
+            R.check(y[c], ref)
+    finally:
+        eng.close()
+
+oracle_lib.lib()
+R_ORACLE = oracle_lib
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+fails = []
+t0 = time.time()
+for seed in range(first, first + count):
+    cases = [("eq", lambda: T.test_eq_random_parameter_sweep(amd, oracle_lib, seed, 48000.0 if seed % 3 else 96000.0, 512 if seed % 2 else 256)),
+             ("conv", lambda: T.test_convolver_random_configuration_sweep(amd, oracle_lib, seed)),
+             ("chain", lambda: T.test_whole_chain_random_transition_sequence(amd, oracle_lib, seed)),
+             ("ragged", lambda: ragged_case(seed))]
+    for name, fn in cases:
+        try:
+            fn()
+        except Exception as e:          # noqa: BLE001
+            fails.append((name, seed))
+            print(f"FAIL {name} seed {seed}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+            traceback.print_exc(limit=3)
+    if (seed - first) % 10 == 9:
+        print(f"... {seed - first + 1} seeds, {len(fails)} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"soak: seeds {first}..{first + count - 1}, {4 * count} cases, {len(fails)} failures: {fails}")
+sys.exit(1 if fails else 0)
