@@ -408,11 +408,7 @@ __device__ __forceinline__ void wg_stage8(double2* lds, int M, int ns, const dou
     double2 v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = lds[wgp(j + q * stride)];
-    if (ns > 1) {
-        const int tstep = M / (8 * ns);
-#pragma unroll
-        for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], twM[q * k * tstep]);
-    }
+    if (ns > 1) mul_powers<INV>(v, twM[k * (M / (8 * ns))]);      // one root per lane and stage, its powers by multiplication
     dft8<INV>(v);
     __syncthreads();
     const int o = ((j - k) << 3) + k;
@@ -787,8 +783,7 @@ __device__ __forceinline__ void col_stage8(double2* lds, int M1, int ns, const d
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = lds[(j + q * stride) * kBigCols + col];
     const int tstep = (M1 / (8 * ns)) * 512;             // exp(-2 pi i m / M1) = twP[m * 512]
-#pragma unroll
-    for (int q = 1; q < 8; ++q) v[q] = cmulw<INV>(v[q], twP[q * k * tstep]);
+    mul_powers<INV>(v, twP[k * tstep]);
     dft8<INV>(v);
     __syncthreads();
     const int o = ((j - k) << 3) + k;
