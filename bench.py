@@ -639,10 +639,7 @@ def main():
                     "frac": round((dk.get("fp64_tflops") or 0.0) / FP64_VECTOR_PEAK_TFLOPS, 4),
                     "note": "k_svf_cascade_tp is fp64-issue bound, not HBM bound: 20 sequential nonlinear bands per sample, "
                             "33 flops per band-sample in the reference's arithmetic against 16 B of HBM traffic per sample; fp64 "
-                            "MFMA and VALU share one datapath on gfx950 (profiles/r02a_ubench_fp64_valu_mfma_coexec.txt); "
-                            "`traffic` (PMC) is ~1.7x the algorithmic bytes because every lane loads / stores its samples "
-                            "as 8-byte words in the MFMA register layout (partial 32-byte sectors per instruction): ~1 TB/s "
-                            "of HBM traffic under a 7 ms kernel, not a bound (a transposing 32-byte variant measured +1 %)",
+                            "MFMA and VALU share one datapath on gfx950 (profiles/r02a_ubench_fp64_valu_mfma_coexec.txt)",
                     "hbm_kernel": {"kernel": "k_fdl_mac", "achieved": per_kernel["k_fdl_mac"]["achieved_gbs"] if "k_fdl_mac" in per_kernel else None,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(per_kernel["k_fdl_mac"]["achieved_gbs"] / HBM_PEAK_GBS, 4) if "k_fdl_mac" in per_kernel else None,

@@ -875,6 +875,51 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
+// Span I/O of the matrix-form kernels.  The MFMA layout wants lane (m, g) to hold samples g + 4 j (register j) of chunk m;
+// loaded as such, one instruction touches an 8-byte word in 16 different 128-byte lines and every 32-byte sector is fetched
+// (and written) in pieces: PMC traffic 1.7x the algorithmic bytes.  Instead lane (m, g) moves the whole sector, samples
+// 4 g ... 4 g + 3, with two 16-byte accesses and a 4 x 4 transpose across the four 16-lane rows of the wave puts them in
+// place (v_permlane32_swap / v_permlane16_swap, tools/ubench/permlane_transpose.hip: 8 VALU instructions per tile).
+__device__ __forceinline__ void tp_swap32(double& a, double& b)      // rows 2,3 of a <-> rows 0,1 of b
+{
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double(h[0], l[0]);
+    b = __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ void tp_swap16(double& a, double& b)      // rows 1,3 of a <-> rows 0,2 of b
+{
+    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double(h[0], l[0]);
+    b = __hiloint2double(h[1], l[1]);
+}
+// s[i] at row g = element (g, i)  ->  s[j] at row g = element (j, g); its own inverse
+__device__ __forceinline__ void tp_transpose4(double (&s)[4])
+{
+    tp_swap32(s[0], s[2]);
+    tp_swap32(s[1], s[3]);
+    tp_swap16(s[0], s[1]);
+    tp_swap16(s[2], s[3]);
+}
+// chunk = the 16 samples of chunk m (128-byte aligned); g = lane >> 4
+__device__ __forceinline__ v4d tp_tile_load(const double* chunk, int g)
+{
+    const double2 a = *reinterpret_cast<const double2*>(chunk + 4 * g), b = *reinterpret_cast<const double2*>(chunk + 4 * g + 2);
+    double s[4] = { a.x, a.y, b.x, b.y };
+    tp_transpose4(s);
+    return v4d{ s[0], s[1], s[2], s[3] };
+}
+__device__ __forceinline__ void tp_tile_store(double* chunk, int g, v4d x, double gain)
+{
+    double s[4] = { x[0] * gain, x[1] * gain, x[2] * gain, x[3] * gain };
+    tp_transpose4(s);
+    *reinterpret_cast<double2*>(chunk + 4 * g) = make_double2(s[0], s[1]);
+    *reinterpret_cast<double2*>(chunk + 4 * g + 2) = make_double2(s[2], s[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Eight waves per channel: spans of 8192 samples (512 chunks of 16).  The band loop is a dependent chain (end states ->
 // reduction -> scan -> product -> output stage) that two waves per SIMD do not hide; with twice the waves per channel
@@ -925,12 +970,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_svf_cascade_tp8(const double*
         bool bad = false;
 #pragma unroll
         for (int tau = 0; tau < 4; ++tau) {
-            const double* p = src + (wave * 64 + tau * 16 + m) * 16 + g;
+            x[tau] = tp_tile_load(src + (wave * 64 + tau * 16 + m) * 16, g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                x[tau][j] = p[4 * j];
-                bad |= !(fabs(x[tau][j]) < kTpInputBound);
-            }
+            for (int j = 0; j < 4; ++j) bad |= !(fabs(x[tau][j]) < kTpInputBound);
         }
         if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
         if (tid == 0) sFlag = 0;
@@ -965,11 +1007,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void k_svf_cascade_tp8(const double*
         if (sat > 0.0) tp_bands_mfma<true, kThreads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
         else           tp_bands_mfma<false, kThreads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
 #pragma unroll
-        for (int tau = 0; tau < 4; ++tau) {
-            double* p = dst + (wave * 64 + tau * 16 + m) * 16 + g;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[4 * j] = x[tau][j] * gain;
-        }
+        for (int tau = 0; tau < 4; ++tau) tp_tile_store(dst + (wave * 64 + tau * 16 + m) * 16, g, x[tau], gain);
         __syncthreads();                      // the last thread's end states are in sNext
         { double* t = sState; sState = sNext; sNext = t; }
     }
@@ -1019,12 +1057,9 @@ __global__ __launch_bounds__(kTpwMaxWaves * 64, 4) void k_svf_cascade_tpw(const 
     bool bad = false;
 #pragma unroll
     for (int tau = 0; tau < 4; ++tau) {
-        const double* p = src + (wave * 64 + tau * 16 + m) * 16 + g;
+        x[tau] = tp_tile_load(src + (wave * 64 + tau * 16 + m) * 16, g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x[tau][j] = p[4 * j];
-            bad |= !(fabs(x[tau][j]) < kTpInputBound);
-        }
+        for (int j = 0; j < 4; ++j) bad |= !(fabs(x[tau][j]) < kTpInputBound);
     }
     if (tid < kBands * 2) bad |= !(fabs(sStateA[tid]) < kTpInputBound);
     if (__any(bad) && lane == 0) atomicOr(&sFlag, 1);
@@ -1058,11 +1093,7 @@ __global__ __launch_bounds__(kTpwMaxWaves * 64, 4) void k_svf_cascade_tpw(const 
     if (sat > 0.0) tp_bands_mfma<true, 0>(x, red, s0q, wtot, sStateA, sStateB, &LM, tid, fl, tb, sat);
     else           tp_bands_mfma<false, 0>(x, red, s0q, wtot, sStateA, sStateB, &LM, tid, fl, tb, sat);
 #pragma unroll
-    for (int tau = 0; tau < 4; ++tau) {
-        double* p = dst + (wave * 64 + tau * 16 + m) * 16 + g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) p[4 * j] = x[tau][j] * gain;
-    }
+    for (int tau = 0; tau < 4; ++tau) tp_tile_store(dst + (wave * 64 + tau * 16 + m) * 16, g, x[tau], gain);
     __syncthreads();                          // the span's end states are in sStateB
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sStateB[tid];
 }
