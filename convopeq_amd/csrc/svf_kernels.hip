@@ -907,7 +907,10 @@ __device__ __forceinline__ void tp_transpose4(double (&s)[4])
 // chunk = the 16 samples of chunk m (128-byte aligned); g = lane >> 4
 __device__ __forceinline__ v4d tp_tile_load(const double* chunk, int g)
 {
-    const double2 a = *reinterpret_cast<const double2*>(chunk + 4 * g), b = *reinterpret_cast<const double2*>(chunk + 4 * g + 2);
+    // streaming accesses: a span is read once and written once per call; the L2 is left to the per-stream scan tables
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2 a = __builtin_nontemporal_load(reinterpret_cast<const v2*>(chunk + 4 * g));
+    const v2 b = __builtin_nontemporal_load(reinterpret_cast<const v2*>(chunk + 4 * g + 2));
     double s[4] = { a.x, a.y, b.x, b.y };
     tp_transpose4(s);
     return v4d{ s[0], s[1], s[2], s[3] };
@@ -924,7 +927,9 @@ __device__ __forceinline__ void tp_tile_store(double* tile, double* buf, int lan
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = lane + 64 * i;                          // pair of samples: chunk p >> 3, samples 2 (p & 7), + 1
-        *reinterpret_cast<double2*>(tile + 2 * p) = *reinterpret_cast<const double2*>(buf + (p >> 3) * kTpStride + 2 * (p & 7));
+        typedef double v2 __attribute__((ext_vector_type(2)));
+        const double2 v = *reinterpret_cast<const double2*>(buf + (p >> 3) * kTpStride + 2 * (p & 7));
+        __builtin_nontemporal_store(v2{ v.x, v.y }, reinterpret_cast<v2*>(tile + 2 * p));
     }
     wave_lds_sync();                                          // the next tile reuses buf
 }
