@@ -229,7 +229,8 @@ int enqueueEqCore(cpq_engine* e, const double* dIn, double* dOut, int64_t stride
 // (band nodes) and cross-faded with the dry block sample by sample; once the fade-out is complete the EQ returns early
 // (states, gain ramp and AGC frozen); releasing the bypass clears every filter state and fades back in.  The call is cut
 // where some stream changes class, each piece runs the ordinary kernels with the streams' tables switched accordingly.
-int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
+// n samples of rows `stride` apart: whole callbacks of e->B samples, or (no per-callback state in play) any n
+static int enqueueEqRange(cpq_engine* e, const double* dIn, double* dOut, int64_t stride, int n)
 {
     if (!e->eqSet) return fail(e, CPQ_ERR_NOT_READY, "cpq_eq_set_params has not been called");
     const int S = e->desc.n_streams;
@@ -242,7 +243,7 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
         for (int s = 0; s < S; ++s)
             if (e->agcResetPending[s]) { const int rc = agcReset(s); if (rc != CPQ_OK) return rc; }
         e->eqProcessed = true;
-        return enqueueEqCore(e, dIn, dOut, (int64_t)n, n, nullptr);
+        return enqueueEqCore(e, dIn, dOut, stride, n, nullptr);
     }
     if (n % e->B != 0)
         return fail(e, CPQ_ERR_UNSUPPORTED, "an EQ bypass transition or band reset is pending: the call must be whole callbacks of %d samples", e->B);
@@ -300,7 +301,7 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
                     hipHostMalloc((void**)&e->silentHost, sizeof(int) * S * cbMax) != hipSuccess)
                     return fail(e, CPQ_ERR_OOM, "silence flags could not be allocated");
             }
-            cpq::launch_block_silence(e->stream, dIn, (int64_t)n, e->B, cbs, S, e->silentDev);
+            cpq::launch_block_silence(e->stream, dIn, stride, e->B, cbs, S, e->silentDev);
             CPQ_HIP(e, hipMemcpyAsync(e->silentHost, e->silentDev, sizeof(int) * (size_t)S * cbs, hipMemcpyDeviceToHost, e->stream));
             CPQ_HIP(e, hipStreamSynchronize(e->stream));
         }
@@ -391,12 +392,12 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
             { const int rcUp = stageUpload(e, e->blendEnd, endHost.data(), sizeof(double) * S); if (rcUp != CPQ_OK) return rcUp; }
             { const int rcUp = stageUpload(e, e->blendGains, gainsHost.data(), sizeof(double) * gainsHost.size()); if (rcUp != CPQ_OK) return rcUp; }
             ProfScope p(e, CPQ_K_MIX);
-            cpq::launch_rows_copy(e->stream, dIn, (int64_t)n, off, e->eqDry, (int64_t)nSeg, 0, nSeg, e->nCh);
+            cpq::launch_rows_copy(e->stream, dIn, stride, off, e->eqDry, (int64_t)nSeg, 0, nSeg, e->nCh);
         }
-        rc = enqueueEqCore(e, dIn + off, dOut + off, (int64_t)n, nSeg, pass.data());
+        rc = enqueueEqCore(e, dIn + off, dOut + off, stride, nSeg, pass.data());
         if (rc == CPQ_OK && anyFade) {
             ProfScope p(e, CPQ_K_MIX);
-            cpq::launch_bypass_blend(e->stream, dOut + off, (int64_t)n, e->eqDry, (int64_t)nSeg, nSeg, e->nCh, e->blendOn,
+            cpq::launch_bypass_blend(e->stream, dOut + off, stride, e->eqDry, (int64_t)nSeg, nSeg, e->nCh, e->blendOn,
                                      e->blendLen, e->blendEnd, e->blendGains, e->blendCap);
             CPQ_HIP(e, hipGetLastError());
         }
@@ -404,6 +405,31 @@ int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
     }
     e->anyEqBypass = stillActive;
     return rc;
+}
+
+// A call whose last callback is shorter than the quantum (CPQ_CALLS_ANY: n = k B + r) runs as the whole callbacks followed
+// by ONE callback of r samples, as the reference's process(block) sees them (src/convolver/ConvolverProcessor.Runtime.cpp:
+// 659-682 cuts the host block the same way): the total-gain ramp skips r samples, the AGC takes its RMS and its block
+// coefficients (table[numSamples], src/eqprocessor/EQProcessor.Processing.cpp:383-400) over r samples, the bypass fade
+// draws r values.  Without per-callback state in play the cascade simply runs over all n samples.
+int enqueueEq(cpq_engine* e, const double* dIn, double* dOut, int n)
+{
+    const int r = n % e->B;
+    bool perCallback = e->anyAgc || e->anyEqBypass || e->anyEqReset;
+    for (size_t s = 0; s < e->gainRamp.size() && !perCallback; ++s) {
+        const auto& g = e->gainRamp[s];
+        perCallback = !e->agcOnHost[s] && (g.remaining > 0 || std::fabs(g.target - g.wanted) > 1e-6 || g.current != g.wanted);
+    }
+    if (r == 0 || !perCallback) return enqueueEqRange(e, dIn, dOut, (int64_t)n, n);
+    int rc = CPQ_OK;
+    if (n - r > 0) rc = enqueueEqRange(e, dIn, dOut, (int64_t)n, n - r);
+    if (rc != CPQ_OK) return rc;
+    struct QuantumOf {            // the short callback is a callback of r samples to everything below
+        cpq_engine* e; int saved;
+        QuantumOf(cpq_engine* e_, int b) : e(e_), saved(e_->B) { e->B = b; }
+        ~QuantumOf() { e->B = saved; }
+    } tail(e, r);
+    return enqueueEqRange(e, dIn + (n - r), dOut + (n - r), (int64_t)n, r);
 }
 
 int enqueueOutFilter(cpq_engine* e, const double* dIn, double* dOut, int n)

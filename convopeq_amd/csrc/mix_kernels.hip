@@ -163,12 +163,14 @@ __global__ __launch_bounds__(64) void k_agc_block_rms(const double* __restrict__
     const int t = live ? grp - c * T : 0;
     const double* d = x + (int64_t)c * chStride + (int64_t)t * B;
     double acc = 0.0;
+    const int vEnd = B & ~3;              // four accumulator lanes over the whole groups of 4, then the scalar remainder
     if (live)
-        for (int i = j; i < B; i += 4) acc = fma(d[i], d[i], acc);
+        for (int i = j; i < vEnd; i += 4) acc = fma(d[i], d[i], acc);
     const int base = threadIdx.x & ~3;
     const double a0 = __shfl(acc, base), a1 = __shfl(acc, base + 1), a2 = __shfl(acc, base + 2), a3 = __shfl(acc, base + 3);
     if (live && j == 0) {
-        const double sumSq = ((a0 + a1) + a2) + a3;
+        double sumSq = ((a0 + a1) + a2) + a3;
+        for (int i = vEnd; i < B; ++i) sumSq += d[i] * d[i];
         rms[grp] = sqrt(sumSq / (double)B);
     }
 }
@@ -225,10 +227,17 @@ __global__ __launch_bounds__(256) void k_agc_ramp(double* data, int64_t chStride
         const int t = idx / B, i = idx - t * B;
         const double start = gains[((int64_t)s * T + t) * 2], inc = gains[((int64_t)s * T + t) * 2 + 1];
         const int j = i & 3, q = (i >> 2) & 3, mm = i >> 4;
-        double g = (j == 0) ? start : (j == 1 ? start + inc : (j == 2 ? start + 2.0 * inc : start + 3.0 * inc));
-        const double inc4 = 4.0 * inc, inc16 = 16.0 * inc;
-        for (int k = 0; k < mm; ++k) g = g + inc16;
-        for (int k = 0; k < q; ++k) g = g + inc4;
+        const int vEnd4 = B & ~3;
+        double g;
+        if (i >= vEnd4) {             // scalar remainder of a callback whose length is not a multiple of 4 (:331-332)
+            g = start + (double)vEnd4 * inc;
+            for (int k = vEnd4; k < i; ++k) g = g + inc;
+        } else {
+            g = (j == 0) ? start : (j == 1 ? start + inc : (j == 2 ? start + 2.0 * inc : start + 3.0 * inc));
+            const double inc4 = 4.0 * inc, inc16 = 16.0 * inc;
+            for (int k = 0; k < mm; ++k) g = g + inc16;
+            for (int k = 0; k < q; ++k) g = g + inc4;
+        }
         d[idx] *= g;
     }
 }

@@ -76,14 +76,15 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
     const double oneMinusSat = 1.0 - sat;
 
     double ylast = 0.0, xlast = 0.0;
-    const int nChunks = nSamples / 64;      // nSamples is a multiple of the 64-sample minimum block
+    const int nChunks = (nSamples + 63) / 64;      // any nSamples (CPQ_CALLS_ANY: 480-sample callbacks, ragged calls): the last chunk may be short
 
     for (int chunk = 0; chunk <= nChunks; ++chunk) {
         // stage the next 64 input samples of the wave's channels (last iteration only drains the skew)
         if (chunk < nChunks) {
 #pragma unroll
             for (int q = 0; q < kChPerWave; ++q)
-                if (c0 + q < nCh) xin[q][lane] = in[(int64_t)(c0 + q) * chStride + (int64_t)chunk * 64 + lane];
+                if (c0 + q < nCh)
+                    xin[q][lane] = (chunk * 64 + lane < nSamples) ? in[(int64_t)(c0 + q) * chStride + (int64_t)chunk * 64 + lane] : 0.0;
         }
         __syncthreads();
         const int steps = (chunk < nChunks) ? 64 : (kBands - 1);
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
         if (chunk >= 1) {
 #pragma unroll
             for (int q = 0; q < kChPerWave; ++q)
-                if (c0 + q < nCh)
+                if (c0 + q < nCh && (chunk - 1) * 64 + lane < nSamples)
                     out[(int64_t)(c0 + q) * chStride + (int64_t)(chunk - 1) * 64 + lane] =
                         yout[q][((chunk - 1) * 64 + lane) & 127];
         }

@@ -235,3 +235,141 @@ def test_per_stream_bypass_rests_one_convolver(amd, oracle):
             nuc.close()
             assert rms(y[2 * s + ch] - ref) <= 1e-13, (s, ch)
     eng.close()
+
+
+def _copy_eq(po, pa):
+    for i in range(20):
+        b, o = pa.bands[i], po.bands[i]
+        b.frequency, b.gain, b.q, b.enabled, b.type, b.channel_mode = o.frequency, o.gain, o.q, o.enabled, o.type, o.channelMode
+    pa.total_gain_db, pa.agc_enabled = po.totalGainDb, po.agcEnabled
+    pa.nonlinear_saturation, pa.filter_structure = po.nonlinearSaturation, po.filterStructure
+    return pa
+
+
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+@pytest.mark.parametrize("agc", [False, True])
+def test_eq_short_last_callback_with_ramp_and_agc(amd, oracle, agc, mode):
+    """CPQ_CALLS_ANY with the EQ's per-callback state in play: calls of k x 480 + r samples.  The short last callback is a
+    callback of r samples to the total-gain ramp (skip(r)), to the block-rate AGC (RMS and table[numSamples] coefficients
+    over r samples, src/eqprocessor/EQProcessor.Processing.cpp:376-427) and to the cascade, as in the reference's
+    process(block); the oracle cuts the call the same way (orc_eq_process_stereo: blocks of `quantum`, the last shorter)."""
+    O = oracle
+    quantum, S = 480, 2
+    call_sizes = [480 * 3 + 200, 480 * 2, 137, 480 + 479, 1, 480 * 4, 959, 480 * 4 + 1, 333, 480 * 4]
+    gains_db = {0: -1.5, 2: 3.0, 3: -6.0, 6: 0.5}             # change points (call index -> new total gain): ramps run through
+    n = sum(call_sizes)                                       # the ragged calls
+    x = make_inputs(O, range(S), n)
+    x[:, 3000:5000] *= 5.0                                    # a level step so that the AGC gain moves
+    po = O.eq_params_bench(0.2)
+    po.agcEnabled = 1 if agc else 0
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=512, max_blocks_per_call=5, call_mode=amd.CPQ_CALLS_ANY)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    state = [np.zeros(168) for _ in range(S)]
+    worst, pos = 0.0, 0
+    for k, m in enumerate(call_sizes):
+        if k in gains_db or k == 0:
+            po.totalGainDb = gains_db.get(k, po.totalGainDb)
+            eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_eq(po, amd.eq_params_default()))
+        seg = np.ascontiguousarray(x[:, pos:pos + m])
+        y = eng.eq_process(seg)
+        for s in range(S):
+            yl, yr, state[s] = O.eq_process_stereo(seg[2 * s], seg[2 * s + 1], po, block=quantum, state=state[s])
+            worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+        pos += m
+    print(f"ragged EQ agc={agc} {mode}: max abs diff {worst:.3e}")
+    assert worst <= 1e-12
+    eng.close()
+
+
+@pytest.mark.parametrize("quantum", [480, 441])
+@pytest.mark.parametrize("agc", [False, True])
+def test_eq_bypass_fade_and_band_reset_across_short_callbacks(amd, oracle, quantum, agc):
+    """The EQ bypass state machine (5 ms fade through the basic path, frozen state, state clear + fade-in on release) and a
+    band reset with calls of k x quantum + r samples: the short last callback draws r values of the fade ramp, like any
+    other callback (EqWithBypass in tests/oracle_lib.py, driven callback by callback with the same cuts)."""
+    O = oracle
+    S = 2
+    call_sizes = [quantum * 2 + 100, quantum, 77, quantum * 3, quantum + 1, quantum * 2 + quantum // 2, 5, quantum * 3 - 1,
+                  quantum * 2, quantum * 3 + 17]
+    req = [[0, 1, 1, 1, 0, 0, 1, 0, 0, 0],
+           [0, 0, 1, 0, 1, 1, 0, 0, 1, 0]]
+    po = O.eq_params_bench(0.2)
+    po.bands[5].gain = 0.0                                 # a flat band: drops out of the basic path's band nodes
+    po.totalGainDb = -2.0
+    po.agcEnabled = int(agc)
+    n = sum(call_sizes)
+    x = make_inputs(O, range(S), n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=512, max_blocks_per_call=4, call_mode=amd.CPQ_CALLS_ANY)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_eq(po, amd.eq_params_default()))
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    outs, pos = [], 0
+    for k, m in enumerate(call_sizes):
+        for s in range(S):
+            eng.set_eq_bypass(s, req[s][k])
+        if k == 7:
+            eng.request_band_reset(1, 0x00000F0F)
+        outs.append(eng.eq_process(np.ascontiguousarray(x[:, pos:pos + m])))
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    for s in range(S):
+        ref = O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, quantum)
+        rl, rr, pos = [], [], 0
+        for k, m in enumerate(call_sizes):
+            if k == 7 and s == 1:
+                ref.request_band_reset(0x00000F0F)
+            o = 0
+            while o < m:
+                ln = min(quantum, m - o)
+                a, b = ref.callback(x[2 * s, pos + o:pos + o + ln].copy(), x[2 * s + 1, pos + o:pos + o + ln].copy(), bool(req[s][k]))
+                rl.append(a)
+                rr.append(b)
+                o += ln
+            pos += m
+        err = max(np.abs(y[2 * s] - np.concatenate(rl)).max(), np.abs(y[2 * s + 1] - np.concatenate(rr)).max())
+        print(f"ragged bypass quantum {quantum} agc={agc} stream {s}: max abs diff {err:.3e}")
+        assert err <= 1e-13, (s, err)
+
+
+@pytest.mark.parametrize("quantum,taps", [(441, 20000), (480, 131072)])
+def test_whole_chain_at_arbitrary_quantum(amd, oracle, quantum, taps):
+    """cpq_engine_process_block with CPQ_CALLS_ANY: convolver (Add + Get per callback of `quantum`, the last one of a call
+    shorter) followed by the EQ on the same callbacks, with the AGC on one stream and a total-gain ramp on the other."""
+    O = oracle
+    S = 2
+    call_sizes = [quantum * 3 + 123, quantum * 2, 59, quantum * 4, quantum + quantum // 3, quantum * 4 - 1, 1, quantum * 3]
+    n = sum(call_sizes)
+    irs = [O.gen_ir(taps, stream=20 + c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, range(20, 20 + S), n)
+    pos_params = [O.eq_params_bench(0.2), O.eq_params_bench(0.2)]
+    pos_params[0].agcEnabled = 1
+    pos_params[1].totalGainDb = -4.0
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=4, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+        eng.set_eq_params(s, _copy_eq(pos_params[s], amd.eq_params_default()))
+    outs, pos = [], 0
+    for k, m in enumerate(call_sizes):
+        if k == 3:                                          # a gain change: the ramp runs through ragged calls
+            pos_params[1].totalGainDb = 2.5
+            eng.set_eq_params(1, _copy_eq(pos_params[1], amd.eq_params_default()))
+        outs.append(eng.process(np.ascontiguousarray(x[:, pos:pos + m])))
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    worst = 0.0
+    for s in range(S):
+        conv = [oracle_calls(O, irs[2 * s + ch], x[2 * s + ch], quantum, call_sizes)[0] for ch in range(2)]
+        state = np.zeros(168)
+        po = O.eq_params_bench(0.2)
+        po.agcEnabled = 1 if s == 0 else 0
+        po.totalGainDb = 0.0 if s == 0 else -4.0
+        pos = 0
+        for k, m in enumerate(call_sizes):
+            if k == 3 and s == 1:
+                po.totalGainDb = 2.5
+            yl, yr, state = O.eq_process_stereo(conv[0][pos:pos + m], conv[1][pos:pos + m], po, block=quantum, state=state)
+            worst = max(worst, rms(y[2 * s, pos:pos + m] - yl), rms(y[2 * s + 1, pos:pos + m] - yr))
+            pos += m
+    print(f"whole chain quantum {quantum}, {taps} taps: worst rms err per call {worst:.3e}")
+    assert worst <= 1e-12
