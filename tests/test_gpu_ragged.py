@@ -373,3 +373,68 @@ def test_whole_chain_at_arbitrary_quantum(amd, oracle, quantum, taps):
             pos += m
     print(f"whole chain quantum {quantum}, {taps} taps: worst rms err per call {worst:.3e}")
     assert worst <= 1e-12
+
+
+@pytest.mark.parametrize("quantum,mix,peak", [(480, 0.35, 100), (441, 1.0, 0), (96, 0.0, 33)])
+def test_processor_level_at_arbitrary_quantum(amd, oracle, quantum, mix, peak):
+    """ConvolverProcessor::process steady state (dry delay line of getLatency() + irPeakLatency, equal-power mix, wet
+    sanitise) around the convolver at a call quantum that is not a power of two and with ragged calls: the algorithm
+    latency is the layer-0 partition nextPow2(max(quantum, 64)), not the quantum."""
+    O = oracle
+    L = O.lib()
+    S, taps = 2, 9000
+    call_sizes = [quantum * 3 + 11, quantum, 7, quantum * 4, quantum * 2 + quantum // 2, 1, quantum * 4 - 3, quantum * 3]
+    n = sum(call_sizes)
+    irs = [O.gen_ir(taps, stream=30 + c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, range(30, 30 + S), n)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=4, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=mix, ir_peak_latency=peak)
+    p0 = max(64, 1 << (quantum - 1).bit_length())
+    assert eng.convproc_delay(0) == p0 + peak
+    outs, pos = [], 0
+    for m in call_sizes:
+        outs.append(eng.convproc_process(np.ascontiguousarray(x[:, pos:pos + m])))
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    mixd = float(np.float32(mix))
+    delay = p0 + peak
+    for c in range(2 * S):
+        dry = np.zeros(n)
+        dry[delay:] = x[c][:n - delay]
+        if not (mixd > 0.001):
+            ref = dry
+        else:
+            wet, _ = oracle_calls(O, irs[c], x[c], quantum, call_sizes)
+            wet_g = L.orc_equal_power_sin(mixd) * 1.0
+            dry_g = L.orc_equal_power_sin(1.0 - mixd) if mixd < 0.999 else 0.0
+            ref = (wet * wet_g) + (dry * dry_g)
+        err = rms(y[c] - ref)
+        assert err <= 1e-13, (c, err)
+
+
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+def test_output_filter_with_ragged_calls(amd, oracle, mode):
+    """OutputFilter (three DF-II-T sections, a stateless-per-callback cascade) over calls of any length: the cascade kernels
+    take any sample count; the filter state carries across the cuts."""
+    O = oracle
+    S, quantum = 2, 441
+    call_sizes = [441 * 3 + 17, 441, 5, 441 * 4, 1000, 1, 441 * 2 + 63, 441 * 4 - 1]
+    n = sum(call_sizes)
+    x = make_inputs(O, range(S), n)
+    q = O.outfilter_design(1, 1, 1, 2, 48000.0)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=512, max_blocks_per_call=4, call_mode=amd.CPQ_CALLS_ANY)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 1, 1, 1, 2)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    outs, pos = [], 0
+    for m in call_sizes:
+        outs.append(eng.outfilter_process(np.ascontiguousarray(x[:, pos:pos + m])))
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    for s in range(S):
+        yl, yr, _ = O.outfilter_process_stereo(x[2 * s], x[2 * s + 1], q)
+        worst = max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+        assert worst <= (0.0 if mode == "sequential" else 5e-12), worst

@@ -37,14 +37,48 @@ def ragged_case(seed):
     S = 2
     irs = [R_ORACLE.gen_ir(taps[c // 2], stream=seed % 1000 + c // 2, channel=c % 2) for c in range(2 * S)]
     x = R.make_inputs(R_ORACLE, [seed % 1000 + s for s in range(S)], n)
+    with_eq = bool(rng.random() < 0.5)                 # the whole chain: the EQ runs on the same callbacks (AGC, a gain ramp)
     eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=max(taps), max_blocks_per_call=max_blocks, call_mode=amd.CPQ_CALLS_ANY)
     try:
         for s in range(S):
             eng.set_impulse(s, irs[2 * s], irs[2 * s + 1], scale=scale, direct_head=direct)
-        y = R.run_engine(eng, x, sizes)
-        for c in range(2 * S):
-            ref, _ = R.oracle_calls(R_ORACLE, irs[c], x[c], quantum, sizes, direct=direct, scale=scale)
-            R.check(y[c], ref)
+        if not with_eq:
+            y = R.run_engine(eng, x, sizes)
+            for c in range(2 * S):
+                ref, _ = R.oracle_calls(R_ORACLE, irs[c], x[c], quantum, sizes, direct=direct, scale=scale)
+                R.check(y[c], ref)
+            return
+        pos_p = [R_ORACLE.eq_params_bench(float(rng.choice([0.0, 0.2, 0.7]))) for _ in range(S)]
+        pos_p[0].agcEnabled = int(rng.random() < 0.5)
+        gain0 = float(rng.uniform(-6, 6))
+        pos_p[1].totalGainDb = gain0
+        if rng.random() < 0.5:
+            eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+        for s in range(S):
+            eng.set_eq_params(s, R._copy_eq(pos_p[s], amd.eq_params_default()))
+        change_at = int(rng.integers(0, len(sizes)))
+        new_gain = float(rng.uniform(-9, 3))
+        outs, pos = [], 0
+        for k, m in enumerate(sizes):
+            if k == change_at:
+                pos_p[1].totalGainDb = new_gain
+                eng.set_eq_params(1, R._copy_eq(pos_p[1], amd.eq_params_default()))
+            outs.append(eng.process(np.ascontiguousarray(x[:, pos:pos + m])))
+            pos += m
+        y = np.concatenate(outs, axis=1)
+        for s in range(S):
+            conv = [R.oracle_calls(R_ORACLE, irs[2 * s + ch], x[2 * s + ch], quantum, sizes, direct=direct, scale=scale)[0] for ch in range(2)]
+            po = R_ORACLE.EqParams.from_buffer_copy(pos_p[s])
+            if s == 1:
+                po.totalGainDb = gain0
+            state, pos = np.zeros(168), 0
+            for k, m in enumerate(sizes):
+                if k == change_at and s == 1:
+                    po.totalGainDb = new_gain
+                yl, yr, state = R_ORACLE.eq_process_stereo(conv[0][pos:pos + m], conv[1][pos:pos + m], po, block=quantum, state=state)
+                err = max(R.rms(y[2 * s, pos:pos + m] - yl), R.rms(y[2 * s + 1, pos:pos + m] - yr))
+                assert err <= 1e-12, (s, k, err)
+                pos += m
     finally:
         eng.close()
 
