@@ -438,3 +438,49 @@ def test_output_filter_with_ragged_calls(amd, oracle, mode):
         yl, yr, _ = O.outfilter_process_stereo(x[2 * s], x[2 * s + 1], q)
         worst = max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
         assert worst <= (0.0 if mode == "sequential" else 5e-12), worst
+
+
+def test_dspcore_chain_at_arbitrary_quantum(amd, oracle):
+    """DSPCore's order Conv (processor level: dry delay + equal-power mix) -> EQ (AGC on) -> OutputFilter through
+    cpq_engine_process_block at a 480-sample quantum with ragged calls."""
+    O = oracle
+    L = O.lib()
+    S, quantum, taps, mix = 2, 480, 7000, 0.6
+    call_sizes = [480 * 3 + 250, 480, 3, 480 * 4, 480 * 2 + 479, 480 * 4 - 7, 480 * 3]
+    n = sum(call_sizes)
+    irs = [O.gen_ir(taps, stream=40 + c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, range(40, 40 + S), n)
+    po = O.eq_params_bench(0.2)
+    po.agcEnabled = 1
+    q = O.outfilter_design(0, 1, 0, 1, 48000.0)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=4, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_eq(po, amd.eq_params_default()))
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=mix)
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    eng.enable_output_filter(True)
+    outs, pos = [], 0
+    for m in call_sizes:
+        outs.append(eng.process(np.ascontiguousarray(x[:, pos:pos + m])))
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    mixd = float(np.float32(mix))
+    wet_g, dry_g = L.orc_equal_power_sin(mixd) * 1.0, L.orc_equal_power_sin(1.0 - mixd)
+    for s in range(S):
+        w = []
+        for ch in range(2):
+            wet, _ = oracle_calls(O, irs[2 * s + ch], x[2 * s + ch], quantum, call_sizes)
+            dry = np.zeros(n)
+            dry[512:] = x[2 * s + ch][:n - 512]
+            w.append((wet * wet_g) + (dry * dry_g))
+        state, pos, el, er = np.zeros(168), 0, [], []
+        for m in call_sizes:
+            a, b, state = O.eq_process_stereo(w[0][pos:pos + m], w[1][pos:pos + m], po, block=quantum, state=state)
+            el.append(a)
+            er.append(b)
+            pos += m
+        fl, fr, _ = O.outfilter_process_stereo(np.concatenate(el), np.concatenate(er), q)
+        assert rms(y[2 * s] - fl) <= 1e-12 and rms(y[2 * s + 1] - fr) <= 1e-12
