@@ -280,7 +280,6 @@ static int enqueueEqRange(cpq_engine* e, const double* dIn, double* dOut, int64_
             }
             if (b.remaining <= 0) b.effective = b.requested;
         }
-        stillActive = stillActive || b.requested || b.effective || b.remaining > 0 || b.mode != 0;
     }
     // pending band resets: at the first callback that is fading (canSafelyResetState, :565-568) or whose input block is
     // silent; a fully bypassed callback returns before it gets there.  Silence is only known on the device: one small
@@ -403,6 +402,9 @@ static int enqueueEqRange(cpq_engine* e, const double* dIn, double* dOut, int64_
         }
         c0 = c1;
     }
+    // after the pieces ran: a stream whose tables were left on the basic path's band nodes (its fade ended inside this call)
+    // still needs the next call to come through here, which puts the parameter tables back
+    for (const auto& b : e->eqBypass) stillActive = stillActive || b.requested || b.effective || b.remaining > 0 || b.mode != 0;
     e->anyEqBypass = stillActive;
     return rc;
 }

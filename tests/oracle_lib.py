@@ -539,14 +539,18 @@ class ConvProcStream:
     compensation with its cross-fade (:263-290, 394-540) and the steady paths (:573-585, :611-676).  The two channels
     share the smoothers, as in the reference."""
 
-    def __init__(self, ir_l, ir_r, block, mix, peak, sr=48000.0, smoothing_time=0.1, scale=1.0, spec=None):
+    def __init__(self, ir_l, ir_r, block, mix, peak, sr=48000.0, smoothing_time=0.1, scale=1.0, spec=None, latency=None):
+        # latency: getLatency() of the convolver = its layer-0 partition; equals the block for power-of-two blocks (default),
+        # nextPow2(max(block, 64)) for any other call quantum.  A callback may be shorter than the block (the last one of a
+        # ragged host call): its length is that of the arrays passed to callback().
         self.block, self.L = block, lib()
+        self.base = block if latency is None else latency
         self.nucs = [Nuc(), Nuc()]
         assert self.nucs[0].set_impulse(ir_l, block, scale=scale, spec=spec)
         assert self.nucs[1].set_impulse(ir_r, block, scale=scale, spec=spec)
         self.mix = LinearRamp(float(np.float32(mix)), sr, smoothing_time)
         self.fade = LinearRamp(1.0, sr, 0.02)
-        self.lat_cur = self.lat_tgt = self.old = float(block + peak)
+        self.lat_cur = self.lat_tgt = self.old = float(self.base + peak)
         self.hist = [np.zeros(0), np.zeros(0)]
 
     def _dry(self, ch, i, d):
@@ -554,12 +558,12 @@ class ConvProcStream:
         return self.hist[ch][j] if j >= 0 else 0.0
 
     def callback(self, xl, xr, mix, peak):
-        B, eps = self.block, self.L.orc_equal_power_sin
+        B, eps = len(xl), self.L.orc_equal_power_sin
         x = [np.ascontiguousarray(xl, dtype=np.float64), np.ascontiguousarray(xr, dtype=np.float64)]
         lo = len(self.hist[0])
         for ch in range(2):
             self.hist[ch] = np.concatenate([self.hist[ch], x[ch]])
-        total = float(B + peak)
+        total = float(self.base + peak)
         if abs(self.lat_tgt - total) >= 2.0 and self.fade.remaining <= 0:
             self.old = self.lat_cur
             self.fade.current = self.fade.target = 0.0
@@ -594,7 +598,10 @@ class ConvProcStream:
                     dry[ch][i] = self._dry(ch, lo + i, d)
         if not needs_conv:
             return dry[0], dry[1]
-        wet = [self.nucs[ch].run(x[ch], B) for ch in range(2)]
+        wet = []
+        for ch in range(2):                                 # Add + Get of one callback (StereoConvolver::process)
+            self.nucs[ch].add(x[ch])
+            wet.append(self.nucs[ch].get(B)[0])
         wet = [np.where(~(np.abs(w) < 1.0e300), 0.0, w) for w in wet]
         out = [np.empty(B), np.empty(B)]
         if smoothing:

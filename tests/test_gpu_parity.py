@@ -1244,6 +1244,47 @@ def test_eq_bypass_fade_state_machine(amd, oracle, block, agc, eq_mode):
     assert not np.array_equal(y[4, k * n:(k + 1) * n], x[4, k * n:(k + 1) * n])
 
 
+@pytest.mark.parametrize("block,T", [(512, 1), (64, 4), (512, 2)])       # the 240-sample fade ends in the LAST callback of a call in the first two
+def test_eq_bypass_request_set_once_then_left_alone(amd, oracle, block, T):
+    """A host sets the bypass request when it changes, not before every block: after the release fade has ended inside a
+    call, the following calls -- with no cpq_eq_set_bypass in between -- must be back on the parameter path (a flat band
+    is active there and applies its saturation stage; on the basic path's band nodes, used while fading, it is not)."""
+    O = oracle
+    po = O.eq_params_bench(0.2)
+    for i in (3, 8, 12):
+        po.bands[i].gain = 0.0
+    n, calls = T * block, 9
+    x = make_inputs(O, 1, calls * n)
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=block, max_blocks_per_call=T)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    changes = {2: True, 5: False}                      # call index -> new request; nothing is set at the other calls
+    req, outs, reqs = False, [], []
+    for k in range(calls):
+        if k in changes:
+            req = changes[k]
+            eng.set_eq_bypass(0, req)
+        if k == 5:                                     # new parameters arrive with the release (they put the stream's
+            pa = _copy_params(po, amd.eq_params_default())     # tables back on the parameter path, the fade moves them again)
+            pa.total_gain_db = 1.5
+            eng.set_eq_params(0, pa)
+        reqs.append(req)
+        outs.append(eng.eq_process(x[:, k * n:(k + 1) * n]))
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    ref = O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, block)
+    rl, rr = [], []
+    for k in range(calls):
+        if k == 5:
+            ref.set_total_gain_db(1.5)
+        for t in range(T):
+            o = (k * T + t) * block
+            a, b = ref.callback(x[0, o:o + block].copy(), x[1, o:o + block].copy(), reqs[k])
+            rl.append(a)
+            rr.append(b)
+    assert np.array_equal(y[0], np.concatenate(rl)) and np.array_equal(y[1], np.concatenate(rr))
+
+
 def test_dspcore_routing_gains_and_bypasses(amd, oracle):
     """The rest of DSPCore's block routing (DSPCoreDouble.cpp:384-470): EQ -> conv order with convolverInputTrimGain,
     outputMakeupGain after the output filter, convBypassed (the convolver stage is skipped, state untouched), and with

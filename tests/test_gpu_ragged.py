@@ -484,3 +484,98 @@ def test_dspcore_chain_at_arbitrary_quantum(amd, oracle):
             pos += m
         fl, fr, _ = O.outfilter_process_stereo(np.concatenate(el), np.concatenate(er), q)
         assert rms(y[2 * s] - fl) <= 1e-12 and rms(y[2 * s + 1] - fr) <= 1e-12
+
+
+@pytest.mark.parametrize("seed", list(range(101, 113)))
+def test_whole_chain_random_transitions_at_arbitrary_quantum(amd, oracle, seed):
+    """tests/test_gpu_parity.py::test_whole_chain_random_transition_sequence under CPQ_CALLS_ANY: a call quantum of 480, 441
+    or 96 samples, ragged calls, and per call and stream a moving mix, IR peak latency (latency cross-fade of the dry
+    path), EQ bypass request, band resets and total-gain changes; every third seed runs EQ -> conv with trim gains.
+    Chain: processor-level convolver -> EQ -> output filter -> make-up gain, against the per-callback restatements
+    (ConvProcStream with getLatency() = nextPow2(max(quantum, 64)), EqWithBypass, the output-filter oracle) cut into the
+    same callbacks: `quantum` samples each, the last one of a call shorter."""
+    O = oracle
+    rng = np.random.default_rng(seed)
+    quantum = int(rng.choice([480, 441, 96]))
+    p0 = max(64, 1 << (quantum - 1).bit_length())
+    S, max_blocks = 2, 3
+    call_sizes = []
+    for _ in range(14):
+        r = rng.random()
+        call_sizes.append(int(quantum * max_blocks if r < 0.2 else (rng.integers(1, 20) if r < 0.3 else rng.integers(1, quantum * max_blocks + 1))))
+    n = sum(call_sizes)
+    irs = [O.gen_ir(int(rng.integers(600, 4000)), stream=50 + s, channel=ch) for s in range(S) for ch in range(2)]
+    ir_len = max(len(h) for h in irs)
+    irs = [np.concatenate([h, np.zeros(ir_len - len(h))]) for h in irs]
+    x = make_inputs(O, range(50, 50 + S), n)
+    po = O.eq_params_bench(0.2)
+    po.bands[5].gain = 0.0
+    q = O.outfilter_design(0, 1, 0, 1, 48000.0)
+    makeup, trim = [1.0, 0.7], [0.5, 1.7]
+    order = amd.CPQ_ORDER_EQ_THEN_CONV if seed % 3 == 0 else amd.CPQ_ORDER_CONV_THEN_EQ
+    mix = [float(rng.uniform(0.2, 1.0)) for _ in range(S)]
+    peak = [int(rng.integers(0, 1500)) for _ in range(S)]
+    byp = [False] * S
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=ir_len, max_blocks_per_call=max_blocks, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+        eng.set_convproc_params(s, mix=mix[s], ir_peak_latency=peak[s])
+        eng.set_gains(s, trim[s], makeup[s])
+    eng.set_order(order)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_eq(po, amd.eq_params_default()))
+    if seed % 2:
+        eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL)
+    eng.set_conv_level(amd.CPQ_LEVEL_PROCESSOR)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    eng.enable_output_filter(True)
+    conv = [None] * S
+    eqs = [O.EqWithBypass(O.EqParams.from_buffer_copy(po), 48000.0, quantum) for _ in range(S)]
+    ofs = [None] * S
+    ref = np.empty_like(x)
+    outs, pos = [], 0
+    for k, m in enumerate(call_sizes):
+        for s in range(S):
+            if k > 0 and rng.random() < 0.3:
+                mix[s] = float(rng.uniform(0.05, 1.0))
+            if k > 0 and rng.random() < 0.3:
+                peak[s] = int(rng.integers(0, 1500)) if rng.random() < 0.8 else peak[s] + 1
+            if rng.random() < 0.25:
+                byp[s] = not byp[s]
+            eng.set_convproc_params(s, mix=mix[s], ir_peak_latency=peak[s])
+            eng.set_eq_bypass(s, byp[s])
+            if k == 0:
+                eqs[s].sync(byp[s])
+            if rng.random() < 0.2:
+                mask = 0xFFFFFFFF if rng.random() < 0.4 else int(rng.integers(1, 1 << 20))
+                eng.request_band_reset(s, mask)
+                eqs[s].request_band_reset(mask)
+            if rng.random() < 0.15:
+                g = float(rng.uniform(-9.0, 3.0))
+                pa = _copy_eq(po, amd.eq_params_default())
+                pa.total_gain_db = g
+                eng.set_eq_params(s, pa)
+                eqs[s].set_total_gain_db(g, before_first_block=(k == 0))
+        outs.append(eng.process(np.ascontiguousarray(x[:, pos:pos + m])))
+        for s in range(S):
+            o = 0
+            while o < m:
+                ln = min(quantum, m - o)
+                a, b = x[2 * s, pos + o:pos + o + ln].copy(), x[2 * s + 1, pos + o:pos + o + ln].copy()
+                if conv[s] is None:
+                    conv[s] = O.ConvProcStream(irs[2 * s], irs[2 * s + 1], quantum, mix[s], peak[s], latency=p0)
+                if order == amd.CPQ_ORDER_CONV_THEN_EQ:
+                    a, b = conv[s].callback(a, b, mix[s], peak[s])
+                    a, b = eqs[s].callback(np.ascontiguousarray(a), np.ascontiguousarray(b), byp[s])
+                else:
+                    a, b = eqs[s].callback(a, b, byp[s])
+                    a, b = a * trim[s], b * trim[s]
+                    a, b = conv[s].callback(a, b, mix[s], peak[s])
+                a, b, ofs[s] = O.outfilter_process_stereo(np.ascontiguousarray(a), np.ascontiguousarray(b), q, ofs[s])
+                ref[2 * s, pos + o:pos + o + ln], ref[2 * s + 1, pos + o:pos + o + ln] = a * makeup[s], b * makeup[s]
+                o += ln
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    for s in range(S):
+        err = np.abs(y[2 * s:2 * s + 2] - ref[2 * s:2 * s + 2]).max()
+        assert err <= 1e-12, (seed, quantum, s, err)
