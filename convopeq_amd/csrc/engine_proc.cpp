@@ -210,7 +210,6 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
     const int R = (int)ranges.size();
     dNew.assign((size_t)R * S, 0); dOld.assign((size_t)R * S, 0); xLen.assign((size_t)R * S, 0);
     xg.assign(R, std::vector<double>());
-    int cap = 1;
     for (int s = 0; s < S; ++s) {
         auto& f = e->latFade[s];
         const int totalI = procDelayOf(e, s);
@@ -249,14 +248,15 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
                 }
             }
             xLen[(size_t)r * S + s] = (int)vals.size();
-            cap = std::max(cap, (int)vals.size());
             if (!vals.empty()) {
                 if (xg[r].empty()) xg[r].assign((size_t)S * (xTotal + e->B), 0.0);
                 std::memcpy(&xg[r][(size_t)s * (xTotal + e->B)], vals.data(), sizeof(double) * vals.size());
             }
         }
     }
-    if (cap > 1 && e->latCap < xTotal + e->B) {
+    bool anyFadeValues = false;            // a fade of ONE value (a one-sample call) needs the buffer as well
+    for (int r = 0; r < R; ++r) anyFadeValues = anyFadeValues || !xg[r].empty();
+    if (anyFadeValues && e->latCap < xTotal + e->B) {
         if (e->latGains) (void)hipFree(e->latGains);
         e->latGains = nullptr;
         e->latCap = 0;

@@ -579,3 +579,36 @@ def test_whole_chain_random_transitions_at_arbitrary_quantum(amd, oracle, seed):
     for s in range(S):
         err = np.abs(y[2 * s:2 * s + 2] - ref[2 * s:2 * s + 2]).max()
         assert err <= 1e-12, (seed, quantum, s, err)
+
+
+def test_latency_cross_fade_starting_in_a_one_sample_call(amd, oracle):
+    """A change of the IR peak latency starts the 20 ms cross-fade of the dry path; when the call it starts in carries a
+    single sample the fade contributes ONE value to that call (the cross-fade buffer must exist for it), and the mix ramp
+    that starts with it likewise."""
+    O = oracle
+    quantum, taps = 96, 3000
+    call_sizes = [96 * 2, 1, 96 * 3, 2, 96 * 3 - 1, 96 * 3, 96 * 3, 96 * 3, 96 * 3, 96 * 3]
+    peaks = [700, 150, 150, 900, 900, 900, 900, 900, 900, 900]
+    mixes = [0.6, 0.25, 0.25, 0.25, 0.8, 0.8, 0.8, 0.8, 0.8, 0.8]
+    n = sum(call_sizes)
+    irs = [O.gen_ir(taps, stream=60, channel=ch) for ch in range(2)]
+    x = make_inputs(O, [60], n)
+    eng = amd.BatchedEngine(1, block_size=quantum, max_ir_len=taps, max_blocks_per_call=3, call_mode=amd.CPQ_CALLS_ANY)
+    eng.set_impulse(0, irs[0], irs[1])
+    eng.set_convproc_params(0, mix=mixes[0], ir_peak_latency=peaks[0])
+    ref = O.ConvProcStream(irs[0], irs[1], quantum, mixes[0], peaks[0], latency=128)
+    outs, rl, rr, pos = [], [], [], 0
+    for k, m in enumerate(call_sizes):
+        eng.set_convproc_params(0, mix=mixes[k], ir_peak_latency=peaks[k])
+        outs.append(eng.convproc_process(np.ascontiguousarray(x[:, pos:pos + m])))
+        o = 0
+        while o < m:
+            ln = min(quantum, m - o)
+            a, b = ref.callback(x[0, pos + o:pos + o + ln].copy(), x[1, pos + o:pos + o + ln].copy(), mixes[k], peaks[k])
+            rl.append(a)
+            rr.append(b)
+            o += ln
+        pos += m
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+    assert np.abs(y[0] - np.concatenate(rl)).max() <= 1e-13 and np.abs(y[1] - np.concatenate(rr)).max() <= 1e-13

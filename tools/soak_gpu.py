@@ -32,7 +32,7 @@ def ragged_case(seed):
     sizes = []
     while sum(sizes) < total:
         r = rng.random()
-        sizes.append(int(max_call if r < 0.15 else (rng.integers(1, 8) if r < 0.3 else rng.integers(1, max_call + 1))))
+        sizes.append(int(max_call if r < 0.15 else (min(max_call, rng.integers(1, 8)) if r < 0.3 else rng.integers(1, max_call + 1))))
     n = sum(sizes)
     S = 2
     irs = [R_ORACLE.gen_ir(taps[c // 2], stream=seed % 1000 + c // 2, channel=c % 2) for c in range(2 * S)]
@@ -92,7 +92,8 @@ for seed in range(first, first + count):
     cases = [("eq", lambda: T.test_eq_random_parameter_sweep(amd, oracle_lib, seed, 48000.0 if seed % 3 else 96000.0, 512 if seed % 2 else 256)),
              ("conv", lambda: T.test_convolver_random_configuration_sweep(amd, oracle_lib, seed)),
              ("chain", lambda: T.test_whole_chain_random_transition_sequence(amd, oracle_lib, seed)),
-             ("ragged", lambda: ragged_case(seed))]
+             ("ragged", lambda: ragged_case(seed)),
+             ("ragged-chain", lambda: R.test_whole_chain_random_transitions_at_arbitrary_quantum(amd, oracle_lib, seed))]
     for name, fn in cases:
         try:
             fn()
@@ -102,5 +103,5 @@ for seed in range(first, first + count):
             traceback.print_exc(limit=3)
     if (seed - first) % 10 == 9:
         print(f"... {seed - first + 1} seeds, {len(fails)} failures, {time.time() - t0:.0f} s", flush=True)
-print(f"soak: seeds {first}..{first + count - 1}, {4 * count} cases, {len(fails)} failures: {fails}")
+print(f"soak: seeds {first}..{first + count - 1}, {5 * count} cases, {len(fails)} failures: {fails}")
 sys.exit(1 if fails else 0)
