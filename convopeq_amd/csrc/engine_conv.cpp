@@ -211,6 +211,23 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
         return CPQ_OK;
     };
     const int sFirst = (stream == CPQ_ALL_STREAMS) ? 0 : stream, sEnd = (stream == CPQ_ALL_STREAMS) ? e->desc.n_streams : stream + 1;
+    // SetImpulse leaves a convolver that has seen no input (every buffer is allocated anew and zeroed,
+    // src/MKLNonUniformConvolver.cpp:697-714, :880-935): the stream's input history goes -- the direct head's last samples, and on
+    // the main path its rows of the frequency-domain delay line and the overlap block; the other streams play on
+    for (int s = sFirst; s < sEnd; ++s) {
+        for (double* p : { e->directHist[0], e->directHist[1] })
+            if (p) CPQ_HIP(e, hipMemsetAsync(p + (size_t)2 * s * 32, 0, sizeof(double) * 2 * 32, e->stream));
+        if (!native && e->X) {
+            CPQ_HIP(e, hipMemsetAsync(e->X + (int64_t)2 * s * e->ringSlots * e->P, 0, (size_t)2 * e->ringSlots * e->P * sizeof(double2), e->stream));
+            CPQ_HIP(e, hipMemsetAsync(e->XDN + (int64_t)2 * s * e->ringSlots, 0, (size_t)2 * e->ringSlots * sizeof(double2), e->stream));
+            for (double* p : { e->hist[0], e->hist[1] })
+                if (p) CPQ_HIP(e, hipMemsetAsync(p + (int64_t)2 * s * e->P, 0, (size_t)2 * e->P * sizeof(double), e->stream));
+            if (e->tailRing)            // layered mode: the stream's delay lines (the reader's phase is the engine's and runs on)
+                for (int l = 0; l + 1 < e->layerPlan.num_layers; ++l)
+                    CPQ_HIP(e, hipMemsetAsync(e->tailRing + ((size_t)l * e->nCh + 2 * s) * e->tailRingSlots, 0,
+                                              sizeof(double) * 2 * e->tailRingSlots, e->stream));
+        }
+    }
     if (native) {
         // the stream(s) leave the main path: their rows there become zero (the main path then contributes silence)
         for (int ch = 0; ch < 2; ++ch) {

@@ -1285,6 +1285,43 @@ def test_eq_bypass_request_set_once_then_left_alone(amd, oracle, block, T):
     assert np.array_equal(y[0], np.concatenate(rl)) and np.array_equal(y[1], np.concatenate(rr))
 
 
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("any_calls", [False, True])
+def test_ir_reload_on_a_live_stream_starts_from_silence(amd, oracle, direct, any_calls):
+    """SetImpulse leaves a convolver that has seen no input (every buffer allocated anew and zeroed,
+    src/MKLNonUniformConvolver.cpp:697-714): a stream given a new IR in mid-run plays like a new NUC from that call on --
+    no old input through the new IR's frequency-domain delay line or its direct head -- while its neighbour plays on."""
+    O = oracle
+    S, T, calls, reload_at = 2, 4, 8, 3
+    n = T * B
+    irs = [O.gen_ir(9000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    new = [O.gen_ir(5000, stream=9, channel=ch) for ch in range(2)]
+    x = make_inputs(O, S, calls * n)
+    eng = amd.BatchedEngine(S, max_ir_len=9000, max_blocks_per_call=T,
+                            call_mode=amd.CPQ_CALLS_ANY if any_calls else amd.CPQ_CALLS_WHOLE_BLOCKS)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1], direct_head=direct)
+    outs = []
+    for k in range(calls):
+        if k == reload_at:
+            eng.set_impulse(1, new[0], new[1], direct_head=direct)
+        outs.append(eng.conv_process(x[:, k * n:(k + 1) * n]))
+    y = np.concatenate(outs, axis=1)
+    eng.close()
+
+    def nuc_run(ir, sig):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(ir, B, direct=direct)
+        out = nuc.run(sig, B)
+        nuc.close()
+        return out
+    cut = reload_at * n
+    for ch in range(2):
+        assert rms(y[ch] - nuc_run(irs[ch], x[ch])) <= 1e-13                          # stream 0 does not notice
+        assert rms(y[2 + ch][:cut] - nuc_run(irs[2 + ch], x[2 + ch][:cut])) <= 1e-13
+        assert rms(y[2 + ch][cut:] - nuc_run(new[ch], x[2 + ch][cut:])) <= 1e-13      # a new NUC from the reload on
+
+
 def test_dspcore_routing_gains_and_bypasses(amd, oracle):
     """The rest of DSPCore's block routing (DSPCoreDouble.cpp:384-470): EQ -> conv order with convolverInputTrimGain,
     outputMakeupGain after the output filter, convBypassed (the convolver stage is skipped, state untouched), and with

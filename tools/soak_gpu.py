@@ -43,9 +43,25 @@ def ragged_case(seed):
         for s in range(S):
             eng.set_impulse(s, irs[2 * s], irs[2 * s + 1], scale=scale, direct_head=direct)
         if not with_eq:
-            y = R.run_engine(eng, x, sizes)
+            # now and then stream 1 gets a new IR in mid-run (a new NUC from silence: SetImpulse) while stream 0 plays on
+            reload_at = int(rng.integers(1, len(sizes))) if (rng.random() < 0.4 and len(sizes) > 1) else None
+            new_len = int(rng.integers(1, max(taps) + 1))
+            new_irs = [R_ORACLE.gen_ir(new_len, stream=seed % 1000 + 7, channel=ch) for ch in range(2)]
+            ys, pos = [], 0
+            for k, m in enumerate(sizes):
+                if k == reload_at:
+                    eng.set_impulse(1, new_irs[0], new_irs[1], scale=scale, direct_head=direct)
+                ys.append(eng.conv_process(np.ascontiguousarray(x[:, pos:pos + m])))
+                pos += m
+            y = np.concatenate(ys, axis=1)
             for c in range(2 * S):
-                ref, _ = R.oracle_calls(R_ORACLE, irs[c], x[c], quantum, sizes, direct=direct, scale=scale)
+                if c >= 2 and reload_at is not None:
+                    p0 = sum(sizes[:reload_at])
+                    ref0, _ = R.oracle_calls(R_ORACLE, irs[c], x[c], quantum, sizes[:reload_at], direct=direct, scale=scale)
+                    ref1, _ = R.oracle_calls(R_ORACLE, new_irs[c - 2], x[c][p0:], quantum, sizes[reload_at:], direct=direct, scale=scale)
+                    ref = np.concatenate([ref0, ref1])
+                else:
+                    ref, _ = R.oracle_calls(R_ORACLE, irs[c], x[c], quantum, sizes, direct=direct, scale=scale)
                 R.check(y[c], ref)
             return
         pos_p = [R_ORACLE.eq_params_bench(float(rng.choice([0.0, 0.2, 0.7]))) for _ in range(S)]
