@@ -1322,6 +1322,44 @@ def test_ir_reload_on_a_live_stream_starts_from_silence(amd, oracle, direct, any
         assert rms(y[2 + ch][cut:] - nuc_run(new[ch], x[2 + ch][cut:])) <= 1e-13      # a new NUC from the reload on
 
 
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+def test_eq_band_parameters_change_on_a_live_stream(amd, oracle, mode):
+    """New band parameters (type, frequency, gain, Q, channel mode, saturation) between calls: the coefficient cache is
+    swapped, the filter states run on (src/eqprocessor/EQProcessor.ProcessingCache.cpp:71-90 builds a new cache, filterState
+    is untouched) -- per stream, while the neighbour keeps its parameters."""
+    O = oracle
+    S, T, calls = 2, 17, 6                      # 17 blocks: an 8192-sample span + a one-wave span of the matrix form
+    n = T * B
+    x = make_inputs(O, S, calls * n)
+    rng = np.random.default_rng(5)
+    po = [O.eq_params_bench(0.2), O.eq_params_bench(0.2)]
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    for s in range(S):
+        eng.set_eq_params(s, _copy_params(po[s], amd.eq_params_default()))
+    state = [np.zeros(168), np.zeros(168)]
+    worst = 0.0
+    for k in range(calls):
+        if k in (2, 3, 5):                       # stream 1 gets new bands; stream 0 never does
+            for i in rng.choice(20, size=6, replace=False):
+                b = po[1].bands[int(i)]
+                b.gain = float(rng.uniform(-9, 9))
+                b.frequency = float(np.clip(b.frequency * rng.uniform(0.5, 2.0), 20.0, 20000.0))
+                b.q = float(rng.uniform(0.3, 6.0))
+                b.type = int(rng.choice([0, 1, 2, 3, 4])) if rng.random() < 0.3 else b.type
+                b.channelMode = int(rng.choice([0, 1, 2])) if rng.random() < 0.3 else b.channelMode
+            po[1].nonlinearSaturation = float(rng.choice([0.0, 0.2, 0.6]))
+            eng.set_eq_params(1, _copy_params(po[1], amd.eq_params_default()))
+        seg = x[:, k * n:(k + 1) * n]
+        y = eng.eq_process(seg)
+        for s in range(S):
+            yl, yr, state[s] = O.eq_process_stereo(seg[2 * s], seg[2 * s + 1], po[s], state=state[s])
+            worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+    print("live EQ parameter change", mode, "max abs diff", worst)
+    assert worst <= (0.0 if mode == "sequential" else 1e-12)
+    eng.close()
+
+
 def test_dspcore_routing_gains_and_bypasses(amd, oracle):
     """The rest of DSPCore's block routing (DSPCoreDouble.cpp:384-470): EQ -> conv order with convolverInputTrimGain,
     outputMakeupGain after the output filter, convBypassed (the convolver stage is skipped, state untouched), and with
