@@ -229,6 +229,8 @@ int32_t cpq_host_unregister(void* ptr);
  * MKLNonUniformConvolver::SetImpulse(impulse, irLen, blockSize, scale, enableDirectHead, filterSpec)
  * (src/MKLNonUniformConvolver.h:197-200).  stream = index or CPQ_ALL_STREAMS (one shared stereo IR).
  * The caller keeps ownership of ir_l/ir_r (copied).
+ * On a stream that is already playing the call leaves, like SetImpulse, a convolver that has seen no input (its input
+ * history -- delay-line spectra, overlap block, the direct head's last samples -- is cleared); the other streams play on.
  * spec: NULL (the primary parity surface), or a FilterSpec: its HC/LC spectral gains (:336-443) and, in tail mode 0,
  * the air-absorption damping (:1060-1097) are applied to every partition spectrum at that LAYER's FFT size, exactly
  * as the reference does.  Layer 0 runs in the main path; every tail layer of the plan runs on the reference's own
