@@ -1286,7 +1286,7 @@ def test_eq_bypass_request_set_once_then_left_alone(amd, oracle, block, T):
 
 
 @pytest.mark.parametrize("direct", [False, True])
-@pytest.mark.parametrize("any_calls", [False, True])
+@pytest.mark.parametrize("any_calls", [False, True, "nuc"])
 def test_ir_reload_on_a_live_stream_starts_from_silence(amd, oracle, direct, any_calls):
     """SetImpulse leaves a convolver that has seen no input (every buffer allocated anew and zeroed,
     src/MKLNonUniformConvolver.cpp:697-714): a stream given a new IR in mid-run plays like a new NUC from that call on --
@@ -1298,7 +1298,8 @@ def test_ir_reload_on_a_live_stream_starts_from_silence(amd, oracle, direct, any
     new = [O.gen_ir(5000, stream=9, channel=ch) for ch in range(2)]
     x = make_inputs(O, S, calls * n)
     eng = amd.BatchedEngine(S, max_ir_len=9000, max_blocks_per_call=T,
-                            call_mode=amd.CPQ_CALLS_ANY if any_calls else amd.CPQ_CALLS_WHOLE_BLOCKS)
+                            call_mode=amd.CPQ_CALLS_ANY if any_calls is True else amd.CPQ_CALLS_WHOLE_BLOCKS,
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if any_calls == "nuc" else amd.CPQ_SCHED_UNIFORM)
     for s in range(S):
         eng.set_impulse(s, irs[2 * s], irs[2 * s + 1], direct_head=direct)
     outs = []
