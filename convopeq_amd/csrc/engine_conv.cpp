@@ -165,8 +165,8 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
             return fail(e, CPQ_ERR_INVALID_ARG, "layer plan failed");
         wantLayered = !probe.lti_valid && probe.num_layers > 1;
         if (wantLayered) {
-            if (e->P != e->B)
-                return fail(e, CPQ_ERR_UNSUPPORTED, "time-varying reference semantics need partition_size == block_size");
+            // each layer is ONE linear convolution of the call with its segment of the IR, whatever the FFT partition;
+            // the reader that makes the plan time-varying is replayed per callback of block_size on the layer outputs
             bool anyLoaded = false;
             for (char l : e->irLoaded) anyLoaded = anyLoaded || l;
             if (anyLoaded && (!e->layered || std::memcmp(&probe, &e->layerPlan, sizeof(probe)) != 0))
@@ -181,7 +181,7 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
                 if (hipMalloc((void**)&e->layerOut, sizeof(double) * nTail * e->nCh * callSamples) != hipSuccess ||
                     hipMalloc((void**)&e->tailRing, sizeof(double) * (size_t)nTail * e->nCh * e->tailRingSlots) != hipSuccess ||
                     hipMalloc(&e->tailState, 3 * sizeof(long long)) != hipSuccess ||
-                    hipMalloc((void**)&e->tailSched, sizeof(long long) * 2 * (size_t)e->tMax) != hipSuccess)
+                    hipMalloc((void**)&e->tailSched, sizeof(long long) * 2 * ((size_t)e->tMax * e->P / e->B)) != hipSuccess)      // per tail layer and callback
                     return fail(e, CPQ_ERR_OOM, "layered-mode buffers could not be allocated");
                 CPQ_HIP(e, hipMemset(e->tailRing, 0, sizeof(double) * (size_t)nTail * e->nCh * e->tailRingSlots));
                 CPQ_HIP(e, hipMemset(e->tailState, 0, 3 * sizeof(long long)));

@@ -232,10 +232,10 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         // K shrinks by P / B, the FFT cost per sample stays): 4096 for calls of at least eight such partitions (below
         // that the MAC streams the same IR + FDL bytes per call at either size and the 512-point kernels do it faster:
         // profiles/r02e_small_calls.txt), else 512, else the block itself.  The reference's own
-        // schedule, ragged calls and the block sizes whose reference plan is time-varying (B >= 1024 under reference
-        // semantics: layered mode at P == B) keep the reference's layer-0 partition.
+        // schedule and ragged calls keep the reference's layer-0 partition.  (Blocks of 1024 and more, whose reference plan
+        // is time-varying, run one convolution per layer: those take the larger partition as well.)
         partition = 0;
-        if (!anyCalls && d->schedule == CPQ_SCHED_UNIFORM && (d->semantics == CPQ_SEM_EXACT || d->block_size <= 512))
+        if (!anyCalls && d->schedule == CPQ_SCHED_UNIFORM)
             for (int32_t cand : { 4096, 512 })
                 if (cand > d->block_size && e->maxCall % cand == 0 && (cand == 512 || e->maxCall >= 8 * cand)) { partition = cand; break; }
     }

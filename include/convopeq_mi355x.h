@@ -159,8 +159,8 @@ typedef struct {
                                         for calls of max_blocks_per_call blocks (4096 when block_size *
                                         max_blocks_per_call is a multiple of it and at least 32768, else 512 when
                                         a multiple of that, else block_size;
-                                        uniform schedule, whole-block calls, block_size <= 512 or exact
-                                        semantics, plain IRs - a FilterSpec with tail layers needs P == block_size;
+                                        uniform schedule, whole-block calls, plain IRs - a FilterSpec with tail
+                                        layers needs P == block_size;
                                         read it back with cpq_engine_partition_size); else a power of two with
                                         block_size <= P <= 4096.  The result is the same convolution (with the
                                         h_eff the reference derives for block_size); larger P trades call

@@ -111,11 +111,11 @@ def test_larger_internal_partition(amd, oracle, partition, blocks_per_call, tile
 @pytest.mark.parametrize("block,blocks_per_call,semantics,schedule,expect", [
     (512, 64, "ref", "uniform", 4096), (512, 3, "ref", "uniform", 512), (128, 256, "ref", "uniform", 4096),
     (128, 64, "ref", "uniform", 512), (128, 12, "ref", "uniform", 512), (256, 3, "ref", "uniform", 256),
-    (1024, 32, "ref", "uniform", 1024), (1024, 32, "exact", "uniform", 4096), (1024, 8, "exact", "uniform", 1024),
+    (1024, 32, "ref", "uniform", 4096), (1024, 32, "exact", "uniform", 4096), (1024, 8, "exact", "uniform", 1024),
     (512, 64, "ref", "nuc", 512)])
 def test_automatic_partition_choice(amd, oracle, block, blocks_per_call, semantics, schedule, expect):
     """CPQ_PARTITION_AUTO: 4096 where the calls are eight or more whole 4096-sample partitions, else 512, else the block; never for
-    the reference's own schedule or for blocks whose reference plan is time-varying.  The output is the oracle's Add/Get
+    the reference's own schedule.  The output is the oracle's Add/Get
     emulation at the caller's block size whatever the engine picks."""
     O = oracle
     L = 20000
@@ -638,10 +638,10 @@ def test_eq_parallel_structure(amd, oracle, sat):
     eng.close()
 
 
-@pytest.mark.parametrize("block,ir_len,blocks_per_call,n_calls", [(1024, 131072, 4, 90), (1024, 131072, 32, 10),
-                                                                   (2048, 131072, 3, 60), (1024, 524288, 16, 50),
-                                                                   (1024, 40000, 5, 30)])
-def test_time_varying_reference_semantics_large_blocks(amd, oracle, block, ir_len, blocks_per_call, n_calls):
+@pytest.mark.parametrize("block,ir_len,blocks_per_call,n_calls,partition", [
+    (1024, 131072, 4, 90, 0), (1024, 131072, 32, 10, 0), (2048, 131072, 3, 60, 0), (1024, 524288, 16, 50, 0),
+    (1024, 40000, 5, 30, 0), (1024, 131072, 32, 10, 4096), (2048, 131072, 16, 12, -1), (1024, 131072, 8, 40, 2048)])
+def test_time_varying_reference_semantics_large_blocks(amd, oracle, block, ir_len, blocks_per_call, n_calls, partition):
     """BASELINE.json configs[2], B >= 1024 with tail layers: partSize_L > outputDelaySamples_L, the reference's
     delay-line reader drops tail samples (SURVEY A6 'model invalid').  The engine runs one convolution per layer and
     replays the reader; compared with the oracle's stateful Add/Get emulation."""
@@ -651,7 +651,11 @@ def test_time_varying_reference_semantics_large_blocks(amd, oracle, block, ir_le
     x = make_inputs(O, S, n_calls * blocks_per_call * block)
     ref = oracle_conv(O, irs, x, block=block)
     assert O.plan(ir_len, block).ltiValid == 0
-    eng = amd.BatchedEngine(S, block_size=block, max_ir_len=ir_len, max_blocks_per_call=blocks_per_call)
+    # partition: the FFT partition of the per-layer convolutions (0 = the block, -1 = the engine's choice); the reader that
+    # makes the plan time-varying runs per callback of `block` on the layer outputs either way
+    eng = amd.BatchedEngine(S, block_size=block, max_ir_len=ir_len, max_blocks_per_call=blocks_per_call, partition_size=partition)
+    if partition == -1:
+        assert eng.partition_size() == 4096
     for s in range(S):
         eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
     step = blocks_per_call * block

@@ -4,7 +4,7 @@
 #  config 2 variants: saturation 0.0, one shared stereo IR, the AutoEq preset, a hot signal (the EQ's guarded output
 #            stage), convolver only, and the round-1 schedule (P = 512, 64 blocks per call)
 #  config 3: block-size sweep at 131072 taps, reference semantics (B >= 1024: the time-varying reference behaviour in
-#            layered mode at P = B; also the exact linear convolution at P = 4096)
+#            layered mode, at the engine's own P = 4096 and at P = B; also the exact linear convolution at P = 4096)
 #  config 4: 64 streams, 524288-tap IR, uniform schedule and the reference's own non-uniform one
 #  config 5 per-GPU share: 1024 streams
 TAG=${1:-r02}
@@ -18,7 +18,8 @@ run --pcm-scale 64
 run --no-eq
 run --partition 512 --blocks-per-call 64
 for B in 128 256; do run --block $B --blocks-per-call $((524288 / B)); done     # the engine picks P = 4096 (CPQ_PARTITION_AUTO)
-for B in 1024 2048; do run --block $B --partition 0 --blocks-per-call $((524288 / B)); done
+for B in 1024 2048; do run --block $B --blocks-per-call $((524288 / B)); done                  # layered mode, the engine picks P = 4096
+for B in 1024 2048; do run --block $B --partition 0 --blocks-per-call $((524288 / B)); done    # the same at P = B
 for B in 1024 2048; do run --exact --block $B --partition 4096 --blocks-per-call $((524288 / B)); done
 run --streams 64 --ir-len 524288
 run --streams 64 --ir-len 524288 --schedule nuc
