@@ -100,6 +100,47 @@ def ragged_case(seed):
 
 oracle_lib.lib()
 R_ORACLE = oracle_lib
+
+
+def partition_case(seed):
+    """Whole-block engines with an internal FFT partition larger than the block (uniform schedule, plain IR): random block,
+    partition, IR length (single-layer, multi-layer LTI and time-varying plans), scale, direct head; calls of whole
+    partitions.  The output is the reference's at the caller's block size whatever the partition."""
+    rng = np.random.default_rng(seed)
+    block = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
+    cands = [p for p in (128, 256, 512, 1024, 2048, 4096) if p > block]
+    part = int(rng.choice(cands)) if rng.random() < 0.8 else -1
+    ir_len = int(np.exp(rng.uniform(np.log(100), np.log(200000))))
+    eff_part = part if part > 0 else 4096
+    calls_parts = int(rng.integers(1, 5)) if part > 0 else int(rng.integers(8, 12))
+    max_blocks = calls_parts * eff_part // block
+    scale = float(rng.choice([1.0, rng.uniform(0.2, 1.5)]))
+    direct = bool(rng.random() < 0.3)
+    irs = [R_ORACLE.gen_ir(ir_len, seed=0x3333 + seed, channel=ch) for ch in range(2)]
+    eng = amd.BatchedEngine(1, block_size=block, max_ir_len=ir_len, max_blocks_per_call=max_blocks, partition_size=part)
+    try:
+        p_used = eng.partition_size()
+        eng.set_impulse(0, irs[0], irs[1], scale=scale, direct_head=direct)
+        total = ir_len + 3 * 4096 + int(rng.integers(0, 30000))
+        sizes = []
+        while sum(sizes) < total:
+            sizes.append(int(rng.integers(1, max_blocks * block // p_used + 1)) * p_used)
+        n = sum(sizes)
+        x = R.make_inputs(R_ORACLE, [seed % 1000], n)
+        outs, pos = [], 0
+        for m in sizes:
+            outs.append(eng.conv_process(np.ascontiguousarray(x[:, pos:pos + m])))
+            pos += m
+        y = np.concatenate(outs, axis=1)
+    finally:
+        eng.close()
+    for c in range(2):
+        nuc = R_ORACLE.Nuc()
+        assert nuc.set_impulse(irs[c], block, scale=scale, direct=direct)
+        ref = nuc.run(x[c], block)
+        nuc.close()
+        err = R.rms(y[c] - ref)
+        assert err <= 1e-12, (seed, block, part, p_used, ir_len, direct, err)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 fails = []
@@ -109,6 +150,7 @@ for seed in range(first, first + count):
              ("conv", lambda: T.test_convolver_random_configuration_sweep(amd, oracle_lib, seed)),
              ("chain", lambda: T.test_whole_chain_random_transition_sequence(amd, oracle_lib, seed)),
              ("ragged", lambda: ragged_case(seed)),
+             ("partition", lambda: partition_case(seed)),
              ("ragged-chain", lambda: R.test_whole_chain_random_transitions_at_arbitrary_quantum(amd, oracle_lib, seed))]
     for name, fn in cases:
         try:
@@ -119,5 +161,5 @@ for seed in range(first, first + count):
             traceback.print_exc(limit=3)
     if (seed - first) % 10 == 9:
         print(f"... {seed - first + 1} seeds, {len(fails)} failures, {time.time() - t0:.0f} s", flush=True)
-print(f"soak: seeds {first}..{first + count - 1}, {5 * count} cases, {len(fails)} failures: {fails}")
+print(f"soak: seeds {first}..{first + count - 1}, {6 * count} cases, {len(fails)} failures: {fails}")
 sys.exit(1 if fails else 0)
