@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Seeded soak of the random GPU parity sweeps beyond the seeds tests/ runs: the EQ parameter space, the convolver's
-configuration space, random transition sequences through the whole chain, ragged calls at random quanta (CPQ_CALLS_ANY).  Prints one line per failing seed and a summary;
+configuration space, random transition sequences through the whole chain, ragged calls at random quanta (CPQ_CALLS_ANY) with mid-run IR
+reloads and the EQ on the same callbacks, internal FFT partitions larger than the block, transition sequences at arbitrary quanta.  Prints one line per failing seed and a summary;
 exit code 1 on any failure.  usage: python tools/soak_gpu.py [first_seed] [n_seeds]   (on the GPU box)"""
 import os
 import sys
