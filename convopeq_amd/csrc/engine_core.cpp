@@ -291,7 +291,11 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->ofSatGain, nCh * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofState, nCh * kBands * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
+        // band-state hand-over between the workgroups of one channel (chained spans of the time-parallel cascade): only
+        // engines whose channels alone leave room for a second workgroup per channel ever use it
+        { (void**)&e->svfChain, nCh <= 256 ? (int64_t)cpq::svf_chain_bytes((int)nCh, e->maxCall) : 0 },
     };
+    e->svfChainSpans = nCh <= 256 ? (int)(cpq::svf_chain_bytes(1, e->maxCall) / cpq::svf_chain_bytes(1, 0)) : 0;
     int64_t total = 0;
     for (const Item& it : items) total += alignUp(it.bytes, 256);
     if (hipMalloc((void**)&e->arena, (size_t)total) != hipSuccess) {

@@ -13,7 +13,8 @@ int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t strid
     const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
     if (nTp > 0) {
         ProfScope p(e, idTp);
-        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables);
+        cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables,
+                                   e->svfChainSpans > 0 ? e->svfChain : nullptr, e->svfChainSpans, &e->svfTicket);
     }
     if (n > nTp) {
         ProfScope p(e, idSeq);

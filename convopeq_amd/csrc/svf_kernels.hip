@@ -304,7 +304,9 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 // den r: v_rcp_f64 is good to 4.6e-8 here, e^3 ~ 1e-22), so r is the correctly rounded reciprocal up to 1 ulp and the
 // result is within ~1 ulp of the reference expression (rounding-level, like the rest of the time-parallel evaluation;
 // 7 operations per sample instead of 10).  Both band kinds share it.
-template <int N>
+// ORDER 2: one second-order step instead (r (1 + e): relative error e^2 <= 2.2e-15 in r, <= 0.4 ... 2 e-15 in the result
+// for sat = 0.2 ... 1 -- the size of the other rounding errors of a band; one operation less).
+template <int N, int ORDER = 3>
 __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 {
     const double ca = c1 * (1.0 / 9.0), cb = 3.0 - c1 * (1.0 / 3.0);
@@ -316,7 +318,7 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const double e = fma(-den[j], r[j], 1.0);
-        r[j] = fma(fma(e, e, e), r[j], r[j]);
+        r[j] = (ORDER == 2) ? fma(e, r[j], r[j]) : fma(fma(e, e, e), r[j], r[j]);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) y[j] *= fma(cb, r[j], ca);
@@ -341,6 +343,16 @@ __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic
             continue;
         }
         const double v3 = v0 - ic2;
+        if (KIND == 3) {
+            // SVF band with m0 == 1 and m2 == 0 (every peaking band): the output needs v1 only, and the second state follows
+            // without v2:  ic2' = 2 v2 - ic2 = ic2 + 2 a2 ic1 + 2 a3 v3  (a1 = 2 a2, a2 = 2 a3 passed in: exact doublings).
+            // Seven operations per sample instead of ten; same quantities, rounded in a different order.
+            const double v1 = fma(m2, ic1, m0 * v3);             // m2 = a1, m0 = a2 of the band here
+            ic2 = fma(a1, ic1, fma(a2, v3, ic2));
+            ic1 = fma(2.0, v1, -ic1);
+            v[j] = fma(m1, v1, v0);
+            continue;
+        }
         if (KIND == 1) {
             const double v1 = a1 * ic1 + a2 * v3;
             const double v2 = ic2 + a2 * ic1 + a3 * v3;
@@ -641,26 +653,6 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
     __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// MFMA form of the main path (chunk length 16).  Inside one band everything between the input and the output stage
-// is linear, and over a chunk of 16 samples it is a small dense product shared by all chunks of the span:
-//     y_lin (16 x chunks) = [ T | G ] (16 x 18)  .  [ x ; s0 ] (18 x chunks),     e (2 x chunks) = E (2 x 16) . x
-// with T the lower-triangular Toeplitz matrix of the band's zero-state impulse response, G = C A^i the state
-// response and s0 the chunk start states from the scan of the end states e.  That product runs on the matrix cores
-// (v_mfma_f64_16x16x4_f64: 5 per tile of 16 chunks), which are idle otherwise and issue beside the VALU.
-// Register layout = the instruction's own: lane (m = lane & 15, g = lane >> 4) holds of tile tau (16 chunks) the
-// samples g + 4 j (j = register) of chunk 16 tau + m.  The D registers of one band ARE the B operands of the next
-// (k-step s = register s), so the span stays in registers across the 20 bands; the output stage is element-wise.
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-struct alignas(16) TpLdsM {
-    double cf[kBands][6];        // a1 a2 a3 m0 m1 m2 (guarded fallback)
-    double M[kBands][28];        // Mk[6][4], Mw[4] (scan)
-    double Gq[kBands][16][4];    // (C A^i)_x, (C A^i)_y, 0, 0: A-operand rows of the state response
-    double ht[kBands][32];
-    double e[kBands][2][16];
-};
-
 // LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the compiler
 // from moving them across each other
 __device__ __forceinline__ void wave_lds_sync()
@@ -668,165 +660,6 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// tables of the matrix form -> LDS (nThreads = threads of the workgroup); the caller synchronises
-__device__ __forceinline__ void tp_load_tables_m(TpLdsM* L, const double* __restrict__ cf,
-                                                 const TpBandTables* __restrict__ tb, int tid, int nThreads)
-{
-    for (int i = tid; i < kBands * 6; i += nThreads) L->cf[i / 6][i % 6] = cf[i];
-    for (int i = tid; i < kBands * 28; i += nThreads) {
-        const int b = i / 28, q = i % 28;
-        L->M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
-    }
-    for (int i = tid; i < kBands * 64; i += nThreads) {
-        const int b = i / 64, r = (i % 64) / 4, q = i % 4;
-        L->Gq[b][r][q] = (q < 2) ? tb[b].t[0].G[r][q] : 0.0;
-    }
-    for (int i = tid; i < kBands * 32; i += nThreads) {
-        L->ht[i / 32][i % 32] = tb[i / 32].mm.ht[i % 32];
-        L->e[i / 32][(i % 32) / 16][i % 16] = tb[i / 32].mm.e[(i % 32) / 16][i % 16];
-    }
-}
-
-// The band loop of the matrix form: x = the wave's 64 chunks in the MFMA layout (in and out); red / s0q = the wave's LDS
-// scratch (256 double2 / 256 doubles); NTHREADS = threads of the workgroup (64 per wave of the span; 0 = blockDim.x).
-// wtot: two parities of [2 * waves] wave totals (one workgroup barrier per band, see tp_scan).  A barrier-free variant
-// (totals published with per-band flags, waves polling only their predecessors) measured slower: 0.59 vs 0.58 ms.
-template <bool SAT, int NTHREADS>
-__device__ __forceinline__ void tp_bands_mfma(v4d (&x)[4], double2* red, double* s0q, double* wtot, const double* sState,
-                                              double* sNext, const TpLdsM* L, int tid, const int* __restrict__ fl,
-                                              const TpBandTables* __restrict__ tb, double sat)
-{
-    const int lane = tid & 63;
-    const int m = lane & 15, g = lane >> 4;
-    const double oneMinusSat = 1.0 - sat;
-    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
-    const double smallC1 = 9.0 - 8.0 * sat;
-        int par = 0;
-        for (int b = 0; b < kBands; ++b) {
-            const int flag = fl[b];
-            if (!(flag & 1)) continue;                    // uniform
-            const int kind = (flag >> 1) & 3;
-            // tables of the band
-            const TpLanePowers pw = {};                       // register-tight: tp_scan loads the per-lane powers where it uses them
-            double a[4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) a[s4] = L->ht[b][15 + m - 4 * s4 - g];
-            // (1) end state of every chunk's zero-state run: e = E x, partial over this lane's four samples per tile ...
-            double e0[4], e1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { e0[j] = L->e[b][0][g + 4 * j]; e1[j] = L->e[b][1][g + 4 * j]; }
-#pragma unroll
-            for (int tau = 0; tau < 4; ++tau) {
-                double px = e0[0] * x[tau][0], py = e1[0] * x[tau][0];
-#pragma unroll
-                for (int j = 1; j < 4; ++j) { px = fma(e0[j], x[tau][j], px); py = fma(e1[j], x[tau][j], py); }
-                red[(tau * 4 + g) * 16 + m] = make_double2(px, py);
-            }
-            // (2) the zero-state part of the product, T x, does not wait for the start states: its 16 MFMAs go to the
-            // matrix pipe now and run beside the reduction and the scan below (x is dead from here: acc takes its place)
-#if !(defined(CPQ_ABL) && (CPQ_ABL & 4))
-#ifndef CPQ_TX_16X16
-            {
-                // T is lower-triangular Toeplitz: of its sixteen 4 x 4 blocks only the ten on and below the diagonal are
-                // non-zero, and block (i, j) depends on i - j alone.  v_mfma_f64_4x4x4_4b_f64 multiplies one such block
-                // into four batches of four chunks; its operand layout (B[k][n] at lane 16 k + n, D[i][n] at lane
-                // 16 i + n, A[i][k] at lane 16 k + 4 batch + i: tools/ubench/mfma_f64_4x4x4.hip) is register s of the
-                // 16x16x4 layout = block row s, so the two instructions mix freely.  10 small MFMAs (~17-20 cycles each)
-                // instead of 4 large ones (64 cycles each) per tile.
-                double a4[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) a4[d] = L->ht[b][15 + 4 * d + (m & 3) - g];
-                double dacc[4][4];
-                // block-column major: consecutive MFMAs write different accumulators
-#ifdef CPQ_TX_TILE_MAJOR
-#pragma unroll
-                for (int tau = 0; tau < 4; ++tau)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int i = j; i < 4; ++i)
-                            dacc[tau][i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[i - j], x[tau][j], j == 0 ? 0.0 : dacc[tau][i], 0, 0, 0);
-#else
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tau = 0; tau < 4; ++tau)
-#pragma unroll
-                        for (int i = j; i < 4; ++i)
-                            dacc[tau][i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[i - j], x[tau][j], j == 0 ? 0.0 : dacc[tau][i], 0, 0, 0);
-#endif
-#pragma unroll
-                for (int tau = 0; tau < 4; ++tau) x[tau] = v4d{ dacc[tau][0], dacc[tau][1], dacc[tau][2], dacc[tau][3] };
-            }
-#else
-            {
-                v4d acc[4];
-#pragma unroll
-                for (int tau = 0; tau < 4; ++tau) acc[tau] = v4d{ 0.0, 0.0, 0.0, 0.0 };
-                // k-step major: consecutive MFMAs belong to different tiles, so none waits for its own accumulator
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int tau = 0; tau < 4; ++tau)
-                        acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[tau][s4], acc[tau], 0, 0, 0);
-#pragma unroll
-                for (int tau = 0; tau < 4; ++tau) x[tau] = acc[tau];
-            }
-#endif
-#endif
-            wave_lds_sync();
-            // ... the partial end states summed over the four lane groups; lane l ends up with chunk l of the wave
-            double ic1, ic2;
-#if defined(CPQ_ABL) && (CPQ_ABL & 1)
-            ic1 = e0[0]; ic2 = e1[1];
-#else
-            {
-                const double2 p0 = red[(g * 4 + 0) * 16 + m], p1 = red[(g * 4 + 1) * 16 + m];
-                const double2 p2 = red[(g * 4 + 2) * 16 + m], p3 = red[(g * 4 + 3) * 16 + m];
-                ic1 = (p0.x + p1.x) + (p2.x + p3.x);
-                ic2 = (p0.y + p1.y) + (p2.y + p3.y);
-            }
-#endif
-            // (3) chunk start states
-            double s0x, s0y;
-#if defined(CPQ_ABL) && (CPQ_ABL & 2)
-            s0x = ic1 * e0[1]; s0y = ic2 * e1[0];
-#else
-            tp_scan<NTHREADS>(ic1, ic2, s0x, s0y, &L->M[0][0], b, pw, wtot + par * 2 * ((NTHREADS ? NTHREADS : (int)blockDim.x) / 64), sState, sNext, tid,
-                              &tb[b].t[0].P[0][0]);
-            par ^= 1;
-#endif
-            // (4) the state response G s0 completes the product (k-step 4: rows 16 + g of [x ; s0], staged through the
-            // wave's LDS scratch), tile by tile, followed by (5) the element-wise output stage of that tile
-            *reinterpret_cast<double2*>(s0q + lane * 4) = make_double2(s0x, s0y);
-            *reinterpret_cast<double2*>(s0q + lane * 4 + 2) = make_double2(0.0, 0.0);
-            wave_lds_sync();
-            const double ag = L->Gq[b][m][g];
-            double sb[4];
-#pragma unroll
-            for (int tau = 0; tau < 4; ++tau) sb[tau] = s0q[(tau * 16 + m) * 4 + g];
-#pragma unroll
-            for (int tau = 0; tau < 4; ++tau) x[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag, sb[tau], x[tau], 0, 0, 0);
-#if defined(CPQ_ABL) && (CPQ_ABL & 8)
-            if (false) {
-#else
-            if (kind != 2) {          // kind 2 (OutputFilter biquad): linear section, no output stage
-#endif
-#pragma unroll
-                for (int tau = 0; tau < 4; ++tau) {
-                    double v[4] = { x[tau][0], x[tau][1], x[tau][2], x[tau][3] };
-                    // four compares with the |.| modifier (a NaN fails them and takes the guarded code below)
-                    const bool small = (int)(fabs(v[0]) < 4.5) & (int)(fabs(v[1]) < 4.5) & (int)(fabs(v[2]) < 4.5) & (int)(fabs(v[3]) < 4.5);
-                    if (smallOk && __all(small)) {
-                        if (SAT) tp_nonlinear_small<4>(v, smallC1);
-                    } else if (kind == 1) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
-                    else                  tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
-                    x[tau] = v4d{ v[0], v[1], v[2], v[3] };
-                }
-            }
-        }
 }
 
 __device__ __forceinline__ void tp_load_tables(TpLds* L, const double* __restrict__ cf,
@@ -876,243 +709,404 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
-// Span I/O of the matrix-form kernels.  The MFMA layout wants lane (m, g) to hold samples g + 4 j (register j) of chunk m;
-// loaded as such, one instruction touches an 8-byte word in 16 different 128-byte lines and every 32-byte sector is fetched
-// (and written) in pieces: PMC traffic 1.7x the algorithmic bytes.  Instead lane (m, g) moves the whole sector, samples
-// 4 g ... 4 g + 3, with two 16-byte accesses and a 4 x 4 transpose across the four 16-lane rows of the wave puts them in
-// place (v_permlane32_swap / v_permlane16_swap, tools/ubench/permlane_transpose.hip: 8 VALU instructions per tile).
-__device__ __forceinline__ void tp_swap32(double& a, double& b)      // rows 2,3 of a <-> rows 0,1 of b
+// ---------------------------------------------------------------------------------------------------------
+// Vector form with the chunk in registers ("tpv").  fp64 MFMA and fp64 VALU share one datapath on gfx950 at the same
+// rate (tools/ubench/coexec_f64.hip), so the dense form of a band's linear part -- T x on ten 4x4x4 block products, G s0
+// on a 16x16x4, E x as 32 FMAs and a cross-lane reduction: ~16 FMA slots per sample -- costs more issue slots than the
+// recurrence it replaces (10 operations per sample, end state included).  Here lane = one chunk of 16 consecutive
+// samples held in 32 VGPRs through all bands, and per band
+//   (1) the chunk start states come from the scan of the zero-state end states e = E x, which the PREVIOUS band's pass
+//       accumulated from its outputs as it produced them (2 FMAs per sample),
+//   (2) ONE pass over the 16 samples runs the reference recurrence from the true start state, applies the output stage
+//       and feeds the next band's E x: no zero-state run, no state-response fix-up, no cross-lane traffic inside a band.
+// Band coefficients are wave-uniform SGPR operands, the E rows come from LDS as broadcast reads, the per-lane scan powers
+// are requested one band ahead.  Span I/O: coalesced 16-byte accesses, transposed to chunk-per-lane through the wave's
+// own padded LDS buffer (two halves of eight samples); the next span's lines are requested into L2 while the bands run.
+// WAVES > 0: whole spans of WAVES x 1024 samples, the workgroup walks the spans g, g + nGroups, ... of its channel
+// (nGroups > 1: several workgroups per channel, chained spans, below); WAVES = 0: ONE span of blockDim.x / 64 (1 ... 7)
+// waves x 1024 samples (what a call leaves after its whole spans).
+// A span whose input or start state is outside the range for which the host proved the reference's guards idle ends the
+// fast loop: that span and the workgroup's later ones go through the one-thread guarded recurrence behind the loop
+// (cold code, kept out of the band loop's register allocation).
+
+// Chained spans (nGroups > 1; engines with fewer channels than the chip has room for workgroups): span s of a channel
+// needs, band by band, the state at the end of span s - 1 -- nothing else ties the spans together, so nGroups workgroups
+// work on consecutive spans of one channel at once, each one band-scan behind its predecessor.  Slot (channel, span,
+// band) carries the state at the END of that span + the ticket of the launch that wrote it (tickets never repeat, so
+// the slots need no clearing).  The launcher keeps channels x nGroups within the number of workgroups the chip holds at
+// once: a consumer only ever waits for a workgroup with a lower block index, which is resident or finished.
+struct TpvChainSlot { double sx, sy; unsigned long long ticket; unsigned long long pad; };
+
+__device__ __forceinline__ void tpv_chain_put(TpvChainSlot* s, double sx, double sy, unsigned long long ticket)
 {
-    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double(h[0], l[0]);
-    b = __hiloint2double(h[1], l[1]);
+    __hip_atomic_store(&s->sx, sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&s->sy, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&s->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void tp_swap16(double& a, double& b)      // rows 1,3 of a <-> rows 0,2 of b
+__device__ __forceinline__ void tpv_chain_get(const TpvChainSlot* s, double& sx, double& sy, unsigned long long ticket)
 {
-    const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    a = __hiloint2double(h[0], l[0]);
-    b = __hiloint2double(h[1], l[1]);
-}
-// s[i] at row g = element (g, i)  ->  s[j] at row g = element (j, g); its own inverse
-__device__ __forceinline__ void tp_transpose4(double (&s)[4])
-{
-    tp_swap32(s[0], s[2]);
-    tp_swap32(s[1], s[3]);
-    tp_swap16(s[0], s[1]);
-    tp_swap16(s[2], s[3]);
-}
-// chunk = the 16 samples of chunk m (128-byte aligned); g = lane >> 4
-__device__ __forceinline__ v4d tp_tile_load(const double* chunk, int g)
-{
-    // streaming accesses: a span is read once and written once per call; the L2 is left to the per-stream scan tables
-    typedef double v2 __attribute__((ext_vector_type(2)));
-    const v2 a = __builtin_nontemporal_load(reinterpret_cast<const v2*>(chunk + 4 * g));
-    const v2 b = __builtin_nontemporal_load(reinterpret_cast<const v2*>(chunk + 4 * g + 2));
-    double s[4] = { a.x, a.y, b.x, b.y };
-    tp_transpose4(s);
-    return v4d{ s[0], s[1], s[2], s[3] };
-}
-// Stores go through the wave's LDS scratch instead (tile = the 16 chunks x 16 samples = 2 KB at `tile`, buf = 16 rows of
-// kTpStride doubles): every store instruction then writes 1 KB of whole 128-byte lines.  Partial-line stores made the L2
-// fetch the rest of each line from memory first (PMC: reads 2.3x, writes 1.4x the algorithmic bytes).
-__device__ __forceinline__ void tp_tile_store(double* tile, double* buf, int lane, v4d x, double gain)
-{
-    const int m = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) buf[m * kTpStride + g + 4 * j] = x[j] * gain;
-    wave_lds_sync();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = lane + 64 * i;                          // pair of samples: chunk p >> 3, samples 2 (p & 7), + 1
-        typedef double v2 __attribute__((ext_vector_type(2)));
-        const double2 v = *reinterpret_cast<const double2*>(buf + (p >> 3) * kTpStride + 2 * (p & 7));
-        __builtin_nontemporal_store(v2{ v.x, v.y }, reinterpret_cast<v2*>(tile + 2 * p));
-    }
-    wave_lds_sync();                                          // the next tile reuses buf
+    while (__hip_atomic_load(&s->ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(2);
+    sx = __hip_atomic_load(&s->sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sy = __hip_atomic_load(&s->sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Eight waves per channel: spans of 8192 samples (512 chunks of 16).  The band loop is a dependent chain (end states ->
-// reduction -> scan -> product -> output stage) that two waves per SIMD do not hide; with twice the waves per channel
-// four waves share a SIMD.  No LDS staging of the span (it would not fit twice per CU beside the tables): every lane
-// loads and stores its 16 samples straight in the MFMA layout (4 x 8 B per 128-byte line and instruction, the four
-// registers of a tile cover the line).  Spans with non-finite / out-of-range input go through the guarded sequential
-// code in two 4096-sample halves staged in the scratch area.  Handles whole 8192-sample spans only; the launcher runs
-// k_svf_cascade_tp on what is left.
-// WAVES = 16 (spans of 16384 samples, one workgroup per CU) is for engines with fewer channels than the chip has CUs:
-// at 128 channels the eight-wave kernel leaves half the CUs idle and the other half at two waves per SIMD.
-constexpr int kTp8Threads = 512;
-constexpr int kTp8Span = kTp8Threads * 16;
+// tuning of the pass (A/B with tools/ab_tpv.sh): samples per group of the small-signal output stage; order of its
+// reciprocal refinement; the seven-operation recurrence for bands with m0 == 1 and m2 == 0
+#ifndef CPQ_TPV_U
+#define CPQ_TPV_U 4
+#endif
+#ifndef CPQ_TPV_ORDER
+#define CPQ_TPV_ORDER 2
+#endif
+#ifndef CPQ_TPV_PEAK
+#define CPQ_TPV_PEAK 1
+#endif
+constexpr int kTpvSpan = 8 * 1024;      // samples per span of the eight-wave kernel
+constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
+constexpr int kTpvGuardPiece = 2048;    // samples per staged piece of the guarded path
+
+// what the kernel keeps in LDS (8 waves: 76 KB, two workgroups per CU)
+template <int MAXW>
+struct TpvShared {
+    // per wave 64 rows x kTpvQStride (span I/O); as a whole: kTpvGuardPiece / 16 rows x kTpStride of the guarded path
+    alignas(16) double scratch[(MAXW * 64 * kTpvQStride > kTpvGuardPiece / 16 * kTpStride) ? MAXW * 64 * kTpvQStride
+                                                                                           : kTpvGuardPiece / 16 * kTpStride];
+    alignas(16) double P[kBands][64][4];                       // A^(16 (n + 1)): per-lane powers of the scan
+    alignas(16) double M[kBands][28];                          // Mk[6][4], Mw[4] of every band (scan)
+    alignas(16) double E[kBands][16][2];                       // (A^(15-k) B)_x, _y: end state of a chunk's zero-state run
+    double stateA[kBands * 2], stateB[kBands * 2];
+    double wtot[2 * 2 * MAXW];
+    int flag;
+    int bandBad[kBands];
+};
+
+// One band over the lane's 16 samples from its true start state.  KIND 0 / 3: SVF band, general / with m0 == 1 and m2 == 0
+// (seven operations per sample in the recurrence instead of ten) (the packed-stereo FMA arithmetic for
+// both arithmetic flavours of the reference -- the time-parallel evaluation is rounding-level anyway; `mono` selects the
+// scalar fastTanh's hard +-1 on the rare large-signal output stage), KIND 2: DF-II-T biquad of the OutputFilter.
+// The recurrence runs over all 16 samples first: the output stage does not feed back into the state, so it follows as
+// independent evaluations behind ONE wave-uniform test for the small-signal form.  En = the NEXT band's E rows in LDS.
+template <int KIND, bool SAT>
+__device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2, const double* __restrict__ cfb, bool mono,
+                                         const double* En, double& e0o, double& e1o,
+                                         double sat, double oneMinusSat, bool smallOk, double smallC1)
+{
+    {
+        const double a1 = cfb[0], a2 = cfb[1], a3 = cfb[2], m0 = cfb[3], m1 = cfb[4], m2 = cfb[5];
+        if (KIND == 3)          // m0 == 1 and m2 == 0 (peaking bands)
+            tp_recur<3, 16>(x, ic1, ic2, 2.0 * a2, 2.0 * a3, 0.0, a2, m1, a1);
+        else
+        tp_recur<KIND, 16>(x, ic1, ic2, a1, a2, a3, m0, m1, m2);
+    }
+    double e0 = 0.0, e1 = 0.0;
+    bool done = false;
+    if (KIND != 2) {          // kind 2: linear section, no output stage
+        int small = 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) small &= (int)(fabs(x[j]) < 4.5);      // a NaN fails and takes the general code
+        if (smallOk && __all(small)) {
+            // CPQ_TPV_U at a time, kept apart in the schedule: sixteen evaluations in flight at once do not fit the registers
+#pragma unroll
+            for (int h = 0; h < 16 / CPQ_TPV_U; ++h) {
+                double v[CPQ_TPV_U];
+#pragma unroll
+                for (int j = 0; j < CPQ_TPV_U; ++j) v[j] = x[CPQ_TPV_U * h + j];
+                if (SAT) tp_nonlinear_small<CPQ_TPV_U, CPQ_TPV_ORDER>(v, smallC1);
+#pragma unroll
+                for (int j = 0; j < CPQ_TPV_U; ++j) {
+                    const double2 ee = *reinterpret_cast<const double2*>(En + 2 * (CPQ_TPV_U * h + j));
+                    e0 = fma(ee.x, v[j], e0);
+                    e1 = fma(ee.y, v[j], e1);
+                    x[CPQ_TPV_U * h + j] = v[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            done = true;
+        } else {
+            // rare: a sample at or above the fastTanh clip threshold somewhere in the wave
+#pragma unroll 1
+            for (int h = 0; h < 4; ++h) {
+                // rotate instead of indexing: x stays in registers
+                double v[4] = { x[0], x[1], x[2], x[3] };
+                if (mono) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
+                else      tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) x[j] = x[j + 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[12 + j] = v[j];
+            }
+        }
+    }
+    if (!done) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double2 ee = *reinterpret_cast<const double2*>(En + 2 * j);
+            e0 = fma(ee.x, x[j], e0);
+            e1 = fma(ee.y, x[j], e1);
+        }
+    }
+    e0o = e0;
+    e1o = e1;
+}
+
+// span <-> registers: 8 coalesced 16-byte accesses per lane, transposed through the wave's LDS buffer in four quarters
+// (samples 4 h ... 4 h + 3 of every chunk: 64 rows of kTpvQStride).  Lane l of access k holds samples 2 (l & 7), + 1 of
+// chunk 8 k + (l >> 3): the lanes with ((l >> 1) & 3) == h belong to quarter h.
+__device__ __forceinline__ void tpv_span_load(const double* src, double* buf, int lane, double (&x)[16])
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    v2 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = __builtin_nontemporal_load(reinterpret_cast<const v2*>(src + k * 128 + lane * 2));
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (((lane >> 1) & 3) == h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1)) = make_double2(t[k].x, t[k].y);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double2 v = *reinterpret_cast<const double2*>(buf + lane * kTpvQStride + 2 * j);
+            x[4 * h + 2 * j] = v.x;
+            x[4 * h + 2 * j + 1] = v.y;
+        }
+        wave_lds_sync();
+    }
+}
+__device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lane, const double (&x)[16], double gain)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    v2 t[8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<double2*>(buf + lane * kTpvQStride + 2 * j) = make_double2(x[4 * h + 2 * j] * gain, x[4 * h + 2 * j + 1] * gain);
+        wave_lds_sync();
+        if (((lane >> 1) & 3) == h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
+                t[k] = v2{ v.x, v.y };
+            }
+        }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(t[k], reinterpret_cast<v2*>(dst + k * 128 + lane * 2));
+}
+
+// Guarded run of the spans sp, sp + nGroups, ... of a channel: pieces of kTpvGuardPiece samples staged in the scratch area as
+// [chunk][sample], one thread runs the reference recurrence with every guard, band by band.  Chained spans: the start
+// states arrive band by band from the span before, the end states are published band by band (skipPub = bands of the
+// first span that the fast path already published before it found a start state out of range).
+template <class SH>
+__device__ void tpv_guarded_spans(SH& sh, int sp, int nSpans, int nGroups, int spanLen, const double* inCh, double* outCh,
+                                  double* sState, const double* cf, unsigned activeMask, unsigned long long kinds, double sat,
+                                  double gain, TpvChainSlot* chainCh, unsigned long long ticket, unsigned skipPub, int tid,
+                                  int nThreads)
+{
+    const bool chained = nGroups > 1;
+    for (; sp < nSpans; sp += nGroups) {
+        for (int base = 0; base < spanLen; base += kTpvGuardPiece) {
+            const int cnt = (spanLen - base < kTpvGuardPiece) ? spanLen - base : kTpvGuardPiece;
+            const double* src = inCh + (int64_t)sp * spanLen + base;
+            double* dst = outCh + (int64_t)sp * spanLen + base;
+            __syncthreads();
+            for (int j = tid; j < cnt; j += nThreads) sh.scratch[(j >> 4) * kTpStride + (j & 15)] = src[j];
+            __syncthreads();
+            if (tid == 0) {
+                for (unsigned m = activeMask; m; m &= m - 1) {
+                    const int b = __builtin_ctz(m);
+                    const int kind = (int)((kinds >> (2 * b)) & 3);
+                    if (chained && sp > 0 && base == 0)
+                        tpv_chain_get(chainCh + (int64_t)(sp - 1) * kBands + b, sState[2 * b], sState[2 * b + 1], ticket);
+                    if (kind == 2)      tp_band_guarded<2>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
+                    else if (kind == 1) tp_band_guarded<1>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
+                    else                tp_band_guarded<0>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
+                    if (chained && base + cnt == spanLen && !((skipPub >> b) & 1))
+                        tpv_chain_put(chainCh + (int64_t)sp * kBands + b, sState[2 * b], sState[2 * b + 1], ticket);
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < cnt; j += nThreads) dst[j] = sh.scratch[(j >> 4) * kTpStride + (j & 15)] * gain;
+        }
+        skipPub = 0;
+    }
+    __syncthreads();
+}
+
+struct TpvChain { const TpvChainSlot* prev; TpvChainSlot* cur; unsigned long long ticket; };   // slots of span - 1 / this span (or null)
+
+// The bands of `run` (one class: CLS 0 = SVF, 3 = SVF with output v0 + m1 v1, 2 = DF-II-T) over the span held in x: per band the scan of the chunk end
+// states, then the pass.  e0 / e1: E x of the run's first band on entry, of the first band of `rest` (the bands behind
+// the run) on exit.  Returns false when a chained start state was out of the proven range (the span then restarts on the
+// guarded path; nothing has been stored).
+template <int CLS, bool SAT, int NT, class SH>
+__device__ __forceinline__ bool tpv_band_run(double (&x)[16], double& e0, double& e1, int& par, unsigned run, unsigned rest,
+                                             unsigned monoMask, SH& sh, double* sState, double* sNext, const double* __restrict__ cf,
+                                             double sat, const TpvChain& ch, unsigned& skipPub, int tid, int nThreads)
+{
+    const double oneMinusSat = 1.0 - sat;
+    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
+    const double smallC1 = 9.0 - 8.0 * sat;
+    const TpLanePowers pw = {};                       // the per-lane powers come from LDS where tp_scan uses them
+#pragma unroll 1
+    while (run) {
+        const int b = __builtin_ctz(run);
+        run &= run - 1;
+        const int nb = run ? __builtin_ctz(run) : (rest ? __builtin_ctz(rest) : b);     // last band: its E x result is not used
+        if (ch.prev && tid == 0) {
+            double sx, sy;
+            tpv_chain_get(ch.prev + b, sx, sy, ch.ticket);
+            sState[2 * b] = sx;
+            sState[2 * b + 1] = sy;
+            if (!(fabs(sx) < kTpInputBound) || !(fabs(sy) < kTpInputBound)) sh.bandBad[b] = 1;
+        }
+        double s0x, s0y;
+        tp_scan<NT>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tid, &sh.P[b][0][0]);
+        par ^= 1;
+        if (ch.cur) {
+            if (sh.bandBad[b]) return false;                  // written before the barrier inside tp_scan
+            if (tid == nThreads - 1) tpv_chain_put(ch.cur + b, sNext[2 * b], sNext[2 * b + 1], ch.ticket);
+            skipPub |= 1u << b;
+        }
+        tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1);
+    }
+    return true;
+}
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 4) void k_svf_cascade_tp8(const double* in, double* out, int64_t chStride,
-                                                                int nSpans, const double* __restrict__ coef,
-                                                                const int* __restrict__ flags,
-                                                                const double* __restrict__ satGain,
-                                                                double* __restrict__ state,
-                                                                const TpBandTables* __restrict__ tables)
+__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
+                                                                              int nSpans, int nGroups, const double* __restrict__ coef,
+                                                                              const int* __restrict__ flags,
+                                                                              const double* __restrict__ satGain,
+                                                                              double* __restrict__ state,
+                                                                              const TpBandTables* __restrict__ tables,
+                                                                              TpvChainSlot* chain, int chainSpans,
+                                                                              unsigned long long ticket)
 {
-    constexpr int kThreads = WAVES * 64, kSpan = kThreads * 16;
-    constexpr int kScratchDoubles = WAVES * (512 + 256);     // per wave: red (256 double2) + s0q (256 doubles); 8 waves: 48 KB
-    static_assert(kScratchDoubles >= 256 * kTpStride, "the guarded path stages 4096 samples in the scratch area");
-    __shared__ __align__(16) double scratch[kScratchDoubles];
-    __shared__ TpLdsM LM;
-    __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];
-    __shared__ double wtot[2 * 2 * WAVES];
-    __shared__ int sFlag;
-    const int tid = threadIdx.x;
+    constexpr int kMaxWaves = WAVES ? WAVES : 7;
+    constexpr int kNT = WAVES * 64;                           // 0: blockDim.x
+    __shared__ TpvShared<kMaxWaves> sh;
+    const int tid = threadIdx.x, nThreads = WAVES ? kNT : (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, g = lane >> 4;
-    const int c = blockIdx.x;
-    const double* cf = coef + (int64_t)c * kBands * 6;
-    const int* fl = flags + c * kBands;
-    const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;
+    const int c = blockIdx.x / nGroups, grp = blockIdx.x - c * nGroups;
+    const int spanLen = nThreads * 16;
+    const double* __restrict__ cf = coef + (int64_t)c * kBands * 6;
+    const TpBandTables* __restrict__ tb = tables + (int64_t)(c >> 1) * kBands;
     const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
-    double* sState = sStateA;
-    double* sNext = sStateB;
-    if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
-    tp_load_tables_m(&LM, cf, tb, tid, kThreads);
+    const bool chained = nGroups > 1;
+    TpvChainSlot* chainCh = chain + (int64_t)c * chainSpans * kBands;
+    const double* inCh = in + (int64_t)c * chStride;
+    double* outCh = out + (int64_t)c * chStride;
+    unsigned activeMask = 0;                                  // bit b: band b is active
+    unsigned long long kinds = 0;                             // 2 bits per band: 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
+    for (int b = 0; b < kBands; ++b) {
+        const int f = flags[c * kBands + b];
+        activeMask |= (unsigned)(f & 1) << b;
+        kinds |= (unsigned long long)((f >> 1) & 3) << (2 * b);
+    }
+    // DF-II-T sections; SVF bands with the scalar fastTanh; SVF bands whose output is v0 + m1 v1 (every peaking band)
+    unsigned dfMask = 0, monoMask = 0, peakMask = 0;
+    for (int b = 0; b < kBands; ++b) {
+        dfMask |= (unsigned)(((kinds >> (2 * b)) & 3) == 2) << b;
+        monoMask |= (unsigned)(((kinds >> (2 * b)) & 3) == 1) << b;
+        peakMask |= (unsigned)(CPQ_TPV_PEAK && ((kinds >> (2 * b)) & 3) != 2 && cf[b * 6 + 3] == 1.0 && cf[b * 6 + 5] == 0.0) << b;
+    }
+    double* sState = sh.stateA;
+    double* sNext = sh.stateB;
+    if (tid < kBands * 2) { sh.stateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sh.stateB[tid] = sh.stateA[tid]; }
+    for (int i = tid; i < kBands * 28; i += nThreads) {
+        const int b = i / 28, q = i % 28;
+        sh.M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
+    }
+    for (int i = tid; i < kBands * 32; i += nThreads) {
+        const int b = i / 32, k = (i % 32) >> 1, r = i & 1;
+        sh.E[b][k][r] = tb[b].mm.e[r][k];
+    }
+    for (int i = tid; i < kBands * 128; i += nThreads) {       // 16-byte pieces of P[64][4]
+        const int b = i >> 7, q = i & 127;
+        reinterpret_cast<double2*>(&sh.P[b][0][0])[q] = reinterpret_cast<const double2*>(&tb[b].t[0].P[0][0])[q];
+    }
     __syncthreads();
+    double* buf = sh.scratch + wave * 64 * kTpvQStride;
+    unsigned skipPub = 0;
 
-    for (int sp = 0; sp < nSpans; ++sp) {
-        const double* src = in + (int64_t)c * chStride + (int64_t)sp * kSpan;
-        double* dst = out + (int64_t)c * chStride + (int64_t)sp * kSpan;
-        v4d x[4];
+    int sp = grp;
+#pragma unroll 1
+    for (; sp < nSpans; sp += nGroups) {
+        const double* src = inCh + (int64_t)sp * spanLen + wave * 1024;
+        double x[16];
+        tpv_span_load(src, buf, lane, x);
         bool bad = false;
 #pragma unroll
-        for (int tau = 0; tau < 4; ++tau) {
-            x[tau] = tp_tile_load(src + (wave * 64 + tau * 16 + m) * 16, g);
+        for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
+        // unchained: the start states of all bands are known now; chained: they arrive band by band and are tested there
+        if (!chained || sp == 0) { if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound); }
+        if (tid == 0) sh.flag = 0;
+        if (tid < kBands) sh.bandBad[tid] = 0;
+        __syncthreads();
+        if (__any(bad) && lane == 0) atomicOr(&sh.flag, 1);
+        __syncthreads();
+        if (sh.flag != 0) break;
+
+        // ---- the band loop: runs of one band class (an EQ channel is all SVF bands, an OutputFilter channel all DF-II-T
+        // sections: one run), each in a loop body of its own
+        bool stopped = false;
+        if (activeMask) {
+            double e0 = 0.0, e1 = 0.0;
+            {
+                const double* E = &sh.E[__builtin_ctz(activeMask)][0][0];     // the first band's E x on the raw input
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bad |= !(fabs(x[tau][j]) < kTpInputBound);
-        }
-        if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
-        if (tid == 0) sFlag = 0;
-        __syncthreads();
-        if (__any(bad) && lane == 0) atomicOr(&sFlag, 1);
-        __syncthreads();
-        if (sFlag != 0) {
-            // guarded path: pieces of 4096 samples through the one-thread reference recurrence, staged in the scratch
-            // area as [chunk][sample]; in and out may alias, every sample of a piece is read before the piece is written
-            for (int half = 0; half < kSpan / 4096; ++half) {
-                for (int j = tid; j < 4096; j += kThreads)
-                    scratch[(j / 16) * kTpStride + (j % 16)] = src[half * 4096 + j];
-                __syncthreads();
-                for (int b = 0; b < kBands; ++b) {
-                    const int flag = fl[b];
-                    if (!(flag & 1)) continue;
-                    if (tid == 0) {
-                        if (flag & 4)      tp_band_guarded<2>(scratch, 16, LM.cf[b], sat, sState + 2 * b);
-                        else if (flag & 2) tp_band_guarded<1>(scratch, 16, LM.cf[b], sat, sState + 2 * b);
-                        else               tp_band_guarded<0>(scratch, 16, LM.cf[b], sat, sState + 2 * b);
-                    }
-                    __syncthreads();
+                for (int j = 0; j < 16; ++j) {
+                    const double2 ee = *reinterpret_cast<const double2*>(E + 2 * j);
+                    e0 = fma(ee.x, x[j], e0);
+                    e1 = fma(ee.y, x[j], e1);
                 }
-                for (int j = tid; j < 4096; j += kThreads)
-                    dst[half * 4096 + j] = scratch[(j / 16) * kTpStride + (j % 16)] * gain;
-                __syncthreads();
             }
-            continue;
+            // the next span of this workgroup: one 4-byte load per 128-byte line pulls it into L2 while the bands run
+            if (sp + nGroups < nSpans) (void)*reinterpret_cast<const volatile int*>(src + (int64_t)nGroups * spanLen + lane * 16);
+            int par = 0;
+            unsigned mask = activeMask;
+#pragma unroll 1
+            while (mask && !stopped) {
+                const int bFirst = __builtin_ctz(mask);
+                const int cls = ((dfMask >> bFirst) & 1) ? 2 : (((peakMask >> bFirst) & 1) ? 3 : 0);
+                const unsigned same = mask & (cls == 2 ? dfMask : (cls == 3 ? peakMask : ~(dfMask | peakMask)));
+                const unsigned other = mask & ~same;
+                const unsigned run = other ? (same & ((other & (0u - other)) - 1u)) : same;     // bands below the first one of another class
+                const unsigned rest = mask & ~run;
+                const TpvChain ch = { chained && sp > 0 ? chainCh + (int64_t)(sp - 1) * kBands : nullptr,
+                                      chained ? chainCh + (int64_t)sp * kBands : nullptr, ticket };
+#define CPQ_RUN(CLS, SAT) stopped = !tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, ch, skipPub, tid, nThreads)
+                if (cls == 2)        CPQ_RUN(2, false);
+                else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
+                else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }
+#undef CPQ_RUN
+                mask = rest;
+            }
         }
-        double2* red = reinterpret_cast<double2*>(scratch) + wave * 256;
-        double* s0q = scratch + WAVES * 512 + wave * 256;
-        if (sat > 0.0) tp_bands_mfma<true, kThreads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
-        else           tp_bands_mfma<false, kThreads>(x, red, s0q, wtot, sState, sNext, &LM, tid, fl, tb, sat);
-#pragma unroll
-        for (int tau = 0; tau < 4; ++tau)
-            tp_tile_store(dst + (wave * 64 + tau * 16) * 16, reinterpret_cast<double*>(red), lane, x[tau], gain);
+        if (stopped) break;                   // (the span's input is untouched: nothing has been stored yet)
+        skipPub = 0;
+        tpv_span_store(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
         __syncthreads();                      // the last thread's end states are in sNext
-        { double* t = sState; sState = sNext; sNext = t; }
+        if (!chained) { double* t = sState; sState = sNext; sNext = t; }
+    }
+    bool slow = false;
+    if (sp < nSpans) {
+        // cold: this span and the workgroup's later ones through the guarded recurrence (states advance in sState)
+        slow = true;
+        tpv_guarded_spans(sh, sp, nSpans, nGroups, spanLen, inCh, outCh, sState, cf, activeMask, kinds, sat, gain, chainCh, ticket,
+                          skipPub, tid, nThreads);
     }
     __syncthreads();
-    if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// One to seven waves per channel, ONE span of waves x 1024 samples in the same matrix form: what a call leaves after
-// its whole 8192-sample spans (and all of a call of 2 ... 15 blocks of 512).  The cost of a span is the latency of the
-// 20-band chain, whatever its length, so the remainder is split over as many waves as it has 1024-sample pieces rather
-// than walked through span by span; before, it ran as 4096-sample spans on four waves and then as 512-sample spans in
-// VALU form (chunk length 2) at three times the cost per block.
-constexpr int kTpwMaxWaves = 7;
-constexpr int kTpwScratchDoubles = kTpwMaxWaves * (512 + 256);      // per wave: red (256 double2) + s0q (256 doubles)
-
-__global__ __launch_bounds__(kTpwMaxWaves * 64, 4) void k_svf_cascade_tpw(const double* in, double* out, int64_t chStride,
-                                                                       const double* __restrict__ coef,
-                                                                       const int* __restrict__ flags,
-                                                                       const double* __restrict__ satGain,
-                                                                       double* __restrict__ state,
-                                                                       const TpBandTables* __restrict__ tables)
-{
-    static_assert(kTpwScratchDoubles >= 256 * kTpStride, "the guarded path stages up to 4096 samples in the scratch area");
-    __shared__ __align__(16) double scratch[kTpwScratchDoubles];
-    __shared__ TpLdsM LM;
-    __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];
-    __shared__ double wtot[2 * 2 * kTpwMaxWaves];
-    __shared__ int sFlag;
-    const int tid = threadIdx.x, nThreads = blockDim.x;
-    const int nWaves = nThreads >> 6;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, g = lane >> 4;
-    const int c = blockIdx.x;
-    const double* cf = coef + (int64_t)c * kBands * 6;
-    const int* fl = flags + c * kBands;
-    const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;
-    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
-    if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
-    tp_load_tables_m(&LM, cf, tb, tid, nThreads);
-    if (tid == 0) sFlag = 0;
-    __syncthreads();
-
-    const double* src = in + (int64_t)c * chStride;
-    double* dst = out + (int64_t)c * chStride;
-    v4d x[4];
-    bool bad = false;
-#pragma unroll
-    for (int tau = 0; tau < 4; ++tau) {
-        x[tau] = tp_tile_load(src + (wave * 64 + tau * 16 + m) * 16, g);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bad |= !(fabs(x[tau][j]) < kTpInputBound);
-    }
-    if (tid < kBands * 2) bad |= !(fabs(sStateA[tid]) < kTpInputBound);
-    if (__any(bad) && lane == 0) atomicOr(&sFlag, 1);
-    __syncthreads();
-    if (sFlag != 0) {
-        // guarded path: pieces of up to 4096 samples through the one-thread reference recurrence, staged in the scratch
-        // area as [chunk][sample]; in and out may alias, every sample of a piece is read before the piece is written
-        const int nSamples = nWaves * 1024;
-        for (int base = 0; base < nSamples; base += 4096) {
-            const int cnt = (nSamples - base < 4096) ? nSamples - base : 4096;
-            for (int j = tid; j < cnt; j += nThreads) scratch[(j / 16) * kTpStride + (j % 16)] = src[base + j];
-            __syncthreads();
-            for (int b = 0; b < kBands; ++b) {
-                const int flag = fl[b];
-                if (!(flag & 1)) continue;
-                if (tid == 0) {
-                    if (flag & 4)      tp_band_guarded<2>(scratch, 16, LM.cf[b], sat, sStateA + 2 * b, cnt / 16);
-                    else if (flag & 2) tp_band_guarded<1>(scratch, 16, LM.cf[b], sat, sStateA + 2 * b, cnt / 16);
-                    else               tp_band_guarded<0>(scratch, 16, LM.cf[b], sat, sStateA + 2 * b, cnt / 16);
-                }
-                __syncthreads();
-            }
-            for (int j = tid; j < cnt; j += nThreads) dst[base + j] = scratch[(j / 16) * kTpStride + (j % 16)] * gain;
-            __syncthreads();
-        }
-        if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sStateA[tid];
-        return;
-    }
-    double2* red = reinterpret_cast<double2*>(scratch) + wave * 256;
-    double* s0q = scratch + kTpwMaxWaves * 512 + wave * 256;
-    if (sat > 0.0) tp_bands_mfma<true, 0>(x, red, s0q, wtot, sStateA, sStateB, &LM, tid, fl, tb, sat);
-    else           tp_bands_mfma<false, 0>(x, red, s0q, wtot, sStateA, sStateB, &LM, tid, fl, tb, sat);
-#pragma unroll
-    for (int tau = 0; tau < 4; ++tau)
-        tp_tile_store(dst + (wave * 64 + tau * 16) * 16, reinterpret_cast<double*>(red), lane, x[tau], gain);
-    __syncthreads();                          // the span's end states are in sStateB
-    if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sStateB[tid];
+    // the call's end states: from the workgroup that ran the last span.  In sState, except after a chained fast span:
+    // there the active bands' are in sNext (inactive bands keep their state)
+    if (nSpans > 0 && (nSpans - 1) % nGroups == grp && tid < kBands * 2)
+        state[(int64_t)c * kBands * 2 + tid] = (chained && !slow && ((activeMask >> (tid >> 1)) & 1)) ? sNext[tid] : sState[tid];
 }
 
 }  // namespace
@@ -1131,37 +1125,49 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 }  // namespace cpq
 
 namespace cpq {
+size_t svf_chain_bytes(int nCh, int maxSamples)
+{
+    return (size_t)nCh * (size_t)(maxSamples / kTpvSpan + 1) * kBands * sizeof(TpvChainSlot);
+}
+
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
                            const double* coef, const int* flags, const double* satGain, double* state,
-                           const void* tables)
+                           const void* tables, void* chain, int chainSpans, unsigned long long* ticket)
 {
     static_assert(sizeof(TpBandTables) == kSvfTpTableDoubles * sizeof(double), "host/device table layout");
     // whole 8192-sample spans on the eight-wave kernel, what is left as one span of 1 ... 7 waves x 1024 samples, and a
     // last block of 512 on the chunk-length-2 path of the four-wave kernel
     const TpBandTables* tb = reinterpret_cast<const TpBandTables*>(tables);
     int done = 0;
-    // fewer channels than CUs: sixteen waves per channel on the whole 16384-sample spans
-    static int nCu = 0;
-    if (nCu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        nCu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    const int nSpans8 = nSamples / kTpvSpan;
+    if (nSpans8 > 0) {
+        // Chained spans (several workgroups per channel, the band states handed over through global memory) cost a
+        // device-scope release / acquire per band -- an L2 write-back each -- and every workgroup of a chain must be
+        // resident at once.  Measured slower than one workgroup per channel from 64 streams up and faster only below
+        // ~32 channels (profiles/r03b_eq_chained_spans.txt); off unless CPQ_SVF_CHAIN=1 (experiments).
+        int nGroups = 1;
+        static int chainOn = -1, nCu = 0;
+        if (chainOn < 0) {
+            const char* f = getenv("CPQ_SVF_CHAIN");
+            chainOn = (f && f[0] == '1') ? 1 : 0;
+            int dev = 0;
+            hipDeviceProp_t prop;
+            nCu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        if (chainOn == 1 && chain && ticket && nSpans8 <= chainSpans) {
+            nGroups = (3 * nCu / 2) / nCh;      // three quarters of the workgroups the chip holds at once (two per CU)
+            if (nGroups > nSpans8) nGroups = nSpans8;
+            if (nGroups < 2) nGroups = 1;
+        }
+        const unsigned long long tk = ticket ? ++*ticket : 0ull;
+        hipLaunchKernelGGL(k_svf_cascade_tpv<8>, dim3(nCh * nGroups), dim3(512), 0, stream, in, out, chStride, nSpans8, nGroups,
+                           coef, flags, satGain, state, tb, reinterpret_cast<TpvChainSlot*>(chain), chainSpans, tk);
+        done = nSpans8 * kTpvSpan;
     }
-    if (nCh <= nCu && nSamples >= 2 * kTp8Span) {
-        const int nSpans16 = nSamples / (2 * kTp8Span);
-        hipLaunchKernelGGL(k_svf_cascade_tp8<16>, dim3(nCh), dim3(2 * kTp8Threads), 0, stream, in, out, chStride, nSpans16, coef,
-                           flags, satGain, state, tb);
-        done = nSpans16 * 2 * kTp8Span;
-    }
-    const int nSpans8 = (nSamples - done) / kTp8Span;
-    if (nSpans8 > 0)
-        hipLaunchKernelGGL(k_svf_cascade_tp8<8>, dim3(nCh), dim3(kTp8Threads), 0, stream, in + done, out + done, chStride, nSpans8,
-                           coef, flags, satGain, state, tb);
-    done += nSpans8 * kTp8Span;
     const int nWaves = (nSamples - done) / 1024;
     if (nWaves > 0) {
-        hipLaunchKernelGGL(k_svf_cascade_tpw, dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, coef,
-                           flags, satGain, state, tb);
+        hipLaunchKernelGGL(k_svf_cascade_tpv<0>, dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, 1,
+                           coef, flags, satGain, state, tb, (TpvChainSlot*)nullptr, 0, 0ull);
         done += nWaves * 1024;
     }
     if (nSamples > done)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 2; the CPQ_ABL hooks are in tools/variants/svf_matrix_form.hip, which is no longer built)
 # timing ablation of the matrix-form EQ kernel (results are wrong by construction): builds variants with phases removed
 # (CPQ_ABL bits: 1 reduction, 2 scan, 4 T.x product, 8 output stage) and times the EQ alone on the bench workload.
 # usage on the GPU box: bash tools/ablate_svf.sh
