@@ -19,8 +19,11 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
     if (!e->groups.empty()) { const int rc = groupsAppend(e, dIn, n); if (rc != CPQ_OK) return rc; }
     if (e->anyDirect) {
         ProfScope p(e, CPQ_K_MIX);
+        // a stream whose convolver rests (per-stream bypass / dry-only at the processor level) keeps its head history: the
+        // reference's processDirectBlock sits inside Add(), which ConvolverProcessor does not call then
         cpq::launch_direct_head(e->stream, dIn, stride, (int)stride, e->directIr, e->directTaps, e->irSlot,
-                                e->directHist[e->directSel], e->directHist[e->directSel ^ 1], e->directOut, e->nCh);
+                                e->directHist[e->directSel], e->directHist[e->directSel ^ 1], e->directOut, e->nCh,
+                                e->honourFrozen ? e->procWetOn : nullptr);
         e->directSel ^= 1;
     }
     auto addDirect = [&]() {

@@ -145,6 +145,60 @@ const char* cpq_kernel_name(int32_t id)
     }
 }
 
+// ------------------------------------------------------------------ diagnostics
+// The partition FFT kernels in isolation (tests/test_gpu_fft.py): forward of every overlap-save frame from a silent history,
+// inverse of the same spectra.  Own device buffers and twiddles, the null stream; no engine.
+int32_t cpq_diag_partition_fft(int32_t P, int32_t nCh, int32_t T, const double* in, double* spectra, double* out)
+{
+    if (P < 64 || P > 32768 || (P & (P - 1)) || nCh <= 0 || T <= 0 || !in || !spectra || !out) return CPQ_ERR_INVALID_ARG;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) { (void)hipGetLastError(); return CPQ_ERR_NO_DEVICE; }
+    int ringSlots = 1;
+    while (ringSlots < T) ringSlots <<= 1;
+    const size_t nTime = (size_t)nCh * T * P, nSpec = (size_t)nCh * ringSlots * P;
+    double *dIn = nullptr, *dOut = nullptr, *dHist = nullptr;
+    double2 *dX = nullptr, *dXdn = nullptr, *dTw = nullptr, *dTw2 = nullptr, *dScratch = nullptr, *dY = nullptr;
+    std::vector<double2> w1((size_t)P), w2((size_t)P);
+    const long double twoPi = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < P; ++m) {
+        const long double a = -twoPi * m / (long double)P, b = -twoPi * m / (long double)(2 * P);
+        w1[(size_t)m] = make_double2((double)cosl(a), (double)sinl(a));
+        w2[(size_t)m] = make_double2((double)cosl(b), (double)sinl(b));
+    }
+    int32_t rc = CPQ_OK;
+    auto ok = [&](hipError_t err) { if (err != hipSuccess && rc == CPQ_OK) { (void)hipGetLastError(); rc = CPQ_ERR_DEVICE; } return err == hipSuccess; };
+    ok(hipMalloc((void**)&dIn, nTime * sizeof(double))) && ok(hipMalloc((void**)&dOut, nTime * sizeof(double))) &&
+        ok(hipMalloc((void**)&dHist, (size_t)2 * nCh * P * sizeof(double))) && ok(hipMalloc((void**)&dX, nSpec * sizeof(double2))) &&
+        ok(hipMalloc((void**)&dXdn, (size_t)nCh * ringSlots * sizeof(double2))) && ok(hipMalloc((void**)&dTw, (size_t)P * sizeof(double2))) &&
+        ok(hipMalloc((void**)&dTw2, (size_t)P * sizeof(double2))) &&
+        ok(hipMalloc((void**)&dScratch, (P > 4096 ? (size_t)nCh * T * P : 1) * sizeof(double2))) &&
+        ok(hipMalloc((void**)&dY, (size_t)nCh * T * P * sizeof(double2)));
+    if (rc == CPQ_OK) {
+        ok(hipMemset(dHist, 0, (size_t)2 * nCh * P * sizeof(double)));
+        ok(hipMemset(dX, 0, nSpec * sizeof(double2)));
+        ok(hipMemcpy(dIn, in, nTime * sizeof(double), hipMemcpyHostToDevice));
+        ok(hipMemcpy(dTw, w1.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice));
+        ok(hipMemcpy(dTw2, w2.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    if (rc == CPQ_OK) {
+        const cpq::FftTables tw{ dTw, dTw2 };
+        cpq::launch_rfft_fwd_ols(nullptr, dIn, (int64_t)T * P, dHist, dHist + (size_t)nCh * P, dX, dXdn, tw, P, nCh, T, 0, ringSlots, dScratch);
+        // the ring holds block t of channel c at [c][t] of ringSlots slots: [c][t] of T slots for the inverse and the caller
+        for (int c = 0; c < nCh && rc == CPQ_OK; ++c)
+            ok(hipMemcpyAsync(dY + (size_t)c * T * P, dX + (size_t)c * ringSlots * P, (size_t)T * P * sizeof(double2), hipMemcpyDeviceToDevice, nullptr));
+        cpq::launch_rfft_inv_ols(nullptr, dY, dOut, (int64_t)T * P, tw, P, nCh, T, dScratch);
+        ok(hipGetLastError());
+        ok(hipDeviceSynchronize());
+    }
+    if (rc == CPQ_OK) {
+        ok(hipMemcpy(spectra, dY, (size_t)nCh * T * P * sizeof(double2), hipMemcpyDeviceToHost));
+        ok(hipMemcpy(out, dOut, nTime * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    for (void* p : { (void*)dIn, (void*)dOut, (void*)dHist, (void*)dX, (void*)dXdn, (void*)dTw, (void*)dTw2, (void*)dScratch, (void*)dY })
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 // ------------------------------------------------------------------ host-only helpers
 int32_t cpq_nuc_plan_compute(int32_t irLen, int32_t blockSize, int32_t direct, const cpq_filter_spec* spec,
                              cpq_nuc_plan* plan)

@@ -242,6 +242,7 @@ struct cpq_engine {
     std::vector<char> procBypass, procDryOnly;      // per stream: bypassed / mix <= 0.001 (the convolver is not called)
     std::vector<int> procWetOnHost;                 // per stream: what the device flags hold
     int* procWetOn = nullptr;                       // [streams] device: 0 = the stream's output is the delayed dry signal
+    bool honourFrozen = false;                      // set around the convolver call of enqueueConvProc: frozen plan groups (and their direct heads) rest
     // mix smoothing (LinearRamp mixSmoother, src/ConvolverProcessor.h:945; Runtime.cpp:340-375, 591-607): per stream
     struct MixRamp { double current = 1.0, target = 1.0, step = 0.0; int remaining = 0, totalSteps = 4800; };
     std::vector<MixRamp> mixRamp;
@@ -324,6 +325,7 @@ int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double*
                      const cpq_filter_spec* spec, const cpq_nuc_plan& pl);
 int leaveNativeGroup(cpq_engine* e, int stream);
 int setStreamFrozen(cpq_engine* e, int stream, bool frozen);
+void clearFrozen(cpq_engine* e);           // no plan group rests any more (conv level change, reset, prepare)
 int groupsAppend(cpq_engine* e, const double* dIn, int n);
 int groupsRunLayer0(cpq_engine* e, double* dOut, int n);
 int groupsRunTails(cpq_engine* e, double* dOut, int n);

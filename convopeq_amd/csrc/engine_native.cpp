@@ -142,45 +142,63 @@ int tabEntries(const cpq_engine* e, const PlanGroup& g)
     return n;
 }
 
-// a group with room for capPairs streams: allocates every layer (the old buffers' row prefixes are kept when growing)
+// a group with room for capPairs streams: allocates every layer (the old buffers' row prefixes are kept when growing).
+// The new layers are built aside and swapped in on success: on any failure the group is as it was.
 int sizeGroup(cpq_engine* e, PlanGroup& g, int capPairs)
 {
     const int newCapCh = 2 * capPairs;
     const int hSlots = g.shared ? 2 : newCapCh;
-    std::vector<NativeLayer> old = g.layers;
+    const std::vector<NativeLayer>& old = g.layers;
     const int oldCapCh = g.capCh, oldHSlots = g.shared ? 2 : oldCapCh;
-    g.layers.clear();
+    std::vector<NativeLayer> fresh;
+    int* chMapNew = nullptr;
+    int* irSlotNew = nullptr;
+    long long* tabNew = nullptr;
+    auto undo = [&](int rc) {
+        for (NativeLayer& t : fresh) if (t.mem) (void)hipFree(t.mem);
+        if (chMapNew) (void)hipFree(chMapNew);
+        if (irSlotNew) (void)hipFree(irSlotNew);
+        if (tabNew) (void)hipFree(tabNew);
+        (void)hipGetLastError();
+        return rc;
+    };
     for (int l = 0; l < g.plan.num_layers; ++l) {
         NativeLayer t;
         if (!old.empty()) { t = old[(size_t)l]; t.mem = nullptr; }
         layerGeometry(e, g.plan, l, t);
         const int rc = allocLayer(e, g, t, newCapCh, hSlots);
-        if (rc != CPQ_OK) { for (NativeLayer& o : old) if (o.mem) (void)hipFree(o.mem); return rc; }
+        if (rc != CPQ_OK) return undo(rc);
+        fresh.push_back(t);
         if (!old.empty()) {
-            NativeLayer& o = old[(size_t)l];
-            auto src = layerItems(o), dst = layerItems(t);
+            const NativeLayer& o = old[(size_t)l];
+            NativeLayer oc = o;
+            auto src = layerItems(oc), dst = layerItems(fresh.back());
             for (size_t i = 0; i < src.size(); ++i) {
                 const int64_t rows = src[i].perSlot ? oldHSlots : oldCapCh;
-                CPQ_HIP(e, hipMemcpyAsync(*dst[i].ptr, *src[i].ptr, (size_t)(rows * src[i].rowBytes), hipMemcpyDeviceToDevice, e->stream));
+                if (hipMemcpyAsync(*dst[i].ptr, *src[i].ptr, (size_t)(rows * src[i].rowBytes), hipMemcpyDeviceToDevice, e->stream) != hipSuccess)
+                    return undo(fail(e, CPQ_ERR_DEVICE, "plan group rows could not be copied"));
             }
         }
-        g.layers.push_back(t);
     }
-    CPQ_HIP(e, hipStreamSynchronize(e->stream));
-    for (NativeLayer& o : old) if (o.mem) (void)hipFree(o.mem);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return undo(fail(e, CPQ_ERR_DEVICE, "plan group resize: stream error"));
+    PlanGroup probe = g;                      // table size of the new geometry
+    probe.layers = fresh;
+    const int tabCap = tabEntries(e, probe);
+    if (hipMalloc((void**)&chMapNew, sizeof(int) * newCapCh) != hipSuccess || hipMalloc((void**)&irSlotNew, sizeof(int) * newCapCh) != hipSuccess ||
+        hipMalloc((void**)&tabNew, sizeof(long long) * (size_t)tabCap) != hipSuccess)
+        return undo(fail(e, CPQ_ERR_OOM, "plan group tables could not be allocated"));
+    // success: swap
+    for (NativeLayer& o : g.layers) if (o.mem) (void)hipFree(o.mem);
     if (g.chMapDev) (void)hipFree(g.chMapDev);
     if (g.irSlotDev) (void)hipFree(g.irSlotDev);
     if (g.tabDev) (void)hipFree(g.tabDev);
-    g.chMapDev = g.irSlotDev = nullptr;
-    g.tabDev = nullptr;
+    g.layers = fresh;
+    g.chMapDev = chMapNew;
+    g.irSlotDev = irSlotNew;
+    g.tabDev = tabNew;
     g.capCh = newCapCh;
     g.streamOfPair.resize((size_t)capPairs, -1);
-    g.tabCap = tabEntries(e, g);
-    if (hipMalloc((void**)&g.chMapDev, sizeof(int) * newCapCh) != hipSuccess || hipMalloc((void**)&g.irSlotDev, sizeof(int) * newCapCh) != hipSuccess ||
-        hipMalloc((void**)&g.tabDev, sizeof(long long) * (size_t)g.tabCap) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(e, CPQ_ERR_OOM, "plan group tables could not be allocated");
-    }
+    g.tabCap = tabCap;
     return uploadGroupMaps(e, g);
 }
 
@@ -281,6 +299,7 @@ int resetGroups(cpq_engine* e)
                 if (!it.perSlot) CPQ_HIP(e, hipMemsetAsync(*it.ptr, 0, (size_t)(it.rowBytes * g.capCh), e->stream));
         }
         resetGroupHost(g);
+        g.frozen = false;       // resting is processor-level state: the next processor-level call re-establishes it (enqueueConvProc)
     }
     return CPQ_OK;
 }
@@ -342,18 +361,24 @@ static int isolateStream(cpq_engine* e, int stream)
         auto si = layerItems(src), di = layerItems(dst);
         for (size_t i = 0; i < si.size(); ++i) {
             const int64_t rows = 2, from = si[i].perSlot ? (g.shared ? 0 : 2 * pair) : 2 * pair;
-            CPQ_HIP(e, hipMemcpyAsync(*di[i].ptr, (char*)*si[i].ptr + from * si[i].rowBytes, (size_t)(rows * si[i].rowBytes),
-                                      hipMemcpyDeviceToDevice, e->stream));
+            if (hipMemcpyAsync(*di[i].ptr, (char*)*si[i].ptr + from * si[i].rowBytes, (size_t)(rows * si[i].rowBytes),
+                               hipMemcpyDeviceToDevice, e->stream) != hipSuccess) {
+                (void)hipStreamSynchronize(e->stream);
+                freeGroupBuffers(*n);
+                delete n;
+                return fail(e, CPQ_ERR_DEVICE, "plan group rows could not be copied");
+            }
         }
         dst.head = src.head; dst.histSel = src.histSel; dst.accSel = src.accSel; dst.fill = src.fill;
         dst.distributing = src.distributing; dst.nextPart = src.nextPart; dst.wPos = src.wPos; dst.rPos = src.rPos;
     }
     n->streamOfPair[0] = stream;
+    // the stream is the new group's from here on, whatever happens below: the engine stays consistent
     g.streamOfPair[(size_t)pair] = -1;
-    rc = zeroPairState(e, g, pair);
-    if (rc != CPQ_OK) return rc;
     e->groups.push_back(n);
     e->groupOf[(size_t)stream] = (int)e->groups.size() - 1;
+    rc = zeroPairState(e, g, pair);
+    if (rc != CPQ_OK) return rc;
     rc = uploadGroupMaps(e, g);
     if (rc == CPQ_OK) rc = uploadGroupMaps(e, *n);
     return rc;
@@ -372,6 +397,11 @@ int setStreamFrozen(cpq_engine* e, int stream, bool frozen)
     gi = e->groupOf[(size_t)stream];
     e->groups[(size_t)gi]->frozen = frozen;
     return CPQ_OK;
+}
+
+void clearFrozen(cpq_engine* e)
+{
+    for (PlanGroup* g : e->groups) g->frozen = false;
 }
 
 // SetImpulse of one stream (or of all streams with one shared stereo IR) on the reference's own layer plan
@@ -395,7 +425,7 @@ int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double*
         for (size_t i = 0; i < e->groups.size() && !g; ++i) {
             PlanGroup& c = *e->groups[i];
             const bool sameSpec = c.hasSpec == (spec != nullptr) && (!spec || std::memcmp(&c.spec, spec, sizeof(*spec)) == 0);
-            if (!c.shared && c.samplesSinceReset == 0 && sameSpec && std::memcmp(&c.plan, &pl, sizeof(pl)) == 0) { g = &c; gi = (int)i; }
+            if (!c.shared && !c.frozen && c.samplesSinceReset == 0 && sameSpec && std::memcmp(&c.plan, &pl, sizeof(pl)) == 0) { g = &c; gi = (int)i; }     // (a resting group holds one isolated stream: nobody joins it)
         }
     if (!g) {
         g = new (std::nothrow) PlanGroup();
@@ -404,7 +434,7 @@ int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double*
         g->hasSpec = spec != nullptr;
         if (spec) g->spec = *spec;
         g->shared = shared;
-        const int rc = sizeGroup(e, *g, shared ? S : std::min(S, 8));
+        const int rc = sizeGroup(e, *g, shared ? S : 1);       // one pair, doubled as members join: 256 one-member groups (256 IR lengths) cost what they use
         if (rc != CPQ_OK) { freeGroupBuffers(*g); delete g; return rc; }
         e->groups.push_back(g);
         gi = (int)e->groups.size() - 1;
@@ -416,7 +446,7 @@ int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double*
         for (size_t p = 0; p < g->streamOfPair.size() && pair < 0; ++p) if (g->streamOfPair[p] < 0) pair = (int)p;
         if (pair < 0) {
             pair = (int)g->streamOfPair.size();
-            const int rc = sizeGroup(e, *g, std::min(S, std::max(2 * pair, 8)));
+            const int rc = sizeGroup(e, *g, std::min(S, std::max(2 * pair, 2)));
             if (rc != CPQ_OK) return rc;
         }
         g->streamOfPair[(size_t)pair] = s;
@@ -528,7 +558,7 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
-        if (g.frozen) continue;
+        if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
         for (NativeLayer& t : g.layers)
             cpq::launch_rows_gather(e->stream, dIn, n, g.chMapDev, t.acc[t.accSel], t.accCap, t.fill, n, g.usedCh);
     }
@@ -582,7 +612,7 @@ int groupsRunLayer0(cpq_engine* e, double* dOut, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
-        if (g.frozen) continue;
+        if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
         const long long w0 = g.layers[0].wPos;
         replayCall(e, g, n, g.tabHost, g.tabOffs, g.nbOf);
         if ((int)g.tabHost.size() > g.tabCap) return fail(e, CPQ_ERR_INVALID_ARG, "call of %d samples exceeds the engine's call capacity", n);
@@ -605,7 +635,7 @@ int groupsRunTails(cpq_engine* e, double* dOut, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
-        if (g.frozen) continue;
+        if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
         for (size_t l = 1; l < g.layers.size(); ++l) {
             NativeLayer& t = g.layers[l];
             { const int rc = runLayerBlocks(e, g, t, n, g.tabDev + g.tabOffs[2 * l + 1], 0); if (rc != CPQ_OK) return rc; }

@@ -75,6 +75,18 @@ int uploadProcParams(cpq_engine* e)
 int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
 {
     if (!e->procGains) { const int rc = uploadProcParams(e); if (rc != CPQ_OK) return rc; }
+    {
+        // feasibility first, before the ramp replay below consumes samples: resting ONE convolver needs that stream in a plan group
+        const int Sn = e->desc.n_streams;
+        bool allWant = true, anyWant = false;
+        for (int s = 0; s < Sn; ++s) { const bool w = e->procBypass[s] || e->procDryOnly[s]; allWant = allWant && w; anyWant = anyWant || w; }
+        if (anyWant && !allWant)
+            for (int s = 0; s < Sn; ++s)
+                if ((e->procBypass[s] || e->procDryOnly[s]) && e->groupOf[(size_t)s] < 0)
+                    return fail(e, CPQ_ERR_UNSUPPORTED, "stream %d: a per-stream bypass / dry-only needs the stream on the reference's own "
+                                "layer plan (CPQ_CALLS_ANY, CPQ_SCHED_REFERENCE_NUC or a FilterSpec plan with tail layers); on the "
+                                "uniform path set it for CPQ_ALL_STREAMS", s);
+    }
     // mix smoothing: per callback the reference moves the ramp's target to the current mix (:366-371) and, while the ramp
     // is running at the START of a callback, mixes that whole callback with per-sample gains equalPowerSin(getNextValue())
     // (:591-607).  Parameters only change between calls, so the smoothed region is a prefix of the call.
@@ -164,7 +176,9 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
     }
     e->dryPos += n;
     if (!skipConv) {
+        e->honourFrozen = true;               // resting streams: their plan groups and direct heads are not run
         const int rc = enqueueConv(e, dIn, dOut, n);
+        e->honourFrozen = false;
         if (rc != CPQ_OK) return rc;
     }
     // Latency compensation per callback and stream (:263-290): a total latency that moved by >= 2 samples starts, unless
@@ -335,6 +349,7 @@ int32_t cpq_engine_set_conv_level(cpq_engine* e, int32_t level)
 {
     if (!e || (level != CPQ_LEVEL_NUC && level != CPQ_LEVEL_PROCESSOR)) return CPQ_ERR_INVALID_ARG;
     e->convLevel = level;
+    if (level == CPQ_LEVEL_NUC) clearFrozen(e);      // resting a stream is processor-level state
     return CPQ_OK;
 }
 

@@ -139,8 +139,10 @@ void launch_block_silence(hipStream_t stream, const double* x, int64_t chStride,
 void launch_rows_scale(hipStream_t stream, double* data, int64_t stride, int n, int nCh, const double* gain);
 
 // direct head: time-domain FIR of the first <= 32 taps over [history | block] into dout ([nCh][n]); then out += dout
+// wetOn[stream] == 0: that stream's head rests (zero output, history kept)
 void launch_direct_head(hipStream_t stream, const double* in, int64_t inStride, int n, const double* irRev, const int* taps,
-                        const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh);
+                        const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh,
+                        const int* wetOn = nullptr);
 void launch_rows_add(hipStream_t stream, double* out, int64_t outStride, const double* add, int n, int nCh);
 
 }  // namespace cpq

@@ -357,9 +357,15 @@ __global__ __launch_bounds__(256) void k_ring_add_chunks(double* __restrict__ ou
 __global__ __launch_bounds__(256) void k_direct_head(const double* __restrict__ in, int64_t inStride, int n,
                                                      const double* __restrict__ irRev, const int* __restrict__ taps,
                                                      const int* __restrict__ irSlot, const double* __restrict__ histOld,
-                                                     double* __restrict__ histNew, double* __restrict__ dout)
+                                                     double* __restrict__ histNew, double* __restrict__ dout,
+                                                     const int* __restrict__ wetOn)
 {
     const int c = blockIdx.y;
+    if (wetOn && wetOn[c >> 1] == 0) {         // the stream's convolver rests: no output, the history stays as it is
+        for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) dout[(int64_t)c * n + s] = 0.0;
+        if (blockIdx.x == 0 && threadIdx.x < 32) histNew[c * 32 + threadIdx.x] = histOld[c * 32 + threadIdx.x];
+        return;
+    }
     const int slot = irSlot[c];
     const int nt = taps[slot];
     const double* h = irRev + slot * 32;
@@ -598,10 +604,10 @@ void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int
 }
 
 void launch_direct_head(hipStream_t stream, const double* in, int64_t inStride, int n, const double* irRev, const int* taps,
-                        const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh)
+                        const int* irSlot, const double* histOld, double* histNew, double* dout, int nCh, const int* wetOn)
 {
     hipLaunchKernelGGL(k_direct_head, rowsGrid(n, nCh), dim3(256), 0, stream, in, inStride, n, irRev, taps, irSlot, histOld,
-                       histNew, dout);
+                       histNew, dout, wetOn);
 }
 
 void launch_rows_add(hipStream_t stream, double* out, int64_t outStride, const double* add, int n, int nCh)

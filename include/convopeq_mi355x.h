@@ -452,6 +452,18 @@ int32_t     cpq_profile_reset(cpq_engine* e);
 int32_t     cpq_profile_read(cpq_engine* e, int32_t kernel_id, int64_t* launches, double* total_ms);
 const char* cpq_kernel_name(int32_t kernel_id);
 
+/* ---------------------------------------------------------------- diagnostics */
+/* The partition FFT on its own (what replaces ProductionFft::forwardRealToCCS / inverseCCSToR, src/FFTBackend.cpp:123-150,
+ * inside processLayerBlock): for n_channels x n_blocks blocks of `partition` samples (host, [channel][block][sample]; the
+ * history before block 0 is silence) the forward transform of every overlap-save frame [previous block | block]
+ * (2 * partition real points, unscaled) and the inverse transform of those spectra (scaled 1 / (2 * partition)), second half.
+ * spectra: [channel][block][partition][2] in the kernels' own storage order -- element 0 = (DC, Nyquist), both real; element
+ * e = bin e for partition <= 2048; for larger partitions element k1 * 512 + k2 = bin k1 + (partition / 512) * k2.
+ * out: [channel][block][sample], equals the input up to rounding.  partition: a power of two in 64 ... 32768.
+ * Needs a gfx950 device; no engine.  For tests of the FFT kernel families in isolation. */
+int32_t     cpq_diag_partition_fft(int32_t partition, int32_t n_channels, int32_t n_blocks, const double* in,
+                                   double* spectra, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,9 @@ and oracle/_ref are only available there).  Fixtures are DATA (inputs + expected
   eq_params_default_ref.json  a default-constructed convo::EQParameters (src/core/EQParameters.h) via the same probe
   svf_display_biquad_ref.json  the reference's own svfToDisplayBiquad (src/tests/EQProcessorMaxGainTests.cpp:67-87, compiled
                            unmodified via oracle/ref_probe_eqmath.cpp) applied to SVF coefficient sets: the biquad each band IS
+  rbj_biquad_ref.json      the reference's own cookbook designers calcPeakingBiquad / calcLowShelfBiquad / calcHighShelfBiquad
+                           (src/tests/EQBoundExcessBenchmark.cpp:188-245, compiled unmodified via oracle/ref_probe_eqbound.cpp)
+                           over a grid of frequency x gain x Q x sample rate: the responses calcSVFCoeffs aims at
   survey_observations.json hand-transcribed observations of the RUNNING reference recorded in SURVEY.md
                            (section 0 findings 2-4, section 8(a) row A6, section 8(c)); provenance: survey session
   nuc_oracle_vectors.npz   outputs of this repo's oracle for fixed seeded inputs (regression pin of the oracle
@@ -62,6 +65,28 @@ def main():
                              "oracle/ref_probe_eqmath.cpp; svf = a1 a2 a3 m0 m1 m2 (this repo's design, hex doubles), "
                              "biquad = b0 b1 b2 a0 a1 a2 (the reference's equivalent biquad, hex doubles); sample rate 48000",
                    "cases": cases}, f, indent=0)
+
+    # the reference's cookbook designers over a grid (float-representable parameters: the EQ's parameters are floats)
+    rb = []
+    for sr in (44100.0, 48000.0, 96000.0, 192000.0, 384000.0):
+        for btype in (0, 1, 2):
+            for freq in (20.0, 55.0, 200.0, 1000.0, 4000.0, 12000.0, 19000.0):
+                for gain in (-24.0, -9.0, -1.0, 0.5, 6.0, 24.0):
+                    for q in (0.1, 0.5, 0.7071, 1.41, 5.0, 20.0):
+                        if (len(rb) * 7 + int(freq)) % 5:          # a fifth of the grid keeps the fixture small
+                            rb_skip = True
+                        else:
+                            rb_skip = False
+                        f32, g32, q32 = float(np.float32(freq)), float(np.float32(gain)), float(np.float32(q))
+                        if rb_skip and not (sr == 48000.0 and q == 0.7071):
+                            continue
+                        b, a = O.ref_rbj_biquad(btype, f32, g32, q32, sr)
+                        rb.append({"type": btype, "freq": f32, "gain_db": g32, "q": q32, "sr": sr,
+                                   "biquad": [float(v).hex() for v in np.concatenate([b, a])]})
+    with open(os.path.join(HERE, "rbj_biquad_ref.json"), "w") as f:
+        json.dump({"source": "reference src/tests/EQBoundExcessBenchmark.cpp calcLowShelfBiquad (type 0) / calcPeakingBiquad (1) / "
+                             "calcHighShelfBiquad (2) compiled unmodified via oracle/ref_probe_eqbound.cpp; "
+                             "biquad = b0 b1 b2 a0 a1 a2 (hex doubles)", "cases": rb}, f, indent=0)
 
     survey = {
         "source": "SURVEY.md: values observed from the unmodified reference sources running in the survey session",

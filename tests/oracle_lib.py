@@ -154,6 +154,20 @@ def ref_svf_to_display_biquad(svf6):
     return out[:3].copy(), out[3:].copy()
 
 
+def ref_rbj_biquad(btype, freq, gain_db, q, sr):
+    """(b, a) of the reference's own cookbook designers (src/tests/EQBoundExcessBenchmark.cpp:188-245, compiled unmodified via
+    oracle/ref_probe_eqbound.cpp): btype 0 low shelf, 1 peaking, 2 high shelf; or None when the probe lacks them."""
+    R = ref_probe()
+    if R is None or not hasattr(R, "ref_rbj_biquad"):
+        return None
+    R.ref_rbj_biquad.restype = C.c_int
+    R.ref_rbj_biquad.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    out = np.empty(6)
+    if R.ref_rbj_biquad(int(btype), float(freq), float(gain_db), float(q), float(sr), dp(out)) != 0:
+        return None
+    return out[:3].copy(), out[3:].copy()
+
+
 def ref_calc_lpf_svf(freq, q, sr):
     out = np.empty(6)
     ref_probe().ref_calc_lpf_svf(freq, q, sr, dp(out))

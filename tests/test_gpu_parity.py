@@ -226,6 +226,47 @@ def test_svf_band_matches_the_reference_display_biquad(amd, oracle, mode):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["sequential", "auto"])
+def test_svf_band_matches_the_reference_cookbook_biquad(amd, oracle, mode):
+    """External anchor for calcSVFCoeffs' peaking / shelving branches (A14): the reference's own cookbook designers
+    (src/tests/EQBoundExcessBenchmark.cpp:188-245, compiled unmodified; fixture tests/golden/rbj_biquad_ref.json) give the
+    z-domain biquad of a low shelf / peaking / high shelf band.  With saturation 0 one enabled band of the HIP EQ -- designed
+    by the product from the same (float) parameters -- must filter like scipy.signal.lfilter with the reference's biquad.
+    The two are the same transfer function in two forms; what is left is the direct form's own coefficient cancellation
+    (tests/test_ref_eq_math_cpu.py states the measured bounds): <= 2e-9 from 200 Hz up, <= 1e-6 below, at 48 kHz."""
+    import json
+    from scipy.signal import lfilter
+    O = oracle
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rbj_biquad_ref.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["sr"] == 48000.0]
+    assert len(cases) >= 30
+    n = 32 * B
+    x = make_inputs(O, 1, n)
+    eng = amd.BatchedEngine(1, max_ir_len=512, max_blocks_per_call=32)
+    eng.set_eq_mode(amd.CPQ_EQ_MODE_SEQUENTIAL if mode == "sequential" else amd.CPQ_EQ_MODE_AUTO)
+    worst = 0.0
+    for case in cases:
+        p = amd.eq_params_default()
+        for i in range(20):
+            p.bands[i].enabled = 0
+        b0 = p.bands[0]
+        b0.enabled, b0.type, b0.frequency, b0.gain, b0.q, b0.channel_mode = 1, case["type"], case["freq"], case["gain_db"], case["q"], 0
+        p.nonlinear_saturation = 0.0
+        p.total_gain_db = 0.0
+        eng.set_eq_params(amd.CPQ_ALL_STREAMS, p)
+        eng.eq_reset()
+        y = eng.eq_process(x)
+        bq = np.array([float.fromhex(v) for v in case["biquad"]])
+        tol = 2e-9 if case["freq"] >= 200.0 else 1e-6
+        for c in range(2):
+            ref = lfilter(bq[:3] / bq[3], bq[3:] / bq[3], x[c])
+            err = np.abs(y[c] - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, err)
+            assert err <= tol, (case["type"], case["freq"], case["gain_db"], case["q"], err)
+    print("SVF band vs the reference's cookbook biquad,", mode, "kernel: worst relative error", worst)
+    eng.close()
+
+
 def test_conv_then_eq_whole_path(amd, oracle):
     O = oracle
     S = 2
@@ -1189,6 +1230,36 @@ def test_ingested_ir_file_end_to_end(amd, oracle):
         worst = max(worst, rms(y[c] - ref) / max(rms(ref), 1e-30))
     assert worst <= 1e-12, worst
     eng.close()
+
+
+def test_long_ingested_ir_three_layers_end_to_end(amd, oracle):
+    """The reference's 20 s sample IR (sampledata/synthetic_long_ir_20s.wav, fixture tests/golden/) through cpq_ir_load_wav ->
+    cpq_ir_prepare (10 s target: 480000 taps) -> set_impulse(scale factor) at 512-sample blocks -- the reference's
+    three-layer plan (512 / 4096 / 32768, src/MKLNonUniformConvolver.cpp:738-758) with its tail gains and lags -> kernel-level
+    process of 300000 samples (past the start of the third layer), against the oracle's stateful emulation on the same
+    prepared IR."""
+    O = oracle
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic_long_ir_20s.wav")
+    ir, rate = amd.ir_load_wav(path)
+    prep = amd.ir_prepare(ir, rate, 48000.0, 10.0)
+    h, sf = prep["ir"], prep["scale"]["scale_factor"]
+    assert h.shape == (2, 480000) and 0.0 < sf < 10.0
+    plan = amd.nuc_plan(480000, B)
+    assert plan.num_layers == 3 and [plan.part_size[l] for l in range(3)] == [512, 4096, 32768]
+    S, T = 1, 64
+    calls = 10                                           # 327680 samples
+    x = make_inputs(O, S, calls * T * B)
+    eng = amd.BatchedEngine(S, max_ir_len=480000, max_blocks_per_call=T)
+    eng.set_impulse(0, h[0], h[1], scale=sf)
+    y = np.concatenate([eng.conv_process(x[:, k * T * B:(k + 1) * T * B]) for k in range(calls)], axis=1)
+    eng.close()
+    for c in range(2):
+        nuc = O.Nuc()
+        assert nuc.set_impulse(h[c], B, scale=sf)
+        ref = nuc.run(x[c], B)
+        nuc.close()
+        assert rms(y[c] - ref) <= 1e-12 * max(1.0, rms(ref)), (c, rms(y[c] - ref), rms(ref))
+        assert rms(ref[300000:]) > 0.0
 
 
 @pytest.mark.parametrize("block,agc,eq_mode", [(512, False, "seq"), (512, False, "auto"), (64, False, "seq"), (512, True, "seq")])

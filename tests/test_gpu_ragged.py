@@ -195,12 +195,14 @@ def test_whole_block_engine_refuses_ragged_calls_loudly(amd, oracle):
     eng.close()
 
 
-def test_per_stream_bypass_rests_one_convolver(amd, oracle):
+@pytest.mark.parametrize("direct", [False, True])
+def test_per_stream_bypass_rests_one_convolver(amd, oracle, direct):
     """ConvolverProcessor bypass of ONE stream (src/convolver/ConvolverProcessor.Runtime.cpp:123-186): its output is the
     delayed dry signal and its convolver is not called -- the NUC keeps the state it had and resumes with it on release --
     while the other streams go on.  Processor level, three streams with their own IRs, the middle one bypassed for two
     calls and released again.  (Dry-only, mix <= 0.001, rests the convolver through the same mechanism once its mix ramp
-    has ended.)"""
+    has ended.)  direct: with the direct head, whose history must rest too (processDirectBlock sits inside Add(),
+    src/MKLNonUniformConvolver.cpp:1407-1430): the first headTaps - 1 samples after a release show it."""
     O = oracle
     L = O.lib()
     quantum, T, taps, S = 512, 8, 20000, 3
@@ -211,7 +213,7 @@ def test_per_stream_bypass_rests_one_convolver(amd, oracle):
     x = make_inputs(O, range(30, 30 + S), n)
     eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=T, call_mode=amd.CPQ_CALLS_ANY)
     for s in range(S):
-        eng.set_impulse(s, irs[s][0], irs[s][1])
+        eng.set_impulse(s, irs[s][0], irs[s][1], direct_head=direct)
     eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=1.0)
     ys = []
     for c, m in enumerate(mode):
@@ -222,9 +224,11 @@ def test_per_stream_bypass_rests_one_convolver(amd, oracle):
     for s in range(S):
         for ch in range(2):
             xc = x[2 * s + ch]
-            dry = np.concatenate([np.zeros(quantum), xc[:-quantum]])
+            # the delayed dry signal: algorithm latency = layer-0 partition, or 0 with the direct head (Runtime.cpp:266; the
+            # start-up cross-fade from block + irLatency is over long before the first bypassed call)
+            dry = xc if direct else np.concatenate([np.zeros(quantum), xc[:-quantum]])
             nuc = O.Nuc()
-            assert nuc.set_impulse(irs[s][ch], quantum)
+            assert nuc.set_impulse(irs[s][ch], quantum, direct=direct)
             ref = np.empty(n)
             for c, m in enumerate(mode):
                 seg = slice(c * n_call, (c + 1) * n_call)
@@ -234,6 +238,37 @@ def test_per_stream_bypass_rests_one_convolver(amd, oracle):
                     ref[seg] = nuc.run(xc[seg], quantum) * wet_g
             nuc.close()
             assert rms(y[2 * s + ch] - ref) <= 1e-13, (s, ch)
+    eng.close()
+
+
+def test_nuc_level_call_runs_a_stream_that_rested_at_processor_level(amd, oracle):
+    """Resting a convolver is processor-level state (ConvolverProcessor::process decides not to call its NUC).  A call at the
+    kernel level -- the NUC's own Add / Get -- after a per-stream bypass runs every stream, the formerly resting one from
+    the state it kept."""
+    O = oracle
+    quantum, T, taps, S = 512, 4, 9000, 2
+    n_call = T * quantum
+    irs = [[O.gen_ir(taps, stream=60 + s, channel=ch) for ch in range(2)] for s in range(S)]
+    x = make_inputs(O, range(60, 60 + S), 3 * n_call)
+    eng = amd.BatchedEngine(S, block_size=quantum, max_ir_len=taps, max_blocks_per_call=T, call_mode=amd.CPQ_CALLS_ANY)
+    for s in range(S):
+        eng.set_impulse(s, irs[s][0], irs[s][1])
+    eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=1.0)
+    y0 = eng.convproc_process(np.ascontiguousarray(x[:, :n_call]))                 # both streams run
+    eng.set_convproc_params(1, mix=1.0, bypassed=True)
+    eng.convproc_process(np.ascontiguousarray(x[:, n_call:2 * n_call]))             # stream 1 rests (its NUC sees nothing)
+    y2 = eng.conv_process(np.ascontiguousarray(x[:, 2 * n_call:]))                  # kernel level: everybody runs
+    assert y0.shape == y2.shape
+    for s in range(S):
+        for ch in range(2):
+            nuc = O.Nuc()
+            assert nuc.set_impulse(irs[s][ch], quantum)
+            nuc.run(x[2 * s + ch, :n_call], quantum)
+            if s == 0:
+                nuc.run(x[2 * s + ch, n_call:2 * n_call], quantum)
+            ref = nuc.run(x[2 * s + ch, 2 * n_call:], quantum)
+            nuc.close()
+            assert rms(y2[2 * s + ch] - ref) <= 1e-13, (s, ch)
     eng.close()
 
 

@@ -251,6 +251,27 @@ def test_prepare_matches_oracle_on_the_sample_ir(amd, O):
     assert 0 < got["scale"]["scale_factor"] and got["scale"]["has_scale_factor"]
 
 
+LONG_IR = os.path.join(HERE, "golden", "synthetic_long_ir_20s.wav")   # the reference's 20 s sample IR (stereo, 16-bit, 48 kHz)
+
+
+def test_long_sample_ir_decodes_and_prepares_like_the_restatement(amd, O):
+    """The reference's sampledata/synthetic_long_ir_20s.wav (960000 frames): 16-bit PCM decoding bit-identical to the
+    restatement and to scipy's reader; conditioned to 10 s (480000 taps: a three-layer plan at 512-sample blocks) like the
+    restatement."""
+    rate, data = wavfile.read(LONG_IR)
+    got, r = amd.ir_load_wav(LONG_IR)
+    ref, r2 = O.load_wav(LONG_IR)
+    assert r == r2 == rate == 48000 and got.shape == ref.shape == (2, 960000) and data.dtype == np.int16
+    assert np.array_equal(got, ref)
+    fixed = (data.astype(np.int64) << 16).astype(np.int32).astype(np.float32) * (np.float32(1.0) / np.float32(0x7FFFFFFF))
+    assert np.array_equal(got, np.clip(fixed.T.astype(np.float64), -1, 1))
+    p, q = amd.ir_prepare(got, r, 48000.0, 10.0), O.prepare(ref, r2, 48000.0, 10.0)
+    assert p["ir"].shape == q["ir"].shape == (2, 480000)
+    assert np.abs(p["ir"] - q["ir"]).max() <= 1e-15
+    scale_close(p["scale"], q["scale"])
+    assert p["ir_peak_latency"] == q["ir_peak_latency"]
+
+
 def test_prepare_variants_and_errors(amd, O):
     rng = np.random.default_rng(8)
     t = np.arange(30000, dtype=np.float64)

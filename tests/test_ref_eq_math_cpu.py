@@ -96,3 +96,63 @@ def test_fixture_cases_are_the_products_designs():
         c = _capi.SvfCoeffs()
         assert lib.cpq_eq_design_svf(case["type"], case["freq"], case["gain_db"], case["q"], 48000.0, C.byref(c)) == 0
         assert [float(v).hex() for v in (c.a1, c.a2, c.a3, c.m0, c.m1, c.m2)] == case["svf"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's cookbook designers (src/tests/EQBoundExcessBenchmark.cpp:188-245, compiled unmodified via
+# oracle/ref_probe_eqbound.cpp; fixture tests/golden/rbj_biquad_ref.json): peaking / low shelf / high shelf as z-domain
+# biquads.  calcSVFCoeffs (EQProcessor.Coefficients.cpp:431-560) designs the SAME transfer functions in TPT-SVF form -- both
+# are the bilinear transform of the cookbook's analog prototypes, pre-warped at the band frequency -- so the product's
+# designSvf, read back through the band's state-space form, must have the response of the reference's biquad.  Measured over
+# the grid (20 Hz ... 19 kHz, +-24 dB, Q 0.1 ... 20, 44.1 ... 384 kHz): relative response deviation <= 2.5e-7, all of it the
+# cookbook form's own cancellation at 20 ... 55 Hz against 192 / 384 kHz (1 - cos w0); <= 2e-10 from 200 Hz up at <= 96 kHz.
+def _svf_response(c, w):
+    """H(e^jw) of the TPT-SVF band with coefficients c = (a1, a2, a3, m0, m1, m2): state (ic1, ic2), input v0."""
+    a1, a2, a3, m0, m1, m2 = c
+    A = np.array([[2 * a1 - 1, -2 * a2], [2 * a2, 1 - 2 * a3]])
+    Bv = np.array([2 * a2, 2 * a3])
+    Cv = np.array([m1 * a1 + m2 * a2, -m1 * a2 + m2 * (1 - a3)])
+    D = m0 + m1 * a2 + m2 * a3
+    z = np.exp(1j * w)
+    det = (z - A[0, 0]) * (z - A[1, 1]) - A[0, 1] * A[1, 0]
+    inv_b0 = ((z - A[1, 1]) * Bv[0] + A[0, 1] * Bv[1]) / det
+    inv_b1 = (A[1, 0] * Bv[0] + (z - A[0, 0]) * Bv[1]) / det
+    return D + Cv[0] * inv_b0 + Cv[1] * inv_b1
+
+
+def _load_rbj_cases():
+    with open(os.path.join(HERE, "golden", "rbj_biquad_ref.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_rbj_fixture_matches_the_probe(oracle):
+    if oracle.ref_rbj_biquad(1, 1000.0, 6.0, 0.707, 48000.0) is None:
+        pytest.skip("oracle/_ref probe of the reference's EQ bound benchmark not available")
+    for case in _load_rbj_cases():
+        b, a = oracle.ref_rbj_biquad(case["type"], case["freq"], case["gain_db"], case["q"], case["sr"])
+        assert [v.hex() for v in np.concatenate([b, a])] == case["biquad"]
+
+
+def test_shelf_and_peaking_designs_have_the_response_of_the_references_cookbook_biquads(oracle):
+    """designSvf (product) and orc_svf_design (oracle), low shelf / peaking / high shelf, against the reference's designers."""
+    import ctypes as C
+    from convopeq_amd import _capi
+    lib = _capi.load()
+    worst, worst_mid = 0.0, 0.0
+    for case in _load_rbj_cases():
+        bq = np.array([float.fromhex(v) for v in case["biquad"]])
+        sr = case["sr"]
+        w = np.geomspace(2 * np.pi * 10.0 / sr, np.pi * 0.999, 300)
+        zi = np.exp(-1j * w)
+        h_ref = (bq[0] + bq[1] * zi + bq[2] * zi * zi) / (bq[3] + bq[4] * zi + bq[5] * zi * zi)
+        c = _capi.SvfCoeffs()
+        assert lib.cpq_eq_design_svf(case["type"], case["freq"], case["gain_db"], case["q"], sr, C.byref(c)) == 0
+        o = oracle.svf_design(case["type"], case["freq"], case["gain_db"], case["q"], sr)
+        assert [c.a1, c.a2, c.a3, c.m0, c.m1, c.m2] == [o.a1, o.a2, o.a3, o.m0, o.m1, o.m2]      # product == oracle, bit for bit
+        h = _svf_response((c.a1, c.a2, c.a3, c.m0, c.m1, c.m2), w)
+        dev = float(np.max(np.abs(h - h_ref) / np.abs(h_ref)))
+        worst = max(worst, dev)
+        if case["freq"] >= 200.0 and sr <= 96000.0:
+            worst_mid = max(worst_mid, dev)
+    assert worst <= 1e-6, worst
+    assert worst_mid <= 1e-9, worst_mid
