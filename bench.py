@@ -356,7 +356,7 @@ def rank_layout(args, env, device_count):
     return rank, local_rank, world, local_rank
 
 
-def timed_steps(step, sync, dist, steps, warmup, after_warmup=None):
+def timed_steps(step, sync, dist, steps, warmup, after_warmup=None, extra=None):
     """The timing contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + device synchronise on
     both sides.  Returns (this rank's own time to its last step, time to the closing barrier)."""
     for _ in range(warmup):
@@ -370,6 +370,8 @@ def timed_steps(step, sync, dist, steps, warmup, after_warmup=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if extra is not None:
+        extra["enqueue_s"] = time.perf_counter() - t0      # host time to enqueue the K steps (before the device has finished them)
     sync()
     mine = time.perf_counter() - t0
     if dist is not None:
@@ -436,6 +438,9 @@ def parse_args(argv=None):
     ap.add_argument("--schedule", choices=["uniform", "nuc"], default="uniform",
                     help="uniform: one partition size for the whole h_eff (headline, HBM-roofline path); nuc: the reference's "
                          "own non-uniform schedule run natively (BASELINE.json configs[3])")
+    ap.add_argument("--call-mode", choices=["blocks", "any"], default="blocks",
+                    help="blocks: calls of whole power-of-two blocks (CPQ_CALLS_WHOLE_BLOCKS); any: CPQ_CALLS_ANY -- --block is then "
+                         "the call quantum (480, 441 ...), the reference's Add / Get are reproduced chunk by chunk (plan groups)")
     ap.add_argument("--exact", action="store_true", help="plain linear convolution instead of reference h_eff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -485,7 +490,8 @@ def main():
     eng = amd.BatchedEngine(S, block_size=B, max_ir_len=L, max_blocks_per_call=T,
                             semantics=amd.CPQ_SEM_EXACT if args.exact else amd.CPQ_SEM_REFERENCE,
                             device=dev_index, mac_tile=args.mac_tile, partition_size=args.partition,
-                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if args.schedule == "nuc" else amd.CPQ_SCHED_UNIFORM)
+                            schedule=amd.CPQ_SCHED_REFERENCE_NUC if args.schedule == "nuc" else amd.CPQ_SCHED_UNIFORM,
+                            call_mode=amd.CPQ_CALLS_ANY if args.call_mode == "any" else amd.CPQ_CALLS_WHOLE_BLOCKS)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
 
@@ -536,14 +542,15 @@ def main():
         eng.profile_enable(True)        # pre-creates the event pool: no hipEventCreate inside the timed region
         eng.profile_reset()
 
-    my_elapsed, elapsed = timed_steps(step, torch.cuda.synchronize, dist, args.steps, args.warmup, start_profile)
+    host_side = {}
+    my_elapsed, elapsed = timed_steps(step, torch.cuda.synchronize, dist, args.steps, args.warmup, start_profile, host_side)
     prof = eng.profile_read()
 
     # The same MAC path with ONE partition per call (the reference's own call pattern): every FDL and IR row is
     # streamed for a single output row, so the kernel is HBM-bound there, whereas at T blocks per call it is past the
     # fp64 ridge.  Measured after the timed region (not part of `value`) to give the roofline object both regimes.
     prof1 = None
-    if not (args.eq_only or args.host_buffers or args.schedule == "nuc") and rank == 0:
+    if not (args.eq_only or args.host_buffers or args.schedule == "nuc" or args.call_mode == "any") and rank == 0:
         P1 = P
         eng.profile_reset()
         for _ in range(40):
@@ -702,6 +709,12 @@ def main():
             "roofline": roof,
             "kernels": per_kernel,
             "kernels_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof.items()},
+            # streaming diagnostics: kernel scopes the engine enqueued per step (a scope = one kernel family of one stage; the
+            # plan groups launch several kernels per scope) and the host time of one enqueue (includes the host replay of the
+            # reference's Add / Get bookkeeping under CPQ_CALLS_ANY / the native schedule)
+            "kernel_scopes_per_step": round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 2),
+            "host_enqueue_us_per_step": round(host_side.get("enqueue_s", 0.0) / max(args.steps, 1) * 1e6, 1),
+            "call_mode": args.call_mode,
             "setup_s": round(setup_s, 2),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -17,6 +17,9 @@
 // This file is compiled with -ffp-contract=off: fused operations appear only where written as fma().
 #include "kernels.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace cpq {
 
 namespace {
@@ -762,6 +765,7 @@ __device__ __forceinline__ void tpv_chain_get(const TpvChainSlot* s, double& sx,
 #define CPQ_TPV_PEAK 1
 #endif
 constexpr int kTpvSpan = 8 * 1024;      // samples per span of the eight-wave kernel
+constexpr unsigned kTpvApplyGain = 1u << 31;      // bandFilter bit: this launch applies the channel's output gain (the last stage)
 constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
 constexpr int kTpvGuardPiece = 2048;    // samples per staged piece of the guarded path
 
@@ -986,7 +990,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
                                                                               double* __restrict__ state,
                                                                               const TpBandTables* __restrict__ tables,
                                                                               TpvChainSlot* chain, int chainSpans,
-                                                                              unsigned long long ticket)
+                                                                              unsigned long long ticket, unsigned bandFilter)
 {
     constexpr int kMaxWaves = WAVES ? WAVES : 7;
     constexpr int kNT = WAVES * 64;                           // 0: blockDim.x
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
     const int spanLen = nThreads * 16;
     const double* __restrict__ cf = coef + (int64_t)c * kBands * 6;
     const TpBandTables* __restrict__ tb = tables + (int64_t)(c >> 1) * kBands;
-    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
+    const double sat = satGain[c * 2], gain = (bandFilter & kTpvApplyGain) ? satGain[c * 2 + 1] : 1.0;
     const bool chained = nGroups > 1;
     TpvChainSlot* chainCh = chain + (int64_t)c * chainSpans * kBands;
     const double* inCh = in + (int64_t)c * chStride;
@@ -1006,7 +1010,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
     unsigned long long kinds = 0;                             // 2 bits per band: 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
     for (int b = 0; b < kBands; ++b) {
         const int f = flags[c * kBands + b];
-        activeMask |= (unsigned)(f & 1) << b;
+        activeMask |= ((unsigned)(f & 1) << b) & bandFilter;      // bandFilter: the bands of this launch (band-pipelined stages)
         kinds |= (unsigned long long)((f >> 1) & 3) << (2 * b);
     }
     // DF-II-T sections; SVF bands with the scalar fastTanh; SVF bands whose output is v0 + m1 v1 (every peaking band)
@@ -1105,8 +1109,9 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
     __syncthreads();
     // the call's end states: from the workgroup that ran the last span.  In sState, except after a chained fast span:
     // there the active bands' are in sNext (inactive bands keep their state)
-    if (nSpans > 0 && (nSpans - 1) % nGroups == grp && tid < kBands * 2)
-        state[(int64_t)c * kBands * 2 + tid] = (chained && !slow && ((activeMask >> (tid >> 1)) & 1)) ? sNext[tid] : sState[tid];
+    // (only this launch's bands are written: another stage may be running the other bands of the channel right now)
+    if (nSpans > 0 && (nSpans - 1) % nGroups == grp && tid < kBands * 2 && ((activeMask >> (tid >> 1)) & 1))
+        state[(int64_t)c * kBands * 2 + tid] = (chained && !slow) ? sNext[tid] : sState[tid];
 }
 
 }  // namespace
@@ -1129,6 +1134,40 @@ size_t svf_chain_bytes(int nCh, int maxSamples)
 {
     return (size_t)nCh * (size_t)(maxSamples / kTpvSpan + 1) * kBands * sizeof(TpvChainSlot);
 }
+
+namespace {
+// Band-pipelined stages for engines whose channels alone do not fill the chip: the 20 bands are dealt to G stages, the
+// call's whole spans to N time slices, and stage g works on slice i while stage g - 1 is already on slice i + 1 -- each
+// stage a launch of its own (one workgroup per channel, `bandFilter` = its bands) on a stream of its own, ordered by
+// events: stage g of slice i behind stage g - 1 of slice i and behind stage g of slice i - 1 (same stream).  A channel's
+// band states never leave the chip's memory model: stage g owns its bands' rows of `state` and its slices run in order.
+// (N + G - 1) / (N G) of the single-stage time.  The alternative that keeps one launch -- several workgroups per channel
+// handing the band states over per band -- costs a device-scope release / acquire per band and measured slower
+// (profiles/r03b_eq_chained_spans.txt).
+struct StagePipe {
+    static constexpr int kMaxStages = 4, kMaxSlices = 16;
+    hipStream_t side[kMaxStages - 1] = {};
+    hipEvent_t done[kMaxStages][kMaxSlices] = {};
+    hipEvent_t fork = nullptr;
+    bool ok = false;
+};
+StagePipe* stagePipe()
+{
+    static StagePipe pipes[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    StagePipe& p = pipes[dev];
+    if (!p.ok) {
+        bool good = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+        for (int g = 0; g < StagePipe::kMaxStages - 1 && good; ++g) good = hipStreamCreateWithFlags(&p.side[g], hipStreamNonBlocking) == hipSuccess;
+        for (int g = 0; g < StagePipe::kMaxStages && good; ++g)
+            for (int i = 0; i < StagePipe::kMaxSlices && good; ++i) good = hipEventCreateWithFlags(&p.done[g][i], hipEventDisableTiming) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); return nullptr; }
+        p.ok = true;
+    }
+    return &p;
+}
+}  // namespace
 
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
                            const double* coef, const int* flags, const double* satGain, double* state,
@@ -1160,14 +1199,47 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
             if (nGroups < 2) nGroups = 1;
         }
         const unsigned long long tk = ticket ? ++*ticket : 0ull;
-        hipLaunchKernelGGL(k_svf_cascade_tpv<8>, dim3(nCh * nGroups), dim3(512), 0, stream, in, out, chStride, nSpans8, nGroups,
-                           coef, flags, satGain, state, tb, reinterpret_cast<TpvChainSlot*>(chain), chainSpans, tk);
+        // at most half as many channels as CUs: band-pipelined stages (above).  One workgroup alone on a CU already runs at
+        // ~85 % of the rate of two sharing it, so with more channels than that there is nothing to gain.
+        static int envStages = -1, envSlices = 0;      // experiments: CPQ_SVF_STAGES=G,N
+        if (envStages < 0) {
+            envStages = 0;
+            if (const char* f = getenv("CPQ_SVF_STAGES")) { envStages = atoi(f); if (const char* c = strchr(f, ',')) envSlices = atoi(c + 1); }
+        }
+        int nStages = (nGroups == 1 && 2 * nCh <= nCu && nSpans8 >= 16) ? 4 : 1;      // 4 stages x 16 slices measured best (profiles/r03d_eq_stage_sweep.txt)
+        if (envStages > 0 && nGroups == 1 && nSpans8 >= envStages) nStages = envStages > StagePipe::kMaxStages ? StagePipe::kMaxStages : envStages;
+        StagePipe* pipe = nStages > 1 ? stagePipe() : nullptr;
+        if (pipe) {
+            int nSlices = envSlices > 0 ? envSlices : 16;
+            if (nSlices > StagePipe::kMaxSlices) nSlices = StagePipe::kMaxSlices;
+            if (nSlices > nSpans8) nSlices = nSpans8;
+            const int bandsPerStage = kBands / nStages;
+            (void)hipEventRecord(pipe->fork, stream);
+            for (int g = 1; g < nStages; ++g) (void)hipStreamWaitEvent(pipe->side[g - 1], pipe->fork, 0);
+            for (int i = 0; i < nSlices; ++i) {
+                const int sp0 = (int)((long long)nSpans8 * i / nSlices), sp1 = (int)((long long)nSpans8 * (i + 1) / nSlices);
+                for (int g = 0; g < nStages; ++g) {
+                    hipStream_t st = g == 0 ? stream : pipe->side[g - 1];
+                    if (g > 0) (void)hipStreamWaitEvent(st, pipe->done[g - 1][i], 0);
+                    const unsigned filter = (((1u << bandsPerStage) - 1u) << (g * bandsPerStage)) | (g == nStages - 1 ? kTpvApplyGain : 0u);      // the channel gain goes on once, behind the last band
+                    // stage 0 reads the call's input, the later stages what the stage before left in `out`
+                    const double* src = (g == 0 ? in : out) + (int64_t)sp0 * kTpvSpan;
+                    hipLaunchKernelGGL(k_svf_cascade_tpv<8>, dim3(nCh), dim3(512), 0, st, src, out + (int64_t)sp0 * kTpvSpan, chStride,
+                                       sp1 - sp0, 1, coef, flags, satGain, state, tb, (TpvChainSlot*)nullptr, 0, 0ull, filter);
+                    (void)hipEventRecord(pipe->done[g][i], st);
+                }
+            }
+            for (int g = 1; g < nStages; ++g) (void)hipStreamWaitEvent(stream, pipe->done[g][nSlices - 1], 0);
+        } else {
+            hipLaunchKernelGGL(k_svf_cascade_tpv<8>, dim3(nCh * nGroups), dim3(512), 0, stream, in, out, chStride, nSpans8, nGroups,
+                               coef, flags, satGain, state, tb, reinterpret_cast<TpvChainSlot*>(chain), chainSpans, tk, 0xFFFFFu | kTpvApplyGain);
+        }
         done = nSpans8 * kTpvSpan;
     }
     const int nWaves = (nSamples - done) / 1024;
     if (nWaves > 0) {
         hipLaunchKernelGGL(k_svf_cascade_tpv<0>, dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, 1,
-                           coef, flags, satGain, state, tb, (TpvChainSlot*)nullptr, 0, 0ull);
+                           coef, flags, satGain, state, tb, (TpvChainSlot*)nullptr, 0, 0ull, 0xFFFFFu | kTpvApplyGain);
         done += nWaves * 1024;
     }
     if (nSamples > done)

@@ -122,3 +122,31 @@ def test_bench_self_launches_two_ranks_and_reduces(tmp_path):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r2.stderr + r2.stdout)
+
+
+def test_bench_under_the_drivers_launcher_at_eight_ranks():
+    """The launch the driver uses for the scaling run -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 ... bench.py --gpus 8` -- with --stub-step (gloo, no GPU): eight ranks, one JSON line from rank
+    0, rank-major disjoint stream shards, whole-job counters over the MAX elapsed time."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--stub-step",
+                        "--steps", "3", "--warmup", "1", "--streams", "4", "--blocks-per-call", "16"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-1000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["first_stream_of_rank"] == [0, 4, 8, 12, 16, 20, 24, 28]
+    total = 8 * 4 * 16 * 512 * 3
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 3 - total) / total < 1e-3
+    assert len(d["per_rank"]["samples_per_s_mega"]) == 8
+    assert d["ms_per_step"] >= 8.0                       # rank 7 sleeps 8 ms per step: the job's time is the slowest rank's
