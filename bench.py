@@ -308,7 +308,7 @@ def load_pmc_traffic(path, kernel, running):
     # the profiler id k_fdl_mac covers the workgroup-cooperative variant of long calls (k_fdl_mac_wg in rocprof names)
     # and the register-tile variants of short ones (k_fdl_mac<TT, PF>, summarised as "k_fdl_mac")
     names = {"k_fdl_mac": ["k_fdl_mac_wg", "k_fdl_mac"], "k_fdl_mac:tile": ["k_fdl_mac"],
-             "k_svf_cascade_tp": ["k_svf_cascade_tp8", "k_svf_cascade_tp"]}.get(kernel, [kernel])
+             "k_svf_cascade_tp": ["k_svf_cascade_tpv", "k_svf_cascade_tp8", "k_svf_cascade_tp"]}.get(kernel, [kernel])
     for nme in names:
         if nme in d and isinstance(d[nme], dict):
             src["match"] = True
@@ -587,14 +587,24 @@ def main():
         else:
             layers = [(P, k_parts, Tp)]
         ir_mult = 2 if args.shared_ir else n_ch
+        # time-varying plans under reference semantics (a tail partition longer than the IR before it: blocks >= 1024 at the
+        # defaults) run in layered mode on the uniform grid: one forward FFT, then per layer a MAC over that layer's partitions
+        # and an inverse FFT, and the replayed delay-line reader (k_tail_*: reads every tail layer's output, writes and reads
+        # its ring, read-modify-writes the call's output)
+        n_tail = plan.num_layers - 1
+        layered = (args.schedule == "uniform" and not args.exact and args.call_mode == "blocks" and
+                   any(plan.part_size[l] > plan.output_delay[l] for l in range(1, plan.num_layers)))
+        mac_layers = [(P, (plan.len[l] + P - 1) // P, Tp) for l in range(plan.num_layers)] if layered else layers
         alg_bytes = {      # per STEP; one launch per step and kernel under the uniform schedule
             "k_rfft_fwd_ols": sum(n_ch * nb * (pl * 8 + pl * 16) for pl, _, nb in layers),
-            "k_fdl_mac": sum((n_ch * (kl + nb - 1) + ir_mult * kl + n_ch * nb) * pl * 16 for pl, kl, nb in layers),
-            "k_fdl_mac_dcnyq": sum(n_ch * (kl + nb - 1 + nb) * 16 + ir_mult * kl * 16 for pl, kl, nb in layers),
-            "k_rfft_inv_ols": sum(n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb in layers),
+            "k_fdl_mac": sum((n_ch * (kl + nb - 1) + ir_mult * kl + n_ch * nb) * pl * 16 for pl, kl, nb in mac_layers),
+            "k_fdl_mac_dcnyq": sum(n_ch * (kl + nb - 1 + nb) * 16 + ir_mult * kl * 16 for pl, kl, nb in mac_layers),
+            "k_rfft_inv_ols": sum(n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb in mac_layers),
             "k_svf_cascade_tp": n_ch * n * 16,
             "k_svf_cascade": n_ch * n * 16,
-            "k_convproc_mix": n_ch * n * 16 * max(0, len(layers) - 1),      # delay-line write / read-add of the tail layers
+            # native schedule: delay-line write / read-add of the tail layers; layered mode: per tail layer its output read,
+            # ring written and read (24 B per sample) + the call's output read and written
+            "k_convproc_mix": n_ch * n * (24 * n_tail + 16) if layered else n_ch * n * 16 * max(0, len(layers) - 1),
         }
         # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF: the reference's band kernel is 17 flops of linear
         # recurrence (10 instructions, 7 of them FMAs) + 16 of output stage (fastTanh blend with one division counted as one,
@@ -602,7 +612,7 @@ def main():
         # the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex MAC (Gauss), the tile kernels 4
         mac_flop = lambda nb: 6.0 if nb >= 48 else 8.0
         n_bands = 20 if args.eq_preset == "bench" else len(load_autoeq_preset()["filters"])
-        alg_flops = {"k_fdl_mac": sum(mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb in layers),
+        alg_flops = {"k_fdl_mac": sum(mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb in mac_layers),
                      "k_svf_cascade_tp": 33.0 * n_bands * n_ch * n}
         per_kernel = {}
         for name, (cnt, ms) in prof.items():

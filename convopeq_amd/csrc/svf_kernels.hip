@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     __shared__ double buf[kTpChunks * kTpStride];
     __shared__ TpLds L;
     __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];     // start / end states of the current span (swapped per span)
-    __shared__ double wtot[2 * 2 * kTpWaves];                        // wave totals, two parities
+    __shared__ __align__(16) double wtot[2 * 2 * kTpWaves];         // wave totals, two parities
     double* sState = sStateA;
     double* sNext = sStateB;
     __shared__ int sFlag;
@@ -764,6 +764,9 @@ __device__ __forceinline__ void tpv_chain_get(const TpvChainSlot* s, double& sx,
 #ifndef CPQ_TPV_PEAK
 #define CPQ_TPV_PEAK 1
 #endif
+#ifndef CPQ_TPV_PREFETCH
+#define CPQ_TPV_PREFETCH 0      // bands before the end of a span at which the next span is requested into L2; 0 = never: it buys 2.5 % of the kernel time for 1.35 ... 1.56 x the HBM traffic (profiles/r03e_ab_eq_prefetch.txt)
+#endif
 constexpr int kTpvSpan = 8 * 1024;      // samples per span of the eight-wave kernel
 constexpr unsigned kTpvApplyGain = 1u << 31;      // bandFilter bit: this launch applies the channel's output gain (the last stage)
 constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
@@ -779,7 +782,7 @@ struct TpvShared {
     alignas(16) double M[kBands][28];                          // Mk[6][4], Mw[4] of every band (scan)
     alignas(16) double E[kBands][16][2];                       // (A^(15-k) B)_x, _y: end state of a chunk's zero-state run
     double stateA[kBands * 2], stateB[kBands * 2];
-    double wtot[2 * 2 * MAXW];
+    alignas(16) double wtot[2 * 2 * MAXW];
     int flag;
     int bandBad[kBands];
 };
@@ -951,7 +954,7 @@ struct TpvChain { const TpvChainSlot* prev; TpvChainSlot* cur; unsigned long lon
 template <int CLS, bool SAT, int NT, class SH>
 __device__ __forceinline__ bool tpv_band_run(double (&x)[16], double& e0, double& e1, int& par, unsigned run, unsigned rest,
                                              unsigned monoMask, SH& sh, double* sState, double* sNext, const double* __restrict__ cf,
-                                             double sat, const TpvChain& ch, unsigned& skipPub, int tid, int nThreads)
+                                             double sat, const TpvChain& ch, unsigned& skipPub, int tid, int nThreads, const double* prefetch)
 {
     const double oneMinusSat = 1.0 - sat;
     const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
@@ -962,6 +965,10 @@ __device__ __forceinline__ bool tpv_band_run(double (&x)[16], double& e0, double
         const int b = __builtin_ctz(run);
         run &= run - 1;
         const int nb = run ? __builtin_ctz(run) : (rest ? __builtin_ctz(rest) : b);     // last band: its E x result is not used
+        // CPQ_TPV_PREFETCH bands before the end of the span: one 4-byte load per 128-byte line pulls the workgroup's next span
+        // into L2 (early enough to hide the HBM latency, late enough to still be there when the span load asks for it: issued
+        // at the start of the span it doubled the kernel's HBM reads, profiles/r03e_ab_eq_prefetch.txt)
+        if (prefetch && __builtin_popcount(run | rest) == CPQ_TPV_PREFETCH - 1) (void)*reinterpret_cast<const volatile int*>(prefetch);
         if (ch.prev && tid == 0) {
             double sx, sy;
             tpv_chain_get(ch.prev + b, sx, sy, ch.ticket);
@@ -1071,8 +1078,8 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
                     e1 = fma(ee.y, x[j], e1);
                 }
             }
-            // the next span of this workgroup: one 4-byte load per 128-byte line pulls it into L2 while the bands run
-            if (sp + nGroups < nSpans) (void)*reinterpret_cast<const volatile int*>(src + (int64_t)nGroups * spanLen + lane * 16);
+            // the next span of this workgroup is requested into L2 while the last bands run (tpv_band_run)
+            const double* prefetch = (CPQ_TPV_PREFETCH && sp + nGroups < nSpans) ? src + (int64_t)nGroups * spanLen + lane * 16 : nullptr;
             int par = 0;
             unsigned mask = activeMask;
 #pragma unroll 1
@@ -1085,7 +1092,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
                 const unsigned rest = mask & ~run;
                 const TpvChain ch = { chained && sp > 0 ? chainCh + (int64_t)(sp - 1) * kBands : nullptr,
                                       chained ? chainCh + (int64_t)sp * kBands : nullptr, ticket };
-#define CPQ_RUN(CLS, SAT) stopped = !tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, ch, skipPub, tid, nThreads)
+#define CPQ_RUN(CLS, SAT) stopped = !tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, ch, skipPub, tid, nThreads, prefetch)
                 if (cls == 2)        CPQ_RUN(2, false);
                 else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
                 else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }

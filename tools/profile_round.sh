@@ -17,6 +17,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -
 echo "[profile_round] WRITE_SIZE pass done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/sq -o q -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity "$@" > $O/sq.log 2>&1 || true
 echo "[profile_round] SQ pass done"
+# LDS pipe of every kernel (the P = 4096 FFT kernels are quoted as LDS-bandwidth bound): array cycles, conflict cycles, issue stalls
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/lds -o l -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity "$@" > $O/lds.log 2>&1 || true
+echo "[profile_round] LDS pass done"
 export CPQ_PROFILES_OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $CPQ_PROFILES_OUT
 python3 tools/summarize_profiles.py $TAG "$(find $O/stats -name '*kernel_stats.csv' | head -1)" \
@@ -24,5 +27,7 @@ python3 tools/summarize_profiles.py $TAG "$(find $O/stats -name '*kernel_stats.c
     $O/stats.log > $O/summary.log 2>&1
 SQ=$(find $O/sq -name '*counter_collection.csv' | head -1)
 if [ -n "$SQ" ]; then python3 tools/summarize_sq.py "$SQ" > $CPQ_PROFILES_OUT/${TAG}_sq_counters.json 2>> $O/summary.log || true; fi
+LDS=$(find $O/lds -name '*counter_collection.csv' | head -1)
+if [ -n "$LDS" ]; then python3 tools/summarize_sq.py "$LDS" > $CPQ_PROFILES_OUT/${TAG}_lds_counters.json 2>> $O/summary.log || true; fi
 grep -h '"metric"' $O/stats.log > $CPQ_PROFILES_OUT/${TAG}_bench_profiled.json || true
 ls -la $CPQ_PROFILES_OUT
