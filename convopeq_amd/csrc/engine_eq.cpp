@@ -5,12 +5,12 @@ using namespace cpqi;
 
 namespace cpqi {
 
-// one cascade launch: the time-parallel kernel over whole 512-sample spans, the lane-skewed one over the rest
+// one cascade launch: the time-parallel kernels over every even number of samples, the lane-skewed one over a last odd sample (or everything)
 int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t stride, int n, bool tp, int idTp, int idSeq,
                    const double* coef, const int* flags, const double* satGain, double* state, const double* tables,
                    bool streamPairs = false)
 {
-    const int nTp = tp ? (n / 512) * 512 : 0;     // the time-parallel kernel works in 512-sample spans
+    const int nTp = tp ? (n & ~1) : 0;            // the time-parallel kernels take any even number of samples (chunks of two at the least); a last odd sample goes to the sequential kernel
     if (nTp > 0) {
         ProfScope p(e, idTp);
         cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables,

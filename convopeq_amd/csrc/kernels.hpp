@@ -63,7 +63,7 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 
 // Time-parallel SVF cascade: one 4-wave workgroup per channel, 256 chunks of a span in flight per band
 // (zero-state chunk runs + state scan + linear state response), span resident in LDS across the 20 bands.
-// nSamples must be a multiple of 512.  tables: kSvfTpTableDoubles doubles per (stream, band):
+// nSamples: any even number.  tables: kSvfTpTableDoubles doubles per (stream, band):
 // for each chunk length LC in kSvfTpLc ({16, 2} at 4 waves per channel): Mk[6][4] = A^(LC 2^k), Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)),
 // G[16][2] = C A^i.
 // geometry constants kSvfTpWaves / kSvfTpLc / kSvfTpTableDoubles: host_design.hpp (shared with the table builder)

@@ -418,7 +418,7 @@ __device__ __forceinline__ TpLanePowers tp_load_powers(const double* __restrict_
 template <int NTHREADS = kTpChunks>
 __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const double* Mall, int b,
                                         const TpLanePowers& pw, double* wtot, const double* sCur, double* sNext, int tid,
-                                        const double* __restrict__ Plate = nullptr)
+                                        const double* __restrict__ Plate = nullptr, int endTid = -1)
 {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the chain below branches on it
@@ -482,7 +482,8 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     s0x = dpp_f64<kDppWaveShr1, 0xF>(sx);
     s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
     if (lane == 0) { s0x = bx; s0y = by; }
-    if (tid == (NTHREADS ? NTHREADS : (int)blockDim.x) - 1) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }     // end of the span
+    // end of the span: the state behind the last chunk (endTid >= 0: behind chunk endTid -- a span whose tail is padding)
+    if (tid == (endTid >= 0 ? endTid : (NTHREADS ? NTHREADS : (int)blockDim.x) - 1)) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
@@ -543,8 +544,10 @@ __device__ __forceinline__ void tp_row_store(const double (&v)[U], double* p)
 template <int LC, bool SAT>
 __device__ __forceinline__ void tp_span(const double* in, double* out, double* buf, double* wtot, double*& sState,
                                         double*& sNext, int* sFlag, const TpLds* L, int tid, const int* __restrict__ fl,
-                                        const TpBandTables* __restrict__ tb, double sat, double gain)
+                                        const TpBandTables* __restrict__ tb, double sat, double gain, int nValid = LC * kTpChunks)
 {
+    // nValid < LC * kTpChunks (a multiple of LC): the span's tail is padding -- read as silence, not written, and the
+    // span's end state is the one behind sample nValid - 1
     constexpr int LCI = (LC == kTpLcMain) ? 0 : 1;
     constexpr int U = (LC < 8) ? LC : 8;
     const double oneMinusSat = 1.0 - sat;
@@ -555,7 +558,7 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 #pragma unroll 4
     for (int it = 0; it < LC; ++it) {
         const int j = it * kTpChunks + tid;
-        const double x = in[j];
+        const double x = (j < nValid) ? in[j] : 0.0;
         bad |= !(fabs(x) < kTpInputBound);
         buf[(j / LC) * kTpStride + (j % LC)] = x;
     }
@@ -571,9 +574,9 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
             const int flag = fl[b];
             if (!(flag & 1)) continue;
             if (tid == 0) {
-                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b);
-                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b);
-                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b);
+                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid / LC);
+                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid / LC);
+                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid / LC);
             }
             __syncthreads();
         }
@@ -604,7 +607,7 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
                 while (nb < kBands && !(fl[nb] & 1)) ++nb;     // next active band (uniform)
                 double s0x, s0y;
                 tp_scan(ic1, ic2, s0x, s0y, &L->M[0][0], b, tp_load_powers(&tb[b].t[LCI].P[0][0], tid & 63),
-                        wtot + par * 2 * kTpWaves, sState, sNext, tid);
+                        wtot + par * 2 * kTpWaves, sState, sNext, tid, nullptr, nValid / LC - 1);
                 par ^= 1;
                 // response table row of band b through a VGPR base: reads below are base + immediate offset
                 uint32_t gOff = (uint32_t)b * (uint32_t)sizeof(L->G[0]);
@@ -651,7 +654,7 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
 #pragma unroll 4
     for (int it = 0; it < LC; ++it) {
         const int j = it * kTpChunks + tid;
-        out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
+        if (j < nValid) out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
     }
     __syncthreads();
 }
@@ -707,6 +710,13 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
     for (int done = 0; nSamples - done >= kTpChunks * kTpLcTail; done += kTpChunks * kTpLcTail) {
         if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
         else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
+    }
+    // what is left of the call (480- and 441-sample callbacks, ragged calls): one more span, its tail padding
+    const int doneAll = nSamples / (kTpChunks * kTpLcTail) * (kTpChunks * kTpLcTail);
+    const int rest = (nSamples - doneAll) / kTpLcTail * kTpLcTail;
+    if (rest > 0) {
+        if (sat > 0.0) tp_span<kTpLcTail, true>(src + doneAll, dst + doneAll, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain, rest);
+        else           tp_span<kTpLcTail, false>(src + doneAll, dst + doneAll, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain, rest);
     }
     __syncthreads();
     if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];

@@ -482,18 +482,22 @@ def test_large_blocks_exact_semantics_long_ir(amd, oracle, block):
     eng.close()
 
 
-def test_eq_small_blocks_use_both_kernels(amd, oracle):
-    """blk 128, 7 blocks per call = 896 samples: 512 through the time-parallel kernel, 384 through the sequential."""
+@pytest.mark.parametrize("blk,T,seq_launches", [(128, 7, 0), (127, 7, 3), (480, 1, 0), (441, 3, 3)])
+def test_eq_small_blocks_use_both_kernels(amd, oracle, blk, T, seq_launches):
+    """Calls that are no whole number of 512-sample spans: the time-parallel kernels take every even number of samples (blk
+    128 x 7 = 896: one whole span + one whose tail is padding; a 480-sample callback: one padded span), a last odd sample
+    goes through the sequential kernel (127 x 7 = 889, 441 x 3 = 1323)."""
     O = oracle
-    S, blk, T = 2, 128, 7
+    S = 2
     x = make_inputs(O, S, 3 * T * blk)
     po = O.eq_params_bench(0.2)
-    eng = amd.BatchedEngine(S, block_size=blk, max_ir_len=512, max_blocks_per_call=T)
+    eng = amd.BatchedEngine(S, block_size=blk, max_ir_len=512, max_blocks_per_call=T,
+                            call_mode=amd.CPQ_CALLS_WHOLE_BLOCKS if blk == 128 else amd.CPQ_CALLS_ANY)
     eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
     eng.profile_enable(True)
     y = np.concatenate([eng.eq_process(x[:, o:o + T * blk]) for o in range(0, x.shape[1], T * blk)], axis=1)
     prof = eng.profile_read()
-    assert prof["k_svf_cascade_tp"][0] == 3 and prof["k_svf_cascade"][0] == 3
+    assert prof["k_svf_cascade_tp"][0] == 3 and prof["k_svf_cascade"][0] == seq_launches
     for s in range(S):
         yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po, block=blk)
         assert max(np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max()) <= 1e-13
