@@ -685,7 +685,8 @@ def test_eq_parallel_structure(amd, oracle, sat):
 
 @pytest.mark.parametrize("block,ir_len,blocks_per_call,n_calls,partition", [
     (1024, 131072, 4, 90, 0), (1024, 131072, 32, 10, 0), (2048, 131072, 3, 60, 0), (1024, 524288, 16, 50, 0),
-    (1024, 40000, 5, 30, 0), (1024, 131072, 32, 10, 4096), (2048, 131072, 16, 12, -1), (1024, 131072, 8, 40, 2048)])
+    (1024, 40000, 5, 30, 0), (1024, 131072, 32, 10, 4096), (2048, 131072, 16, 12, -1), (1024, 131072, 8, 40, 2048),
+    (1024, 600000, 32, 23, -1)])        # three layers 1024 / 8192 / 65536: the third one starts at tap 530048
 def test_time_varying_reference_semantics_large_blocks(amd, oracle, block, ir_len, blocks_per_call, n_calls, partition):
     """BASELINE.json configs[2], B >= 1024 with tail layers: partSize_L > outputDelaySamples_L, the reference's
     delay-line reader drops tail samples (SURVEY A6 'model invalid').  The engine runs one convolution per layer and
