@@ -150,7 +150,7 @@ const char* cpq_kernel_name(int32_t id)
 // inverse of the same spectra.  Own device buffers and twiddles, the null stream; no engine.
 int32_t cpq_diag_partition_fft(int32_t P, int32_t nCh, int32_t T, const double* in, double* spectra, double* out)
 {
-    if (P < 64 || P > 32768 || (P & (P - 1)) || nCh <= 0 || T <= 0 || !in || !spectra || !out) return CPQ_ERR_INVALID_ARG;
+    if (P < 64 || P > 131072 || (P & (P - 1)) || nCh <= 0 || T <= 0 || !in || !spectra || !out) return CPQ_ERR_INVALID_ARG;
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) { (void)hipGetLastError(); return CPQ_ERR_NO_DEVICE; }
     int ringSlots = 1;

@@ -411,8 +411,8 @@ int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double*
     if (pl.part_size[0] > 4096)
         return fail(e, CPQ_ERR_UNSUPPORTED, "layer-0 partition %d > 4096", pl.part_size[0]);
     for (int l = 1; l < pl.num_layers; ++l)
-        if (pl.part_size[l] > 32768 || (pl.part_size[l] & (pl.part_size[l] - 1)))
-            return fail(e, CPQ_ERR_UNSUPPORTED, "tail layer %d has partition size %d; supported: powers of two up to 32768", l, pl.part_size[l]);
+        if (pl.part_size[l] > 131072 || (pl.part_size[l] & (pl.part_size[l] - 1)))
+            return fail(e, CPQ_ERR_UNSUPPORTED, "tail layer %d has partition size %d; supported: powers of two up to 131072", l, pl.part_size[l]);
     const int S = e->desc.n_streams;
     const bool shared = stream == CPQ_ALL_STREAMS;
     const int s0 = shared ? 0 : stream, s1 = shared ? S : stream + 1;

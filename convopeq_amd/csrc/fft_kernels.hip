@@ -771,11 +771,13 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
 // two waves transforms the row pair (k1, M1 - k1).  tools/fft_fourstep_proto.py is the numpy model of this scheme.
 // tw.tw512 = exp(-2 pi i m / P) and tw.tw1024 = exp(-2 pi i k / 2P), P entries each.
 
-constexpr int kBigCols = 64;            // columns per workgroup in the column pass (one wave-width: coalesced rows)
+// columns per workgroup in the column pass: a wave-width of them (coalesced 1 KB rows) up to 64-point columns, fewer for the
+// 128- / 256-point columns of 65536- / 131072-sample partitions so that the tile stays at 64 KB and the workgroup at 512 threads
+__host__ __device__ constexpr int bigCols(int M1) { return M1 <= 64 ? 64 : (M1 == 128 ? 32 : 16); }
 
 // Stockham stages over the element axis of a [element][column] LDS tile; thread = (column, j), j < M1 / 8
 template <bool INV>
-__device__ __forceinline__ void col_stage8(double2* lds, int M1, int ns, const double2* __restrict__ twP, int j, int col)
+__device__ __forceinline__ void col_stage8(double2* lds, int M1, int ns, const double2* __restrict__ twP, int j, int col, int kBigCols)
 {
     const int stride = M1 >> 3;
     const int k = j & (ns - 1);
@@ -793,7 +795,7 @@ __device__ __forceinline__ void col_stage8(double2* lds, int M1, int ns, const d
 }
 
 template <bool INV, int R>
-__device__ __forceinline__ void col_stage_small(double2* lds, int M1, int ns, const double2* __restrict__ twP, int j, int col)
+__device__ __forceinline__ void col_stage_small(double2* lds, int M1, int ns, const double2* __restrict__ twP, int j, int col, int kBigCols)
 {
     constexpr int NB = 8 / R;
     const int nthr = M1 >> 3;
@@ -825,15 +827,18 @@ __device__ __forceinline__ void col_stage_small(double2* lds, int M1, int ns, co
 // M1-point FFT of the thread's column: the first radix-8 stage takes its inputs from registers (v[q] = element
 // j + q M1/8), the result ends in LDS in natural order
 template <bool INV>
-__device__ __forceinline__ void col_fft(double2 (&v)[8], double2* lds, int M1, const double2* __restrict__ twP, int j, int col)
+__device__ __forceinline__ void col_fft(double2 (&v)[8], double2* lds, int M1, const double2* __restrict__ twP, int j, int col, int kBigCols)
 {
     dft8<INV>(v);
 #pragma unroll
     for (int q = 0; q < 8; ++q) lds[(8 * j + q) * kBigCols + col] = v[q];
     __syncthreads();
-    if (M1 == 64) col_stage8<INV>(lds, M1, 8, twP, j, col);
-    else if (M1 == 32) col_stage_small<INV, 4>(lds, M1, 8, twP, j, col);
-    else col_stage_small<INV, 2>(lds, M1, 8, twP, j, col);
+    if (M1 >= 64) {                  // 64 = 8 x 8, 128 = 8 x 8 x 2, 256 = 8 x 8 x 4
+        col_stage8<INV>(lds, M1, 8, twP, j, col, kBigCols);
+        if (M1 == 128) col_stage_small<INV, 2>(lds, M1, 64, twP, j, col, kBigCols);
+        else if (M1 == 256) col_stage_small<INV, 4>(lds, M1, 64, twP, j, col, kBigCols);
+    } else if (M1 == 32) col_stage_small<INV, 4>(lds, M1, 8, twP, j, col, kBigCols);
+    else col_stage_small<INV, 2>(lds, M1, 8, twP, j, col, kBigCols);
 }
 
 // column pass, forward.  FRAME = true: overlap-save frame [previous P | current P] of (channel c, block t);
@@ -845,8 +850,9 @@ __global__ __launch_bounds__(512) void k_big_cols_fwd(const double* __restrict__
 {
     extern __shared__ double2 dyn[];
     const int M1 = P >> 9;
-    const int tr = blockIdx.x >> 3, tile = blockIdx.x & 7;
-    const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int kBigCols = bigCols(M1), nTiles = 512 / kBigCols;
+    const int tr = blockIdx.x / nTiles, tile = blockIdx.x - tr * nTiles;
+    const int col = threadIdx.x & (kBigCols - 1), j = threadIdx.x / kBigCols;
     const int n2 = tile * kBigCols + col;
     const int halfM = P >> 1;
     const int stride = M1 >> 3;
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(512) void k_big_cols_fwd(const double* __restrict__
             v[q] = x;
         }
     }
-    col_fft<false>(v, dyn, M1, tw.tw512, j, col);
+    col_fft<false>(v, dyn, M1, tw.tw512, j, col, kBigCols);
     double2* a = A + (int64_t)tr * P;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -972,15 +978,16 @@ __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict_
 {
     extern __shared__ double2 dyn[];
     const int M1 = P >> 9;
-    const int tr = blockIdx.x >> 3, tile = blockIdx.x & 7;
-    const int col = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int kBigCols = bigCols(M1), nTiles = 512 / kBigCols;
+    const int tr = blockIdx.x / nTiles, tile = blockIdx.x - tr * nTiles;
+    const int col = threadIdx.x & (kBigCols - 1), j = threadIdx.x / kBigCols;
     const int n2 = tile * kBigCols + col;
     const int stride = M1 >> 3;
     const double2* a = A + (int64_t)tr * P;
     double2 v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = a[(j + q * stride) * 512 + n2];
-    col_fft<true>(v, dyn, M1, tw.tw512, j, col);
+    col_fft<true>(v, dyn, M1, tw.tw512, j, col, kBigCols);
     const int c = tr / T, t = tr - c * T;
     double* o = out + (int64_t)c * chStride + (int64_t)t * P;
     const double s = 1.0 / (double)P;
@@ -1043,7 +1050,7 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
 {
     if (P > 4096) {         // four-step: column pass into scratch [nCh * T][P], then row pass + split into the FDL ring
         const int M1 = P >> 9;
-        hipLaunchKernelGGL(k_big_cols_fwd<true>, dim3(nCh * T * 8), dim3(8 * M1), (size_t)M1 * kBigCols * sizeof(double2),
+        hipLaunchKernelGGL(k_big_cols_fwd<true>, dim3(nCh * T * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2),
                            stream, in, chStride, histOld, histNew, 0, scratch, tw, P, T);
         hipLaunchKernelGGL(k_big_rows_fwd, dim3(nCh * T * ((M1 >> 1) + 1)), dim3(128), 0, stream, scratch, X, XDN, tw, P,
                            T, head, ringSlots - 1, ringSlots);
@@ -1071,7 +1078,7 @@ void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, doub
 {
     if (P > 4096) {         // scratch [nParts][P]
         const int M1 = P >> 9;
-        hipLaunchKernelGGL(k_big_cols_fwd<false>, dim3(nParts * 8), dim3(8 * M1), (size_t)M1 * kBigCols * sizeof(double2),
+        hipLaunchKernelGGL(k_big_cols_fwd<false>, dim3(nParts * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2),
                            stream, heff, 0, nullptr, nullptr, heffLen, scratch, tw, P, 1);
         hipLaunchKernelGGL(k_big_rows_fwd, dim3(nParts * ((M1 >> 1) + 1)), dim3(128), 0, stream, scratch, H, HDN, tw, P, 1, 0,
                            0, 0);
@@ -1102,7 +1109,7 @@ void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int6
     if (P > 4096) {         // scratch [nCh * T][P]
         const int M1 = P >> 9;
         hipLaunchKernelGGL(k_big_rows_inv, dim3(nCh * T * ((M1 >> 1) + 1)), dim3(128), 0, stream, Y, scratch, tw, P);
-        hipLaunchKernelGGL(k_big_cols_inv, dim3(nCh * T * 8), dim3(8 * M1), (size_t)M1 * kBigCols * sizeof(double2), stream,
+        hipLaunchKernelGGL(k_big_cols_inv, dim3(nCh * T * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2), stream,
                            scratch, out, chStride, tw, P, T);
         return;
     }

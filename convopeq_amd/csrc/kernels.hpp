@@ -49,7 +49,7 @@ void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2*
                           double2* Y, int P, int nCh, int K, int ringSlots, int head, int T, int hdnStride);
 
 // inverse 1024-point real FFT of Y, scaled 1/N, second half (P samples) to out.
-// P > 4096 (8192 / 16384 / 32768): four-step transforms through `scratch` ([transforms][P] double2); the spectra are
+// P > 4096 (8192 ... 131072): four-step transforms through `scratch` ([transforms][P] double2); the spectra are
 // then stored permuted (element k1 * 512 + k2 = bin k1 + (P / 512) k2), consistently in all three launchers.
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw,
                          int P, int nCh, int T, double2* scratch = nullptr);

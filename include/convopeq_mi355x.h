@@ -235,9 +235,9 @@ int32_t cpq_host_unregister(void* ptr);
  * the air-absorption damping (:1060-1097) are applied to every partition spectrum at that LAYER's FFT size, exactly
  * as the reference does.  Layer 0 runs in the main path; every tail layer of the plan runs on the reference's own
  * partition grid (block_size * multiplier, ...) and reaches the output through the delay-line lag done_callback * B.
- * Tail partitions up to 32768 samples are supported (above 4096 through a four-step FFT); plans that are time-varying
+ * Tail partitions up to 131072 samples are supported (above 4096 through a four-step FFT); plans that are time-varying
  * in the reference (cpq_nuc_plan.lti_valid == 0) follow the replayed delay-line reader.
- * Limits (CPQ_ERR_UNSUPPORTED): tail partitions that are not a power of two or exceed 32768, FilterSpec IRs with
+ * Limits (CPQ_ERR_UNSUPPORTED): tail partitions that are not a power of two or exceed 131072 (no plan of the reference does), FilterSpec IRs with
  * different layer plans in one engine, partition_size != block_size.
  * enable_direct_head: the first min(ir_len, 32) taps leave the FFT path before the spectra (and any FilterSpec gains)
  * are formed and run as a time-domain FIR over [history | block], flushed below 1e-20, added before the tail layers
@@ -459,7 +459,7 @@ const char* cpq_kernel_name(int32_t kernel_id);
  * (2 * partition real points, unscaled) and the inverse transform of those spectra (scaled 1 / (2 * partition)), second half.
  * spectra: [channel][block][partition][2] in the kernels' own storage order -- element 0 = (DC, Nyquist), both real; element
  * e = bin e for partition <= 2048; for larger partitions element k1 * 512 + k2 = bin k1 + (partition / 512) * k2.
- * out: [channel][block][sample], equals the input up to rounding.  partition: a power of two in 64 ... 32768.
+ * out: [channel][block][sample], equals the input up to rounding.  partition: a power of two in 64 ... 131072.
  * Needs a gfx950 device; no engine.  For tests of the FFT kernel families in isolation. */
 int32_t     cpq_diag_partition_fft(int32_t partition, int32_t n_channels, int32_t n_blocks, const double* in,
                                    double* spectra, double* out);

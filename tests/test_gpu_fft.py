@@ -8,7 +8,8 @@ itself), and the round trip.  One case per kernel family:
   P = 512                 k_rfft_*_ols           (wave-level 512-point transform, 8 points per lane)
   P = 1024 / 2048         k_rfft_*_ols_wg        (one workgroup per transform, mixed radix)
   P = 4096                k_rfft_*_ols_p4        (four-step inside a workgroup; spectra stored permuted)
-  P = 8192 ... 32768      k_big_cols_* / k_big_rows_*   (four-step through a scratch buffer; spectra stored permuted)
+  P = 8192 ... 131072     k_big_cols_* / k_big_rows_*   (four-step through a scratch buffer; spectra stored permuted;
+                          65536 / 131072: 128- / 256-point columns, 32 / 16 columns per workgroup)
 
 Tolerance: 4e-15 of the largest spectral magnitude on the forward transform and of the largest sample against numpy's
 inverse, 2e-15 on the round trip
@@ -39,7 +40,7 @@ def _bins(P):
     return (e // 512) + m1 * (e % 512)
 
 
-@pytest.mark.parametrize("P", [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize("P", [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072])
 def test_partition_fft_forward_inverse_round_trip(amd, P):
     from convopeq_amd import _capi
     lib = _capi.load()

@@ -898,7 +898,9 @@ def test_filter_spec_tails_shared_ir_in_place_whole_path(amd, oracle):
 
 
 @pytest.mark.parametrize("ir_len,block,T,S", [(131072, 512, 8, 2), (131072, 512, 64, 2), (524288, 512, 16, 1),
-                                              (131072, 1024, 4, 1), (20000, 128, 12, 2), (3000, 512, 4, 1)])
+                                              (131072, 1024, 4, 1), (20000, 128, 12, 2), (3000, 512, 4, 1),
+                                              # three layers above B = 512: 1024 / 8192 / 65536 and 2048 / 16384 / 131072
+                                              (600000, 1024, 32, 1), (1150000, 2048, 32, 1)])
 def test_native_non_uniform_schedule(amd, oracle, ir_len, block, T, S):
     """CPQ_SCHED_REFERENCE_NUC (BASELINE.json configs[3]): the reference's own non-uniform partition schedule run
     natively -- layer 0 at the block size, tail layers at 8x / 64x on their own FFT grids, merged through the replayed
