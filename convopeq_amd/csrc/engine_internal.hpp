@@ -59,6 +59,7 @@ struct PlanGroup {
     bool frozen = false;                        // processor-level bypass / dry-only of its (single) member: not processed
     cpq_filter_spec spec{};
     int capCh = 0, usedCh = 0;                  // allocated / launched local channels (2 per pair slot)
+    bool identityMap = false;                   // chMap[i] == i for every launched channel (layer 0 may then write the output rows itself)
     std::vector<int> streamOfPair;              // pair slot -> stream, -1 = free
     std::vector<NativeLayer> layers;
     int* chMapDev = nullptr;                    // [capCh] local channel -> row of the call's buffers (-1 = free slot)

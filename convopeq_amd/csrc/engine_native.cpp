@@ -128,6 +128,8 @@ int uploadGroupMaps(cpq_engine* e, PlanGroup& g)
         }
         if (s >= 0) g.usedCh = 2 * p + 2;
     }
+    g.identityMap = true;                      // local channel i = row i of the call's buffers, no free slot in between
+    for (int i = 0; i < g.usedCh; ++i) g.identityMap = g.identityMap && chMap[(size_t)i] == i;
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     CPQ_HIP(e, hipMemcpy(g.chMapDev, chMap.data(), sizeof(int) * chMap.size(), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(g.irSlotDev, irSlot.data(), sizeof(int) * irSlot.size(), hipMemcpyHostToDevice));
@@ -554,13 +556,30 @@ static void replayCall(const cpq_engine* e, PlanGroup& g, int n, std::vector<lon
     }
 }
 
+// layer 0 had no input waiting and nothing in its output ring before this call (w0 = its write position then)
+static bool layer0WasEmpty(const PlanGroup& g, long long w0, long long r0)
+{
+    return g.layers[0].fill == 0 && r0 == w0;
+}
+
 int groupsAppend(cpq_engine* e, const double* dIn, int n)
 {
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
         if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
-        for (NativeLayer& t : g.layers)
-            cpq::launch_rows_gather(e->stream, dIn, n, g.chMapDev, t.acc[t.accSel], t.accCap, t.fill, n, g.usedCh);
+        // every layer accumulates the same input (Add(), :1431-1446): one pass over it
+        double* dst[3];
+        int64_t stride[3], off[3];
+        int nl = 0;
+        for (NativeLayer& t : g.layers) {
+            if (nl == 3) break;
+            dst[nl] = t.acc[t.accSel];
+            stride[nl] = t.accCap;
+            off[nl] = t.fill;
+            ++nl;
+        }
+        ProfScope p(e, CPQ_K_MIX);
+        cpq::launch_rows_gather_multi(e->stream, dIn, n, g.chMapDev, nl, dst, stride, off, n, g.usedCh);
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
@@ -568,7 +587,10 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
 
 // one layer: every partition that filled up in this call is convolved (FFT, FDL push, MAC over the layer's partitions,
 // IFFT; NUC.cpp:1245-1336 / :1456-1544) and stored in the layer's output ring / delay line
-static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, const long long* putPos, long long ringPos0)
+// directOut != nullptr (layer 0 only): the inverse transform writes the members' output rows themselves and the output ring is
+// passed by -- the caller has checked that this call's Get() reads exactly what this call's blocks produce
+static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, const long long* putPos, long long ringPos0,
+                          double* directOut = nullptr)
 {
     const int total = t.fill + n;
     const int nb = total / t.P;
@@ -592,10 +614,12 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
         }
         {
             ProfScope p(e, CPQ_K_RFFT_INV);
-            cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, nCh, nb, t.scratch);
+            if (directOut) cpq::launch_rfft_inv_ols(e->stream, t.Y, directOut, (int64_t)n, tw, t.P, nCh, nb, t.scratch);
+            else           cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, nCh, nb, t.scratch);
         }
         ProfScope p(e, CPQ_K_MIX);
-        if (putPos) cpq::launch_ring_put_blocks(e->stream, t.z, (int64_t)t.nbMax * t.P, t.P, nb, t.ring, t.outRing, putPos, nCh);
+        if (directOut) { /* nothing to store: the ring stays empty (read and write positions advanced together on the host) */ }
+        else if (putPos) cpq::launch_ring_put_blocks(e->stream, t.z, (int64_t)t.nbMax * t.P, t.P, nb, t.ring, t.outRing, putPos, nCh);
         else cpq::launch_ring_put(e->stream, t.z, (int64_t)t.nbMax * t.P, nb * t.P, t.ring, t.outRing, ringPos0, nCh);
         cpq::launch_rows_copy(e->stream, t.acc[t.accSel], t.accCap, (int64_t)nb * t.P, t.acc[t.accSel ^ 1], t.accCap, 0, rem, nCh);
         t.head = (t.head + nb) & (t.ringSlots - 1);
@@ -613,14 +637,27 @@ int groupsRunLayer0(cpq_engine* e, double* dOut, int n)
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
         if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
-        const long long w0 = g.layers[0].wPos;
+        const long long w0 = g.layers[0].wPos, r0 = g.layers[0].rPos;
         replayCall(e, g, n, g.tabHost, g.tabOffs, g.nbOf);
         if ((int)g.tabHost.size() > g.tabCap) return fail(e, CPQ_ERR_INVALID_ARG, "call of %d samples exceeds the engine's call capacity", n);
         { const int rc = stageUpload(e, g.tabDev, g.tabHost.data(), g.tabHost.size() * sizeof(long long)); if (rc != CPQ_OK) return rc; }
-        { const int rc = runLayerBlocks(e, g, g.layers[0], n, nullptr, w0); if (rc != CPQ_OK) return rc; }
-        ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_ring_get_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, g.layers[0].ring, g.layers[0].outRing,
-                                    g.tabDev + g.tabOffs[0], g.tabDev + g.tabOffs[1], g.usedCh);
+        // Whole-block call on an empty ring, every chunk's Get() taking exactly the chunk this call's blocks produce, members =
+        // all channels in order: the inverse FFT writes the output rows directly, no ring put / get (two passes and two
+        // launches less; the ring stays empty, its positions advanced on the host by the replay above)
+        bool direct = g.identityMap && g.usedCh == e->nCh && layer0WasEmpty(g, w0, r0) && n % g.layers[0].P == 0;
+        if (direct) {
+            const size_t chunks = (size_t)((n + e->B - 1) / e->B);
+            for (size_t c = 0; c < chunks && direct; ++c) {
+                const long long want = std::min<long long>(e->B, n - (long long)c * e->B);
+                direct = g.tabHost[g.tabOffs[0] + c] == w0 + (long long)c * e->B && g.tabHost[g.tabOffs[1] + c] == want;
+            }
+        }
+        { const int rc = runLayerBlocks(e, g, g.layers[0], n, nullptr, w0, direct ? dOut : nullptr); if (rc != CPQ_OK) return rc; }
+        if (!direct) {
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_ring_get_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, g.layers[0].ring, g.layers[0].outRing,
+                                        g.tabDev + g.tabOffs[0], g.tabDev + g.tabOffs[1], g.usedCh);
+        }
         g.samplesSinceReset += n;
         g.lastCall = n;
         g.lastGot = 0;
@@ -637,11 +674,18 @@ int groupsRunTails(cpq_engine* e, double* dOut, int n)
         PlanGroup& g = *gp;
         if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
         for (size_t l = 1; l < g.layers.size(); ++l) {
-            NativeLayer& t = g.layers[l];
-            { const int rc = runLayerBlocks(e, g, t, n, g.tabDev + g.tabOffs[2 * l + 1], 0); if (rc != CPQ_OK) return rc; }
-            ProfScope p(e, CPQ_K_MIX);
-            cpq::launch_ring_add_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, t.ring, t.outRing, g.tabDev + g.tabOffs[2 * l],
-                                        t.gain, g.usedCh);
+            const int rc = runLayerBlocks(e, g, g.layers[l], n, g.tabDev + g.tabOffs[2 * l + 1], 0);
+            if (rc != CPQ_OK) return rc;
+        }
+        ProfScope p(e, CPQ_K_MIX);
+        if (g.layers.size() == 3) {          // both delay lines in one pass over the output (layer 1 first, as Get() adds them)
+            NativeLayer& a = g.layers[1];
+            NativeLayer& b = g.layers[2];
+            cpq::launch_ring_add_chunks2(e->stream, dOut, n, g.chMapDev, n, e->B, a.ring, a.outRing, g.tabDev + g.tabOffs[2], a.gain,
+                                         b.ring, b.outRing, g.tabDev + g.tabOffs[4], b.gain, g.usedCh);
+        } else if (g.layers.size() == 2) {
+            NativeLayer& t = g.layers[1];
+            cpq::launch_ring_add_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, t.ring, t.outRing, g.tabDev + g.tabOffs[2], t.gain, g.usedCh);
         }
     }
     CPQ_HIP(e, hipGetLastError());

@@ -123,6 +123,12 @@ void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int
 // (one Add / Get pair of the reference per chunk); pos / cnt / sched: per chunk, replayed on the host.
 void launch_rows_gather(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, double* dst,
                         int64_t dstStride, int64_t dstOff, int n, int nCh);
+// up to three layers' accumulators in one pass over the input; both tail layers' read-add in one pass over the output
+void launch_rows_gather_multi(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, int nLayers,
+                              double* const* dst, const int64_t* dstStride, const int64_t* dstOff, int n, int nCh);
+void launch_ring_add_chunks2(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                             const double* ringA, int ringSizeA, const long long* schedA, double gainA,
+                             const double* ringB, int ringSizeB, const long long* schedB, double gainB, int nCh);
 void launch_ring_put_blocks(hipStream_t stream, const double* z, int64_t zStride, int P, int nb, double* ring, int ringSize,
                             const long long* pos, int nCh);
 void launch_ring_get_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,

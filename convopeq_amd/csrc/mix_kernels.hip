@@ -314,6 +314,51 @@ __global__ __launch_bounds__(256) void k_ring_put_blocks(const double* __restric
 }
 
 // Get() of layer 0 per chunk: cnt[cb] samples from ring position pos[cb], zero-filled to the chunk's end (:1376-1402)
+// the call's input into the accumulators of up to three layers of a plan group at once (Add(): every layer accumulates the
+// same input, src/MKLNonUniformConvolver.cpp:1431-1446): the input row is read once
+struct GatherDst { double* dst[3]; long long stride[3]; long long off[3]; int n; };
+__global__ __launch_bounds__(256) void k_rows_gather_multi(const double* __restrict__ src, int64_t srcStride,
+                                                           const int* __restrict__ chMap, GatherDst d, int n)
+{
+    const int g = chMap[blockIdx.y];
+    if (g < 0) return;
+    const double* s = src + (int64_t)g * srcStride;
+    double* d0 = d.dst[0] + (int64_t)blockIdx.y * d.stride[0] + d.off[0];
+    double* d1 = d.n > 1 ? d.dst[1] + (int64_t)blockIdx.y * d.stride[1] + d.off[1] : nullptr;
+    double* d2 = d.n > 2 ? d.dst[2] + (int64_t)blockIdx.y * d.stride[2] + d.off[2] : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = s[i];
+        d0[i] = v;
+        if (d1) d1[i] = v;
+        if (d2) d2[i] = v;
+    }
+}
+
+// delay-line read-add of both tail layers in one pass over the output (Get(), :1620-1633: layer 1 first, then layer 2)
+__global__ __launch_bounds__(256) void k_ring_add_chunks2(double* __restrict__ out, int64_t outStride,
+                                                          const int* __restrict__ chMap, int n, int q,
+                                                          const double* __restrict__ ringA, int maskA,
+                                                          const long long* __restrict__ schedA, double gainA,
+                                                          const double* __restrict__ ringB, int maskB,
+                                                          const long long* __restrict__ schedB, double gainB)
+{
+    const int g = chMap[blockIdx.y];
+    if (g < 0) return;
+    double* o = out + (int64_t)g * outStride;
+    const double* ra = ringA + (int64_t)blockIdx.y * (maskA + 1);
+    const double* rb = ringB + (int64_t)blockIdx.y * (maskB + 1);
+    const bool unityA = fabs(gainA - 1.0) < 1.0e-12, unityB = fabs(gainB - 1.0) < 1.0e-12;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cb = i / q, j = i - cb * q;
+        const long long sa = schedA[cb], sb = schedB[cb];
+        if (sa < 0 && sb < 0) continue;
+        double v = o[i];
+        if (sa >= 0) { const double a = ra[(sa + j) & maskA]; v = unityA ? (v + a) : (v + a * gainA); }
+        if (sb >= 0) { const double b = rb[(sb + j) & maskB]; v = unityB ? (v + b) : (v + b * gainB); }
+        o[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ring_get_chunks(double* __restrict__ out, int64_t outStride,
                                                          const int* __restrict__ chMap, int n, int q,
                                                          const double* __restrict__ ring, int mask,
@@ -571,6 +616,25 @@ void launch_rows_gather(hipStream_t stream, const double* src, int64_t srcStride
 {
     if (n <= 0 || nCh <= 0) return;
     hipLaunchKernelGGL(k_rows_gather, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, chMap, dst, dstStride, dstOff, n);
+}
+
+void launch_rows_gather_multi(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, int nLayers,
+                              double* const* dst, const int64_t* dstStride, const int64_t* dstOff, int n, int nCh)
+{
+    if (n <= 0 || nCh <= 0 || nLayers <= 0) return;
+    GatherDst d{};
+    d.n = nLayers > 3 ? 3 : nLayers;
+    for (int l = 0; l < d.n; ++l) { d.dst[l] = dst[l]; d.stride[l] = dstStride[l]; d.off[l] = dstOff[l]; }
+    hipLaunchKernelGGL(k_rows_gather_multi, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, chMap, d, n);
+}
+
+void launch_ring_add_chunks2(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                             const double* ringA, int ringSizeA, const long long* schedA, double gainA,
+                             const double* ringB, int ringSizeB, const long long* schedB, double gainB, int nCh)
+{
+    if (n <= 0 || nCh <= 0) return;
+    hipLaunchKernelGGL(k_ring_add_chunks2, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, chMap, n, q, ringA,
+                       ringSizeA - 1, schedA, gainA, ringB, ringSizeB - 1, schedB, gainB);
 }
 
 void launch_ring_put_blocks(hipStream_t stream, const double* z, int64_t zStride, int P, int nb, double* ring, int ringSize,
