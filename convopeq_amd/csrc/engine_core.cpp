@@ -345,8 +345,8 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->ofSatGain, nCh * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofState, nCh * kBands * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
-        // band-state hand-over between the workgroups of one channel (chained spans of the time-parallel cascade): only
-        // engines whose channels alone leave room for a second workgroup per channel ever use it
+        // hand-over words between the band-pipelined stages of one channel (time-parallel cascade, svf_kernels.hip): only
+        // engines whose channels alone leave room for a second workgroup per channel ever use them
         { (void**)&e->svfChain, nCh <= 256 ? (int64_t)cpq::svf_chain_bytes((int)nCh, e->maxCall) : 0 },
     };
     e->svfChainSpans = nCh <= 256 ? (int)(cpq::svf_chain_bytes(1, e->maxCall) / cpq::svf_chain_bytes(1, 0)) : 0;

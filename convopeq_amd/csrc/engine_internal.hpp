@@ -142,7 +142,7 @@ struct cpq_engine {
     double* ofSatGain = nullptr;
     double* ofState = nullptr;  // [nCh][20][2]  w1 w2
     double* ofTp = nullptr;     // [streams][20][kSvfTpTableDoubles]
-    void* svfChain = nullptr;   // [channels][svfChainSpans][20] band-state hand-over between the workgroups of one channel (chained spans of the time-parallel cascade), or none
+    void* svfChain = nullptr;   // [channels][<= 20 stages][svfChainSpans] hand-over words of the band-pipelined stages (time-parallel cascade), or none
     int svfChainSpans = 0;
     unsigned long long svfTicket = 0;   // one per time-parallel launch: marks the slots that launch wrote
     bool ofSet = false, ofTpSafe = true, ofInPath = false;

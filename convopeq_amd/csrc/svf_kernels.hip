@@ -470,6 +470,27 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     double bx = sCur[2 * b], by = sCur[2 * b + 1];
     const double2 mw01 = Mb2[12], mw23 = Mb2[13];
     const double mw0 = mw01.x, mw1 = mw01.y, mw2 = mw23.x, mw3 = mw23.y;
+#if CPQ_TP_CHAIN_PRELOAD
+    if (Plate && (NTHREADS ? NTHREADS : (int)blockDim.x) <= 512) {
+        // the totals of the waves before this one, all requested at once (one LDS latency instead of one per step: the last
+        // wave's chain of seven steps is on the critical path of every band), kept apart from the per-lane power loads below
+        // so that the 28 registers are free again before those are issued
+        __builtin_amdgcn_sched_barrier(0);
+        double2 tt[7];
+#pragma unroll
+        for (int w = 0; w < 7; ++w) tt[w] = *reinterpret_cast<const double2*>(wtot + 2 * w);
+#pragma unroll
+        for (int w = 0; w < 7; ++w) {
+            if (w < wave) {          // wave-uniform
+                const double nx = fma(mw1, by, fma(mw0, bx, tt[w].x));
+                const double ny = fma(mw3, by, fma(mw2, bx, tt[w].y));
+                bx = nx;
+                by = ny;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    } else
+#endif
     for (int w = 0; w < wave; ++w) {
         const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
         const double nx = fma(mw1, by, fma(mw0, bx, tx));
@@ -735,32 +756,35 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
 // Band coefficients are wave-uniform SGPR operands, the E rows come from LDS as broadcast reads, the per-lane scan powers
 // are requested one band ahead.  Span I/O: coalesced 16-byte accesses, transposed to chunk-per-lane through the wave's
 // own padded LDS buffer (two halves of eight samples); the next span's lines are requested into L2 while the bands run.
-// WAVES > 0: whole spans of WAVES x 1024 samples, the workgroup walks the spans g, g + nGroups, ... of its channel
-// (nGroups > 1: several workgroups per channel, chained spans, below); WAVES = 0: ONE span of blockDim.x / 64 (1 ... 7)
+// WAVES > 0: whole spans of WAVES x 1024 samples, the workgroup walks the spans of its channel (STAGED: several
+// workgroups per channel, each with a run of the bands, below); WAVES = 0: ONE span of blockDim.x / 64 (1 ... 7)
 // waves x 1024 samples (what a call leaves after its whole spans).
 // A span whose input or start state is outside the range for which the host proved the reference's guards idle ends the
 // fast loop: that span and the workgroup's later ones go through the one-thread guarded recurrence behind the loop
 // (cold code, kept out of the band loop's register allocation).
 
-// Chained spans (nGroups > 1; engines with fewer channels than the chip has room for workgroups): span s of a channel
-// needs, band by band, the state at the end of span s - 1 -- nothing else ties the spans together, so nGroups workgroups
-// work on consecutive spans of one channel at once, each one band-scan behind its predecessor.  Slot (channel, span,
-// band) carries the state at the END of that span + the ticket of the launch that wrote it (tickets never repeat, so
-// the slots need no clearing).  The launcher keeps channels x nGroups within the number of workgroups the chip holds at
-// once: a consumer only ever waits for a workgroup with a lower block index, which is resident or finished.
-struct TpvChainSlot { double sx, sy; unsigned long long ticket; unsigned long long pad; };
-
-__device__ __forceinline__ void tpv_chain_put(TpvChainSlot* s, double sx, double sy, unsigned long long ticket)
+// Band-pipelined stages (STAGED; engines with fewer channels than the chip has room for workgroups): the cascade is a
+// pipeline in the band index too, so nStages workgroups share one channel, workgroup g running bands [g, g + 1) * 20 /
+// nStages over ALL spans, one span behind workgroup g - 1 -- it reads what that one stored (in `out`, in place) and
+// stores its own result over it.  One release / acquire pair per span and stage (an earlier form that split the SPANS
+// over the workgroups handed the band states over instead, 20 pairs per span, and lost more to the L2 write-backs than
+// it gained: profiles/r03b_eq_chained_spans.txt).  Blocks are numbered stage-major: a consumer only ever waits for a
+// workgroup with a lower block index, which the dispatcher has placed before it -- resident or finished, whatever else
+// runs on the chip.
+// Hand-over between the stages of one launch (band-pipelined stages, below): one 64-bit word per (channel, stage, span),
+// holding the launch's ticket once that stage has stored that span.  Tickets differ from launch to launch, so the words
+// are never cleared.  The accesses are relaxed: the fast path moves the span itself with agent-scope accesses and needs
+// no fence (tpv_span_load), the guarded path puts its own fences around them.
+#ifndef CPQ_TPV_FLAG_FENCED
+#define CPQ_TPV_FLAG_FENCED 1
+#endif
+__device__ __forceinline__ void tpv_span_publish(unsigned long long* flag, unsigned long long ticket)
 {
-    __hip_atomic_store(&s->sx, sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&s->sy, sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&s->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flag, ticket, CPQ_TPV_FLAG_FENCED ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void tpv_chain_get(const TpvChainSlot* s, double& sx, double& sy, unsigned long long ticket)
+__device__ __forceinline__ void tpv_span_await(const unsigned long long* flag, unsigned long long ticket)
 {
-    while (__hip_atomic_load(&s->ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(2);
-    sx = __hip_atomic_load(&s->sx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sy = __hip_atomic_load(&s->sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(flag, CPQ_TPV_FLAG_FENCED ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(8);
 }
 
 // tuning of the pass (A/B with tools/ab_tpv.sh): samples per group of the small-signal output stage; order of its
@@ -774,10 +798,26 @@ __device__ __forceinline__ void tpv_chain_get(const TpvChainSlot* s, double& sx,
 #ifndef CPQ_TPV_PEAK
 #define CPQ_TPV_PEAK 1
 #endif
+#ifndef CPQ_TPV_HL
+#define CPQ_TPV_HL 1
+#endif
+#ifndef CPQ_TPV_HS
+#define CPQ_TPV_HS 1
+#endif
+#ifndef CPQ_TPV_LAUNDER
+#define CPQ_TPV_LAUNDER 1
+#endif
+#ifndef CPQ_TP_CHAIN_PRELOAD
+#define CPQ_TP_CHAIN_PRELOAD 0
+#endif
 #ifndef CPQ_TPV_PREFETCH
 #define CPQ_TPV_PREFETCH 0      // bands before the end of a span at which the next span is requested into L2; 0 = never: it buys 2.5 % of the kernel time for 1.35 ... 1.56 x the HBM traffic (profiles/r03e_ab_eq_prefetch.txt)
 #endif
-constexpr int kTpvSpan = 8 * 1024;      // samples per span of the eight-wave kernel
+#ifndef CPQ_TPV_WAVES
+#define CPQ_TPV_WAVES 8
+#endif
+constexpr int kTpvWaves = CPQ_TPV_WAVES;          // waves of the span kernel
+constexpr int kTpvSpan = kTpvWaves * 1024;      // samples per span
 constexpr unsigned kTpvApplyGain = 1u << 31;      // bandFilter bit: this launch applies the channel's output gain (the last stage)
 constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
 constexpr int kTpvGuardPiece = 2048;    // samples per staged piece of the guarded path
@@ -869,12 +909,34 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
 // span <-> registers: 8 coalesced 16-byte accesses per lane, transposed through the wave's LDS buffer in four quarters
 // (samples 4 h ... 4 h + 3 of every chunk: 64 rows of kTpvQStride).  Lane l of access k holds samples 2 (l & 7), + 1 of
 // chunk 8 k + (l >> 3): the lanes with ((l >> 1) & 3) == h belong to quarter h.
+// COHERENT (the hand-over between band-pipelined stages): the accesses carry the agent-scope bit, i.e. they go past the
+// L2 of this XCD to where the other XCDs see them -- what an agent-scope atomic access does, 16 bytes wide.  The stages
+// then need no release / acquire fence around the hand-over: a fence writes back, or invalidates, the whole L2 of the XCD,
+// and with hundreds of workgroups doing that per span it cost several times the kernel (profiles/r03h_eq_staged_kernel.txt).
+template <bool COHERENT>
 __device__ __forceinline__ void tpv_span_load(const double* src, double* buf, int lane, double (&x)[16])
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
     v2 t[8];
+    if (COHERENT) {
+        const double* p0 = src + lane * 2;
+        const double* p1 = p0 + 4 * 128;
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                     "global_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+                     "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+                     "global_load_dwordx4 %4, %9, off sc1\n\t"
+                     "global_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+                     "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\t"
+                     "global_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                     : "v"(p0), "v"(p1)
+                     : "memory");
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = __builtin_nontemporal_load(reinterpret_cast<const v2*>(src + k * 128 + lane * 2));
+        for (int k = 0; k < 8; ++k) t[k] = __builtin_nontemporal_load(reinterpret_cast<const v2*>(src + k * 128 + lane * 2));
+    }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         if (((lane >> 1) & 3) == h) {
@@ -892,6 +954,7 @@ __device__ __forceinline__ void tpv_span_load(const double* src, double* buf, in
         wave_lds_sync();
     }
 }
+template <bool COHERENT>
 __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lane, const double (&x)[16], double gain)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
@@ -911,8 +974,26 @@ __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lan
         }
         wave_lds_sync();
     }
+    if (COHERENT) {
+        double* p0 = dst + lane * 2;
+        double* p1 = p0 + 4 * 128;
+        // (waits for the stores to be acknowledged: the flag that announces them goes out behind the barrier that follows)
+        asm volatile("global_store_dwordx4 %8, %0, off sc1\n\t"
+                     "global_store_dwordx4 %8, %1, off offset:1024 sc1\n\t"
+                     "global_store_dwordx4 %8, %2, off offset:2048 sc1\n\t"
+                     "global_store_dwordx4 %8, %3, off offset:3072 sc1\n\t"
+                     "global_store_dwordx4 %9, %4, off sc1\n\t"
+                     "global_store_dwordx4 %9, %5, off offset:1024 sc1\n\t"
+                     "global_store_dwordx4 %9, %6, off offset:2048 sc1\n\t"
+                     "global_store_dwordx4 %9, %7, off offset:3072 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     :
+                     : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(p0), "v"(p1)
+                     : "memory");
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(t[k], reinterpret_cast<v2*>(dst + k * 128 + lane * 2));
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(t[k], reinterpret_cast<v2*>(dst + k * 128 + lane * 2));
+    }
 }
 
 // Guarded run of the spans sp, sp + nGroups, ... of a channel: pieces of kTpvGuardPiece samples staged in the scratch area as
@@ -920,13 +1001,17 @@ __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lan
 // states arrive band by band from the span before, the end states are published band by band (skipPub = bands of the
 // first span that the fast path already published before it found a start state out of range).
 template <class SH>
-__device__ void tpv_guarded_spans(SH& sh, int sp, int nSpans, int nGroups, int spanLen, const double* inCh, double* outCh,
+__device__ void tpv_guarded_spans(SH& sh, int sp, int nSpans, int spanLen, const double* inCh, double* outCh,
                                   double* sState, const double* cf, unsigned activeMask, unsigned long long kinds, double sat,
-                                  double gain, TpvChainSlot* chainCh, unsigned long long ticket, unsigned skipPub, int tid,
-                                  int nThreads)
+                                  double gain, const unsigned long long* awaitFlags, unsigned long long* publishFlags,
+                                  unsigned long long ticket, int tid, int nThreads)
 {
-    const bool chained = nGroups > 1;
-    for (; sp < nSpans; sp += nGroups) {
+    for (; sp < nSpans; ++sp) {
+        if (awaitFlags) {                     // (staged: the span as the stage before this one left it)
+            if (tid == 0) tpv_span_await(awaitFlags + sp, ticket);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         for (int base = 0; base < spanLen; base += kTpvGuardPiece) {
             const int cnt = (spanLen - base < kTpvGuardPiece) ? spanLen - base : kTpvGuardPiece;
             const double* src = inCh + (int64_t)sp * spanLen + base;
@@ -938,37 +1023,41 @@ __device__ void tpv_guarded_spans(SH& sh, int sp, int nSpans, int nGroups, int s
                 for (unsigned m = activeMask; m; m &= m - 1) {
                     const int b = __builtin_ctz(m);
                     const int kind = (int)((kinds >> (2 * b)) & 3);
-                    if (chained && sp > 0 && base == 0)
-                        tpv_chain_get(chainCh + (int64_t)(sp - 1) * kBands + b, sState[2 * b], sState[2 * b + 1], ticket);
                     if (kind == 2)      tp_band_guarded<2>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
                     else if (kind == 1) tp_band_guarded<1>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
                     else                tp_band_guarded<0>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
-                    if (chained && base + cnt == spanLen && !((skipPub >> b) & 1))
-                        tpv_chain_put(chainCh + (int64_t)sp * kBands + b, sState[2 * b], sState[2 * b + 1], ticket);
                 }
             }
             __syncthreads();
             for (int j = tid; j < cnt; j += nThreads) dst[j] = sh.scratch[(j >> 4) * kTpStride + (j & 15)] * gain;
         }
-        skipPub = 0;
+        if (publishFlags) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) tpv_span_publish(publishFlags + sp, ticket);
+        }
     }
     __syncthreads();
 }
 
-struct TpvChain { const TpvChainSlot* prev; TpvChainSlot* cur; unsigned long long ticket; };   // slots of span - 1 / this span (or null)
+// a wave-uniform double, said to be one (two scalar registers instead of two vector registers)
+__device__ __forceinline__ double tpv_uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 // The bands of `run` (one class: CLS 0 = SVF, 3 = SVF with output v0 + m1 v1, 2 = DF-II-T) over the span held in x: per band the scan of the chunk end
 // states, then the pass.  e0 / e1: E x of the run's first band on entry, of the first band of `rest` (the bands behind
-// the run) on exit.  Returns false when a chained start state was out of the proven range (the span then restarts on the
-// guarded path; nothing has been stored).
+// the run) on exit.
 template <int CLS, bool SAT, int NT, class SH>
-__device__ __forceinline__ bool tpv_band_run(double (&x)[16], double& e0, double& e1, int& par, unsigned run, unsigned rest,
+__device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double& e1, int& par, unsigned run, unsigned rest,
                                              unsigned monoMask, SH& sh, double* sState, double* sNext, const double* __restrict__ cf,
-                                             double sat, const TpvChain& ch, unsigned& skipPub, int tid, int nThreads, const double* prefetch)
+                                             double sat, int tid, int waveU, int nThreads, const double* prefetch)
 {
-    const double oneMinusSat = 1.0 - sat;
+    const double oneMinusSat = tpv_uniform(1.0 - sat);
     const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
-    const double smallC1 = 9.0 - 8.0 * sat;
+    const double smallC1 = tpv_uniform(9.0 - 8.0 * sat);
     const TpLanePowers pw = {};                       // the per-lane powers come from LDS where tp_scan uses them
 #pragma unroll 1
     while (run) {
@@ -978,35 +1067,34 @@ __device__ __forceinline__ bool tpv_band_run(double (&x)[16], double& e0, double
         // CPQ_TPV_PREFETCH bands before the end of the span: one 4-byte load per 128-byte line pulls the workgroup's next span
         // into L2 (early enough to hide the HBM latency, late enough to still be there when the span load asks for it: issued
         // at the start of the span it doubled the kernel's HBM reads, profiles/r03e_ab_eq_prefetch.txt)
-        if (prefetch && __builtin_popcount(run | rest) == CPQ_TPV_PREFETCH - 1) (void)*reinterpret_cast<const volatile int*>(prefetch);
-        if (ch.prev && tid == 0) {
-            double sx, sy;
-            tpv_chain_get(ch.prev + b, sx, sy, ch.ticket);
-            sState[2 * b] = sx;
-            sState[2 * b + 1] = sy;
-            if (!(fabs(sx) < kTpInputBound) || !(fabs(sy) < kTpInputBound)) sh.bandBad[b] = 1;
-        }
+        if (CPQ_TPV_PREFETCH && prefetch && __builtin_popcount(run | rest) == CPQ_TPV_PREFETCH - 1)
+            (void)*reinterpret_cast<const volatile int*>(prefetch);
         double s0x, s0y;
-        tp_scan<NT>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tid, &sh.P[b][0][0]);
+#if CPQ_TPV_LAUNDER
+        // the thread index and the LDS addresses derived from it are cheap to rebuild and expensive to keep: held across the
+        // band loop they end up in scratch (the kernel sits at the 128-register limit) and every band then waits for their
+        // reloads.  Rebuilt per band from the wave number (a scalar) and the lane count, behind a value the compiler cannot
+        // see through so that it does not hoist the lot out of the loop again.
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const int tidL = (waveU << 6) + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
+#else
+        const int tidL = tid;
+#endif
+        tp_scan<NT>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tidL, &sh.P[b][0][0]);
         par ^= 1;
-        if (ch.cur) {
-            if (sh.bandBad[b]) return false;                  // written before the barrier inside tp_scan
-            if (tid == nThreads - 1) tpv_chain_put(ch.cur + b, sNext[2 * b], sNext[2 * b + 1], ch.ticket);
-            skipPub |= 1u << b;
-        }
         tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1);
     }
-    return true;
 }
 
-template <int WAVES>
-__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
-                                                                              int nSpans, int nGroups, const double* __restrict__ coef,
+template <int WAVES, bool STAGED>
+__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, (WAVES == 6 ? 3 : 4)) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
+                                                                              int nSpans, int nStages, const double* __restrict__ coef,
                                                                               const int* __restrict__ flags,
                                                                               const double* __restrict__ satGain,
                                                                               double* __restrict__ state,
                                                                               const TpBandTables* __restrict__ tables,
-                                                                              TpvChainSlot* chain, int chainSpans,
+                                                                              unsigned long long* handover,
                                                                               unsigned long long ticket, unsigned bandFilter)
 {
     constexpr int kMaxWaves = WAVES ? WAVES : 7;
@@ -1014,20 +1102,28 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
     __shared__ TpvShared<kMaxWaves> sh;
     const int tid = threadIdx.x, nThreads = WAVES ? kNT : (int)blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int c = blockIdx.x / nGroups, grp = blockIdx.x - c * nGroups;
+    // staged: blocks [stage][channel]; stage g has the bands [g, g + 1) * 20 / nStages and applies the gain if it is the last
+    const int nChGrid = STAGED ? (int)gridDim.x / nStages : (int)gridDim.x;
+    const int stage = STAGED ? (int)blockIdx.x / nChGrid : 0;
+    const int c = (int)blockIdx.x - stage * nChGrid;
+    if (STAGED) {
+        const int per = kBands / nStages;
+        bandFilter = (((1u << per) - 1u) << (stage * per)) | (stage == nStages - 1 ? kTpvApplyGain : 0u);
+    }
+    const unsigned long long* awaitFlags = (STAGED && stage > 0) ? handover + ((int64_t)c * nStages + stage - 1) * nSpans : nullptr;
+    unsigned long long* publishFlags = (STAGED && stage < nStages - 1) ? handover + ((int64_t)c * nStages + stage) * nSpans : nullptr;
     const int spanLen = nThreads * 16;
     const double* __restrict__ cf = coef + (int64_t)c * kBands * 6;
     const TpBandTables* __restrict__ tb = tables + (int64_t)(c >> 1) * kBands;
-    const double sat = satGain[c * 2], gain = (bandFilter & kTpvApplyGain) ? satGain[c * 2 + 1] : 1.0;
-    const bool chained = nGroups > 1;
-    TpvChainSlot* chainCh = chain + (int64_t)c * chainSpans * kBands;
-    const double* inCh = in + (int64_t)c * chStride;
+    const int waveU = __builtin_amdgcn_readfirstlane(wave);
+    const double sat = tpv_uniform(satGain[c * 2]), gain = tpv_uniform((bandFilter & kTpvApplyGain) ? satGain[c * 2 + 1] : 1.0);
     double* outCh = out + (int64_t)c * chStride;
+    const double* inCh = (STAGED && stage > 0) ? outCh : in + (int64_t)c * chStride;     // later stages work in place on `out`
     unsigned activeMask = 0;                                  // bit b: band b is active
     unsigned long long kinds = 0;                             // 2 bits per band: 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
     for (int b = 0; b < kBands; ++b) {
         const int f = flags[c * kBands + b];
-        activeMask |= ((unsigned)(f & 1) << b) & bandFilter;      // bandFilter: the bands of this launch (band-pipelined stages)
+        activeMask |= ((unsigned)(f & 1) << b) & bandFilter;      // bandFilter: the bands of this launch / stage
         kinds |= (unsigned long long)((f >> 1) & 3) << (2 * b);
     }
     // DF-II-T sections; SVF bands with the scalar fastTanh; SVF bands whose output is v0 + m1 v1 (every peaking band)
@@ -1037,6 +1133,12 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
         monoMask |= (unsigned)(((kinds >> (2 * b)) & 3) == 1) << b;
         peakMask |= (unsigned)(CPQ_TPV_PEAK && ((kinds >> (2 * b)) & 3) != 2 && cf[b * 6 + 3] == 1.0 && cf[b * 6 + 5] == 0.0) << b;
     }
+    // wave-uniform by construction; said so, they live in scalar registers (left in vector registers they were spilled and
+    // reloaded inside the band loop)
+    activeMask = __builtin_amdgcn_readfirstlane(activeMask);
+    dfMask = __builtin_amdgcn_readfirstlane(dfMask);
+    monoMask = __builtin_amdgcn_readfirstlane(monoMask);
+    peakMask = __builtin_amdgcn_readfirstlane(peakMask);
     double* sState = sh.stateA;
     double* sNext = sh.stateB;
     if (tid < kBands * 2) { sh.stateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sh.stateB[tid] = sh.stateA[tid]; }
@@ -1054,21 +1156,29 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
     }
     __syncthreads();
     double* buf = sh.scratch + wave * 64 * kTpvQStride;
-    unsigned skipPub = 0;
 
-    int sp = grp;
+    int sp = 0;
 #pragma unroll 1
-    for (; sp < nSpans; sp += nGroups) {
+    for (; sp < nSpans; ++sp) {
         const double* src = inCh + (int64_t)sp * spanLen + wave * 1024;
         double x[16];
-        tpv_span_load(src, buf, lane, x);
+        if (STAGED && awaitFlags) {           // the span as the stage before this one left it
+            if (tid == 0) tpv_span_await(awaitFlags + sp, ticket);
+            __syncthreads();
+#if CPQ_TPV_HL
+            tpv_span_load<true>(src, buf, lane, x);
+#else
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            tpv_span_load<false>(src, buf, lane, x);
+#endif
+        } else {
+            tpv_span_load<false>(src, buf, lane, x);
+        }
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
-        // unchained: the start states of all bands are known now; chained: they arrive band by band and are tested there
-        if (!chained || sp == 0) { if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound); }
+        if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
         if (tid == 0) sh.flag = 0;
-        if (tid < kBands) sh.bandBad[tid] = 0;
         __syncthreads();
         if (__any(bad) && lane == 0) atomicOr(&sh.flag, 1);
         __syncthreads();
@@ -1076,7 +1186,6 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
 
         // ---- the band loop: runs of one band class (an EQ channel is all SVF bands, an OutputFilter channel all DF-II-T
         // sections: one run), each in a loop body of its own
-        bool stopped = false;
         if (activeMask) {
             double e0 = 0.0, e1 = 0.0;
             {
@@ -1089,20 +1198,18 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
                 }
             }
             // the next span of this workgroup is requested into L2 while the last bands run (tpv_band_run)
-            const double* prefetch = (CPQ_TPV_PREFETCH && sp + nGroups < nSpans) ? src + (int64_t)nGroups * spanLen + lane * 16 : nullptr;
+            const double* prefetch = (CPQ_TPV_PREFETCH && !STAGED && sp + 1 < nSpans) ? src + spanLen + lane * 16 : nullptr;
             int par = 0;
             unsigned mask = activeMask;
 #pragma unroll 1
-            while (mask && !stopped) {
+            while (mask) {
                 const int bFirst = __builtin_ctz(mask);
                 const int cls = ((dfMask >> bFirst) & 1) ? 2 : (((peakMask >> bFirst) & 1) ? 3 : 0);
                 const unsigned same = mask & (cls == 2 ? dfMask : (cls == 3 ? peakMask : ~(dfMask | peakMask)));
                 const unsigned other = mask & ~same;
                 const unsigned run = other ? (same & ((other & (0u - other)) - 1u)) : same;     // bands below the first one of another class
                 const unsigned rest = mask & ~run;
-                const TpvChain ch = { chained && sp > 0 ? chainCh + (int64_t)(sp - 1) * kBands : nullptr,
-                                      chained ? chainCh + (int64_t)sp * kBands : nullptr, ticket };
-#define CPQ_RUN(CLS, SAT) stopped = !tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, ch, skipPub, tid, nThreads, prefetch)
+#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, tid, waveU, nThreads, prefetch)
                 if (cls == 2)        CPQ_RUN(2, false);
                 else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
                 else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }
@@ -1110,25 +1217,27 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
                 mask = rest;
             }
         }
-        if (stopped) break;                   // (the span's input is untouched: nothing has been stored yet)
-        skipPub = 0;
-        tpv_span_store(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
-        __syncthreads();                      // the last thread's end states are in sNext
-        if (!chained) { double* t = sState; sState = sNext; sNext = t; }
+#if CPQ_TPV_HS
+        if (STAGED && publishFlags) tpv_span_store<true>(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
+        else                        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
+#else
+        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
+        if (STAGED && publishFlags) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        __syncthreads();                      // the last thread's end states are in sNext; every wave's stores are out
+        if (STAGED && publishFlags && tid == 0) tpv_span_publish(publishFlags + sp, ticket);
+        { double* t = sState; sState = sNext; sNext = t; }
     }
-    bool slow = false;
     if (sp < nSpans) {
-        // cold: this span and the workgroup's later ones through the guarded recurrence (states advance in sState)
-        slow = true;
-        tpv_guarded_spans(sh, sp, nSpans, nGroups, spanLen, inCh, outCh, sState, cf, activeMask, kinds, sat, gain, chainCh, ticket,
-                          skipPub, tid, nThreads);
+        // cold: this span and the later ones through the guarded recurrence (states advance in sState).  The span's wait
+        // for the stage before has been done above; the guarded loop waits again, which returns at once.
+        tpv_guarded_spans(sh, sp, nSpans, spanLen, inCh, outCh, sState, cf, activeMask, kinds, sat, gain, awaitFlags,
+                          publishFlags, ticket, tid, nThreads);
     }
     __syncthreads();
-    // the call's end states: from the workgroup that ran the last span.  In sState, except after a chained fast span:
-    // there the active bands' are in sNext (inactive bands keep their state)
-    // (only this launch's bands are written: another stage may be running the other bands of the channel right now)
-    if (nSpans > 0 && (nSpans - 1) % nGroups == grp && tid < kBands * 2 && ((activeMask >> (tid >> 1)) & 1))
-        state[(int64_t)c * kBands * 2 + tid] = (chained && !slow) ? sNext[tid] : sState[tid];
+    // the call's end states (only this launch's / stage's bands are written: another stage has the other bands of the
+    // channel)
+    if (nSpans > 0 && tid < kBands * 2 && ((activeMask >> (tid >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
 }  // namespace
@@ -1149,18 +1258,17 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 namespace cpq {
 size_t svf_chain_bytes(int nCh, int maxSamples)
 {
-    return (size_t)nCh * (size_t)(maxSamples / kTpvSpan + 1) * kBands * sizeof(TpvChainSlot);
+    // hand-over words of the band-pipelined stages: [channel][stage <= 20][span]
+    return (size_t)nCh * (size_t)(maxSamples / kTpvSpan + 1) * kBands * sizeof(unsigned long long);
 }
 
 namespace {
 // Band-pipelined stages for engines whose channels alone do not fill the chip: the 20 bands are dealt to G stages, the
 // call's whole spans to N time slices, and stage g works on slice i while stage g - 1 is already on slice i + 1 -- each
 // stage a launch of its own (one workgroup per channel, `bandFilter` = its bands) on a stream of its own, ordered by
-// events: stage g of slice i behind stage g - 1 of slice i and behind stage g of slice i - 1 (same stream).  A channel's
-// band states never leave the chip's memory model: stage g owns its bands' rows of `state` and its slices run in order.
-// (N + G - 1) / (N G) of the single-stage time.  The alternative that keeps one launch -- several workgroups per channel
-// handing the band states over per band -- costs a device-scope release / acquire per band and measured slower
-// (profiles/r03b_eq_chained_spans.txt).
+// events: stage g of slice i behind stage g - 1 of slice i and behind stage g of slice i - 1 (same stream).  Stage g owns
+// its bands' rows of `state` and its slices run in order.  (N + G - 1) / (N G) of the single-stage time at best
+// (profiles/r03d_eq_stage_sweep.txt).  The same pipeline inside ONE launch is the STAGED kernel above.
 struct StagePipe {
     static constexpr int kMaxStages = 4, kMaxSlices = 16;
     hipStream_t side[kMaxStages - 1] = {};
@@ -1194,40 +1302,33 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
     // whole 8192-sample spans on the eight-wave kernel, what is left as one span of 1 ... 7 waves x 1024 samples, and a
     // last block of 512 on the chunk-length-2 path of the four-wave kernel
     const TpBandTables* tb = reinterpret_cast<const TpBandTables*>(tables);
+    constexpr unsigned kAllBands = 0xFFFFFu | kTpvApplyGain;
     int done = 0;
     const int nSpans8 = nSamples / kTpvSpan;
     if (nSpans8 > 0) {
-        // Chained spans (several workgroups per channel, the band states handed over through global memory) cost a
-        // device-scope release / acquire per band -- an L2 write-back each -- and every workgroup of a chain must be
-        // resident at once.  Measured slower than one workgroup per channel from 64 streams up and faster only below
-        // ~32 channels (profiles/r03b_eq_chained_spans.txt); off unless CPQ_SVF_CHAIN=1 (experiments).
-        int nGroups = 1;
-        static int chainOn = -1, nCu = 0;
-        if (chainOn < 0) {
-            const char* f = getenv("CPQ_SVF_CHAIN");
-            chainOn = (f && f[0] == '1') ? 1 : 0;
+        static int nCu = 0, envStages = -1, envSlices = 0;      // experiments: CPQ_SVF_STAGES=G[,N]
+        if (envStages < 0) {
             int dev = 0;
             hipDeviceProp_t prop;
             nCu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        }
-        if (chainOn == 1 && chain && ticket && nSpans8 <= chainSpans) {
-            nGroups = (3 * nCu / 2) / nCh;      // three quarters of the workgroups the chip holds at once (two per CU)
-            if (nGroups > nSpans8) nGroups = nSpans8;
-            if (nGroups < 2) nGroups = 1;
-        }
-        const unsigned long long tk = ticket ? ++*ticket : 0ull;
-        // at most half as many channels as CUs: band-pipelined stages (above).  One workgroup alone on a CU already runs at
-        // ~85 % of the rate of two sharing it, so with more channels than that there is nothing to gain.
-        static int envStages = -1, envSlices = 0;      // experiments: CPQ_SVF_STAGES=G,N
-        if (envStages < 0) {
             envStages = 0;
             if (const char* f = getenv("CPQ_SVF_STAGES")) { envStages = atoi(f); if (const char* c = strchr(f, ',')) envSlices = atoi(c + 1); }
         }
-        int nStages = (nGroups == 1 && 2 * nCh <= nCu && nSpans8 >= 16) ? 4 : 1;      // 4 stages x 16 slices measured best (profiles/r03d_eq_stage_sweep.txt)
-        if (envStages > 0 && nGroups == 1 && nSpans8 >= envStages) nStages = envStages > StagePipe::kMaxStages ? StagePipe::kMaxStages : envStages;
-        StagePipe* pipe = nStages > 1 ? stagePipe() : nullptr;
+        // At most half as many channels as CUs: band-pipelined stages.  (One workgroup alone on a CU already runs at ~85 % of
+        // the rate of two sharing it, so with more channels than that there is nothing to gain.)  By default as 4 stages x
+        // 16 time slices of event-ordered launches (StagePipe above); CPQ_SVF_STAGES=G selects the single staged launch
+        // instead, which measured no faster at any stream count (profiles/r03h_eq_staged_kernel.txt).
+        const bool inKernel = envStages > 1 && envSlices == 0 && kBands % envStages == 0 && chain && ticket && nSpans8 <= chainSpans && nSpans8 >= 2;
+        int nStages = inKernel ? envStages : 1;
+        int nSlices = 0;
+        if (!inKernel) {
+            if (envStages > 0 && envSlices > 0) { if (nSpans8 >= envStages) { nStages = envStages; nSlices = envSlices; } }
+            else if (envStages < 1 && 2 * nCh <= nCu && nSpans8 >= 16) { nStages = 4; nSlices = 16; }      // measured best (profiles/r03d_eq_stage_sweep.txt)
+        }
+        StagePipe* pipe = nSlices > 0 ? stagePipe() : nullptr;
+        if (!pipe && !inKernel) nStages = 1;
         if (pipe) {
-            int nSlices = envSlices > 0 ? envSlices : 16;
+            if (nStages > StagePipe::kMaxStages) nStages = StagePipe::kMaxStages;
             if (nSlices > StagePipe::kMaxSlices) nSlices = StagePipe::kMaxSlices;
             if (nSlices > nSpans8) nSlices = nSpans8;
             const int bandsPerStage = kBands / nStages;
@@ -1241,22 +1342,25 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
                     const unsigned filter = (((1u << bandsPerStage) - 1u) << (g * bandsPerStage)) | (g == nStages - 1 ? kTpvApplyGain : 0u);      // the channel gain goes on once, behind the last band
                     // stage 0 reads the call's input, the later stages what the stage before left in `out`
                     const double* src = (g == 0 ? in : out) + (int64_t)sp0 * kTpvSpan;
-                    hipLaunchKernelGGL(k_svf_cascade_tpv<8>, dim3(nCh), dim3(512), 0, st, src, out + (int64_t)sp0 * kTpvSpan, chStride,
-                                       sp1 - sp0, 1, coef, flags, satGain, state, tb, (TpvChainSlot*)nullptr, 0, 0ull, filter);
+                    hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, st, src, out + (int64_t)sp0 * kTpvSpan, chStride,
+                                       sp1 - sp0, 1, coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0ull, filter);
                     (void)hipEventRecord(pipe->done[g][i], st);
                 }
             }
             for (int g = 1; g < nStages; ++g) (void)hipStreamWaitEvent(stream, pipe->done[g][nSlices - 1], 0);
+        } else if (nStages > 1) {
+            hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, true>), dim3(nCh * nStages), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8,
+                               nStages, coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain), ++*ticket, kAllBands);
         } else {
-            hipLaunchKernelGGL(k_svf_cascade_tpv<8>, dim3(nCh * nGroups), dim3(512), 0, stream, in, out, chStride, nSpans8, nGroups,
-                               coef, flags, satGain, state, tb, reinterpret_cast<TpvChainSlot*>(chain), chainSpans, tk, 0xFFFFFu | kTpvApplyGain);
+            hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8, 1,
+                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0ull, kAllBands);
         }
         done = nSpans8 * kTpvSpan;
     }
     const int nWaves = (nSamples - done) / 1024;
     if (nWaves > 0) {
-        hipLaunchKernelGGL(k_svf_cascade_tpv<0>, dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, 1,
-                           coef, flags, satGain, state, tb, (TpvChainSlot*)nullptr, 0, 0ull, 0xFFFFFu | kTpvApplyGain);
+        hipLaunchKernelGGL((k_svf_cascade_tpv<0, false>), dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, 1,
+                           coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0ull, kAllBands);
         done += nWaves * 1024;
     }
     if (nSamples > done)
