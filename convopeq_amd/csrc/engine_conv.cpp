@@ -183,11 +183,11 @@ int32_t cpq_conv_set_impulse(cpq_engine* e, int32_t stream, const double* irL, c
                 const size_t callSamples = (size_t)e->tMax * e->P;
                 if (hipMalloc((void**)&e->layerOut, sizeof(double) * nTail * e->nCh * callSamples) != hipSuccess ||
                     hipMalloc((void**)&e->tailRing, sizeof(double) * (size_t)nTail * e->nCh * e->tailRingSlots) != hipSuccess ||
-                    hipMalloc(&e->tailState, 3 * sizeof(long long)) != hipSuccess ||
+                    hipMalloc(&e->tailState, 4 * sizeof(long long)) != hipSuccess ||
                     hipMalloc((void**)&e->tailSched, sizeof(long long) * 2 * ((size_t)e->tMax * e->P / e->B)) != hipSuccess)      // per tail layer and callback
                     return fail(e, CPQ_ERR_OOM, "layered-mode buffers could not be allocated");
                 CPQ_HIP(e, hipMemset(e->tailRing, 0, sizeof(double) * (size_t)nTail * e->nCh * e->tailRingSlots));
-                CPQ_HIP(e, hipMemset(e->tailState, 0, 3 * sizeof(long long)));
+                CPQ_HIP(e, hipMemset(e->tailState, 0, 4 * sizeof(long long)));
                 e->layerPlan = probe;
                 int row = 0;
                 for (int l = 0; l < probe.num_layers; ++l) {

@@ -83,7 +83,7 @@ int zeroRuntimeState(cpq_engine* e, bool conv, bool eq)
         { const int rc = resetGroups(e); if (rc != CPQ_OK) return rc; }
         for (double* p : { e->directHist[0], e->directHist[1] })
             if (p) CPQ_HIP(e, hipMemsetAsync(p, 0, sizeof(double) * 32 * e->nCh, e->stream));
-        if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 3 * sizeof(long long), e->stream));
+        if (e->tailState) CPQ_HIP(e, hipMemsetAsync(e->tailState, 0, 4 * sizeof(long long), e->stream));
         if (e->tailRing) CPQ_HIP(e, hipMemsetAsync(e->tailRing, 0, sizeof(double) * (size_t)(e->layerPlan.num_layers - 1) * e->nCh * e->tailRingSlots, e->stream));
         if (e->dryRing) CPQ_HIP(e, hipMemsetAsync(e->dryRing, 0, (size_t)e->nCh * e->dryRingSize * sizeof(double), e->stream));
         e->dryPos = 0;

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void k_ring_regrow(const double* __restrict__ 
 struct TailState {            // device-resident, zeroed by reset
     long long cb;             // callbacks (blocks of B) processed since reset
     long long R[2];           // delayReadCursor of tail layers 1, 2
+    long long g0;             // global index of the first sample of the call the schedule was last made for
 };
 
 // one thread per tail layer replays the reader for the T callbacks of this call
@@ -106,44 +107,71 @@ __global__ void k_tail_schedule(TailState* st, long long* __restrict__ sched, in
         st->R[l] = R;
     }
     __syncthreads();
-    if (l == 0) st->cb = cb0 + T;
+    if (l == 0) { st->cb = cb0 + T; st->g0 = cb0 * (long long)B; }
 }
 
-// append this call's natural-time tail outputs to the per-layer rings at (global sample index & mask); runs BEFORE
-// the schedule kernel advances the callback counter
-__global__ __launch_bounds__(256) void k_tail_append(const double* __restrict__ layerOut, double* __restrict__ ring,
-                                                     const TailState* __restrict__ st, int nSamples, int B, int ringMask)
-{
-    const int v = blockIdx.y;                      // (tail layer, channel)
-    const double* src = layerOut + (long long)v * nSamples;
-    double* dst = ring + (long long)v * (ringMask + 1);
-    const long long g0 = st->cb * (long long)B;    // global index of the call's first sample
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nSamples; i += stride)
-        dst[(g0 + i) & ringMask] = src[i];
-}
-
-__global__ __launch_bounds__(256) void k_layer_combine(double* out, const double* __restrict__ ring,
+// The reader's additions straight from this call's natural-time tail outputs where the sample it wants lies inside the
+// call (global index >= g0: all of a long call but its first output_delay or so), from the layer's ring where it is older.
+// One workgroup per (callback, channel): the callback's read positions are uniform, the samples stream through as pairs
+// (the tail streams are read as scalars: a read position may be odd).
+__global__ __launch_bounds__(256) void k_layer_combine(double* out, const double* __restrict__ layerOut,
+                                                       const double* __restrict__ ring, const TailState* __restrict__ st,
                                                        const long long* __restrict__ sched, int nCh, int nSamples,
                                                        int T, int B, int ringMask, int nTail, double g1, double g2)
 {
-    const int c = blockIdx.y;
-    double* o = out + (long long)c * nSamples;
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nSamples; i += stride) {
-        const int cbk = i / B, j = i - cbk * B;
-        double y = o[i];
-        for (int l = 0; l < nTail; ++l) {
-            const long long s = sched[(long long)l * T + cbk];
-            if (s >= 0) {
-                const double g = l == 0 ? g1 : g2;
-                const double t = ring[((long long)l * nCh + c) * (ringMask + 1) + ((s + j) & ringMask)];
-                // delayLineReadAdd: dst += src (gain within 1e-12 of 1) else dst += src * gain (:1673-1676)
-                y = (fabs(g - 1.0) < 1.0e-12) ? (y + t) : (y + t * g);
-            }
+    const int cbk = blockIdx.x, c = blockIdx.y;
+    double* o = out + (long long)c * nSamples + (long long)cbk * B;
+    const long long g0 = st->g0;
+    const long long s0 = sched[cbk], s1 = nTail > 1 ? sched[(long long)T + cbk] : -1;
+    if (s0 < 0 && s1 < 0) return;                                 // this callback reads nothing
+    const double* cur0 = layerOut + (long long)c * nSamples;
+    const double* cur1 = layerOut + ((long long)nCh + c) * nSamples;
+    const double* old0 = ring + (long long)c * (ringMask + 1);
+    const double* old1 = ring + ((long long)nCh + c) * (ringMask + 1);
+    // delayLineReadAdd: dst += src (gain within 1e-12 of 1) else dst += src * gain (:1673-1676)
+    const bool unit0 = fabs(g1 - 1.0) < 1.0e-12, unit1 = fabs(g2 - 1.0) < 1.0e-12;
+    auto tail = [&](int j, double y) {
+        if (s0 >= 0) {
+            const long long idx = s0 + j;
+            const double t = idx >= g0 ? cur0[idx - g0] : old0[idx & ringMask];
+            y = unit0 ? (y + t) : (y + t * g1);
         }
-        o[i] = y;
+        if (s1 >= 0) {
+            const long long idx = s1 + j;
+            const double t = idx >= g0 ? cur1[idx - g0] : old1[idx & ringMask];
+            y = unit1 ? (y + t) : (y + t * g2);
+        }
+        return y;
+    };
+    if ((B & 1) == 0 && (nSamples & 1) == 0) {
+        for (int j = threadIdx.x * 2; j < B; j += 512) {
+            double2 y = *reinterpret_cast<const double2*>(o + j);
+            y.x = tail(j, y.x);
+            y.y = tail(j + 1, y.y);
+            *reinterpret_cast<double2*>(o + j) = y;
+        }
+    } else {
+        for (int j = threadIdx.x; j < B; j += 256) o[j] = tail(j, o[j]);
     }
+}
+
+// what later calls may still read of this call's tail outputs goes into the per-layer rings at (global sample index &
+// mask): everything from the layer's read cursor on (the reader never steps back), at most one ring's worth.  Runs behind
+// k_layer_combine, which still reads the older contents.
+__global__ __launch_bounds__(256) void k_tail_append(const double* __restrict__ layerOut, double* __restrict__ ring,
+                                                     const TailState* __restrict__ st, int nCh, int nSamples, int ringMask)
+{
+    const int v = blockIdx.y;                      // (tail layer, channel)
+    const int l = v / nCh;
+    const double* src = layerOut + (long long)v * nSamples;
+    double* dst = ring + (long long)v * (ringMask + 1);
+    const long long g0 = st->g0;
+    long long from = st->R[l] - g0;
+    if (from < nSamples - (ringMask + 1)) from = nSamples - (ringMask + 1);
+    if (from < 0) from = 0;
+    const int stride = gridDim.x * blockDim.x;
+    for (long long i = from + blockIdx.x * blockDim.x + threadIdx.x; i < nSamples; i += stride)
+        dst[(g0 + i) & ringMask] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -538,14 +566,12 @@ void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const
 {
     const int T = nSamples / B;
     TailState* st = reinterpret_cast<TailState*>(state);
-    int bx = (nSamples + 255) / 256;
-    if (bx > 32) bx = 32;
-    hipLaunchKernelGGL(k_tail_append, dim3(bx, nCh * nTail), dim3(256), 0, stream, layerOut, ring, st, nSamples, B,
-                       ringSlots - 1);
+    // the reader's schedule for the call's callbacks, its additions, then what later calls may still read into the rings
     hipLaunchKernelGGL(k_tail_schedule, dim3(1), dim3(64), 0, stream, st, sched, T, B, nTail, make_int2(pl1, ol1),
                        make_int2(pl2, ol2), d1, d2);
-    hipLaunchKernelGGL(k_layer_combine, dim3(bx, nCh), dim3(256), 0, stream, out, ring, sched, nCh, nSamples, T, B,
+    hipLaunchKernelGGL(k_layer_combine, dim3(T, nCh), dim3(256), 0, stream, out, layerOut, ring, st, sched, nCh, nSamples, T, B,
                        ringSlots - 1, nTail, g1, g2);
+    hipLaunchKernelGGL(k_tail_append, dim3(8, nCh * nTail), dim3(256), 0, stream, layerOut, ring, st, nCh, nSamples, ringSlots - 1);
 }
 
 void launch_convproc_mix(hipStream_t stream, const double* wet, double* out, int64_t chStride, int nCh, int nSamples,
