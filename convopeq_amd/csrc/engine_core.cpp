@@ -169,8 +169,8 @@ int32_t cpq_diag_partition_fft(int32_t P, int32_t nCh, int32_t T, const double* 
     auto ok = [&](hipError_t err) { if (err != hipSuccess && rc == CPQ_OK) { (void)hipGetLastError(); rc = CPQ_ERR_DEVICE; } return err == hipSuccess; };
     ok(hipMalloc((void**)&dIn, nTime * sizeof(double))) && ok(hipMalloc((void**)&dOut, nTime * sizeof(double))) &&
         ok(hipMalloc((void**)&dHist, (size_t)2 * nCh * P * sizeof(double))) && ok(hipMalloc((void**)&dX, nSpec * sizeof(double2))) &&
-        ok(hipMalloc((void**)&dXdn, (size_t)nCh * ringSlots * sizeof(double2))) && ok(hipMalloc((void**)&dTw, (size_t)P * sizeof(double2))) &&
-        ok(hipMalloc((void**)&dTw2, (size_t)P * sizeof(double2))) &&
+        ok(hipMalloc((void**)&dXdn, (size_t)nCh * ringSlots * sizeof(double2))) && ok(hipMalloc((void**)&dTw, (size_t)2 * P * sizeof(double2))) &&
+        ok(hipMalloc((void**)&dTw2, (size_t)2 * P * sizeof(double2))) &&       // (second halves: the reordered tables of the four-step transforms)
         ok(hipMalloc((void**)&dScratch, (P > 4096 ? (size_t)nCh * T * P : 1) * sizeof(double2))) &&
         ok(hipMalloc((void**)&dY, (size_t)nCh * T * P * sizeof(double2)));
     if (rc == CPQ_OK) {
@@ -179,9 +179,15 @@ int32_t cpq_diag_partition_fft(int32_t P, int32_t nCh, int32_t T, const double* 
         ok(hipMemcpy(dIn, in, nTime * sizeof(double), hipMemcpyHostToDevice));
         ok(hipMemcpy(dTw, w1.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice));
         ok(hipMemcpy(dTw2, w2.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice));
+        if (P > 4096) {
+            std::vector<double2> wc((size_t)P), ws((size_t)P);
+            cpq::fill_big_twiddles(w1.data(), w2.data(), P, wc.data(), ws.data());
+            ok(hipMemcpy(dTw + P, wc.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice));
+            ok(hipMemcpy(dTw2 + P, ws.data(), (size_t)P * sizeof(double2), hipMemcpyHostToDevice));
+        }
     }
     if (rc == CPQ_OK) {
-        const cpq::FftTables tw{ dTw, dTw2 };
+        const cpq::FftTables tw{ dTw, dTw2, P > 4096 ? dTw + P : nullptr, P > 4096 ? dTw2 + P : nullptr };
         cpq::launch_rfft_fwd_ols(nullptr, dIn, (int64_t)T * P, dHist, dHist + (size_t)nCh * P, dX, dXdn, tw, P, nCh, T, 0, ringSlots, dScratch);
         // the ring holds block t of channel c at [c][t] of ringSlots slots: [c][t] of T slots for the inverse and the caller
         for (int c = 0; c < nCh && rc == CPQ_OK; ++c)

@@ -46,7 +46,8 @@ int allocLayer(cpq_engine* e, PlanGroup& g, NativeLayer& t, int capCh, int hSlot
     const int64_t twBytes = alignUp(t.P * (int64_t)sizeof(double2), 256);
     const int64_t gainBytes = alignUp((t.P + 1) * (int64_t)sizeof(double), 256);
     const int64_t scratchBytes = t.P > 4096 ? alignUp(std::max<int64_t>((int64_t)capCh * t.nbMax, t.K) * t.P * (int64_t)sizeof(double2), 256) : 256;
-    total += 2 * twBytes + gainBytes + scratchBytes;
+    const bool big = t.P > 4096;          // four-step transforms: + the two reordered tables (kernels.hpp: FftTables)
+    total += (big ? 4 : 2) * twBytes + gainBytes + scratchBytes;
     char* mem = nullptr;
     if (hipMalloc((void**)&mem, (size_t)total) != hipSuccess) {
         (void)hipGetLastError();
@@ -58,6 +59,8 @@ int allocLayer(cpq_engine* e, PlanGroup& g, NativeLayer& t, int capCh, int hSlot
     for (const BufItem& it : items) { *it.ptr = mem + off; off += alignUp(it.rowBytes * (it.perSlot ? hSlots : capCh), 256); }
     t.tw = (double2*)(mem + off); off += twBytes;
     t.tw2 = (double2*)(mem + off); off += twBytes;
+    t.twCol = t.twSplit = nullptr;
+    if (big) { t.twCol = (double2*)(mem + off); off += twBytes; t.twSplit = (double2*)(mem + off); off += twBytes; }
     t.gainDev = (double*)(mem + off); off += gainBytes;
     t.scratch = (double2*)(mem + off);
     t.mem = mem;
@@ -72,6 +75,12 @@ int allocLayer(cpq_engine* e, PlanGroup& g, NativeLayer& t, int capCh, int hSlot
     CPQ_HIP(e, hipStreamSynchronize(e->stream));
     CPQ_HIP(e, hipMemcpy(t.tw, w.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
     CPQ_HIP(e, hipMemcpy(t.tw2, w2.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
+    if (big) {
+        std::vector<double2> wc(t.P), ws(t.P);
+        cpq::fill_big_twiddles(w.data(), w2.data(), t.P, wc.data(), ws.data());
+        CPQ_HIP(e, hipMemcpy(t.twCol, wc.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
+        CPQ_HIP(e, hipMemcpy(t.twSplit, ws.data(), t.P * sizeof(double2), hipMemcpyHostToDevice));
+    }
     (void)g;
     return CPQ_OK;
 }
@@ -476,7 +485,7 @@ int nativeSetImpulse(cpq_engine* e, int stream, const double* irL, const double*
             CPQ_HIP(e, hipMemsetAsync(Ht, 0, (size_t)t.hRows * t.P * sizeof(double2), e->stream));
             CPQ_HIP(e, hipMemsetAsync(HDNt, 0, (size_t)t.hRows * sizeof(double2), e->stream));
             CPQ_HIP(e, hipMemcpyAsync(e->heffDev, seg.data(), seg.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-            cpq::launch_ir_spectra(e->stream, e->heffDev, (int)seg.size(), Ht, HDNt, cpq::FftTables{ t.tw, t.tw2 }, t.P, t.K, t.scratch);
+            cpq::launch_ir_spectra(e->stream, e->heffDev, (int)seg.size(), Ht, HDNt, cpq::FftTables{ t.tw, t.tw2, t.twCol, t.twSplit }, t.P, t.K, t.scratch);
             if (spec) {
                 cpq::spectrumFilterGains(*spec, 2 * t.P, gains);
                 CPQ_HIP(e, hipMemcpyAsync(t.gainDev, gains.data(), gains.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -597,7 +606,7 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
     const int rem = total - nb * t.P;
     const int nCh = g.usedCh;
     if (nb > 0) {
-        const cpq::FftTables tw{ t.tw, t.tw2 };
+        const cpq::FftTables tw{ t.tw, t.tw2, t.twCol, t.twSplit };
         {
             ProfScope p(e, CPQ_K_RFFT_FWD);
             cpq::launch_rfft_fwd_ols(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN, tw,

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(512) void k_big_cols_fwd(const double* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int k1 = j + q * stride;
-        a[k1 * 512 + n2] = cmulw<false>(dyn[k1 * kBigCols + col], tw.tw512[n2 * k1]);       // W_M^(n2 k1)
+        a[k1 * 512 + n2] = cmulw<false>(dyn[k1 * kBigCols + col], tw.twCol[k1 * 512 + n2]);       // W_M^(n2 k1)
     }
 }
 
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(128) void k_big_rows_fwd(const double2* __restrict_
         const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
         const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
         const double2 o = make_double2(d.y, -d.x);
-        const double2 wk = tw.tw1024[krow + M1 * k2];
+        const double2 wk = tw.twSplit[krow * 512 + k2];
         double2 xk = make_double2(e.x + fma(o.x, wk.x, -(o.y * wk.y)), e.y + fma(o.x, wk.y, o.y * wk.x));
         if (krow == 0 && k2 == 0) {
             xk = make_double2(zk.x + zk.y, zk.x - zk.y);   // (DC, Nyquist)
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict_
         const double2 yp = ym[krow == 0 ? ((512 - k2) & 511) : (511 - k2)];
         const double2 e = make_double2(0.5 * (yk.x + yp.x), 0.5 * (yk.y - yp.y));
         const double2 d = make_double2(0.5 * (yk.x - yp.x), 0.5 * (yk.y + yp.y));
-        const double2 wk = tw.tw1024[krow + M1 * k2];
+        const double2 wk = tw.twSplit[krow * 512 + k2];
         const double2 o = make_double2(fma(d.x, wk.x, d.y * wk.y), fma(d.y, wk.x, -(d.x * wk.y)));   // d * conj(w)
         double2 z = make_double2(e.x - o.y, e.y + o.x);
         if (krow == 0 && k2 == 0) z = make_double2(0.5 * (y0.x + y0.y), 0.5 * (y0.x - y0.y));
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict_
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n2 = lane + 64 * r;
-        a[n2] = cmulw<true>(v[r], tw.tw512[n2 * krow]);
+        a[n2] = cmulw<true>(v[r], tw.twCol[krow * 512 + n2]);
     }
 }
 
@@ -1002,6 +1002,18 @@ __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict_
         }
     }
 }
+
+}  // namespace
+void fill_big_twiddles(const double2* tw512, const double2* tw1024, int P, double2* twCol, double2* twSplit)
+{
+    const int M1 = P >> 9;
+    for (int k1 = 0; k1 < M1; ++k1)
+        for (int n = 0; n < 512; ++n) {
+            twCol[k1 * 512 + n] = tw512[n * k1];
+            twSplit[k1 * 512 + n] = tw1024[k1 + M1 * n];
+        }
+}
+namespace {
 
 // H[k][bin] *= gain[bin] for the IR partition spectra of one IR slot (the HC/LC spectral shaping of a non-NULL
 // FilterSpec, src/MKLNonUniformConvolver.cpp:433-441); packed bin 0 = (DC * gain[0], Nyquist * gain[P])

@@ -18,7 +18,13 @@ constexpr int kBands = 20;
 struct FftTables {
     const double2* tw512;    // exp(-2 pi i m / P),  m < P   (P = partition size; 512 in the headline config)
     const double2* tw1024;   // exp(-2 pi i k / 2P), k < P
+    // P > 4096 (four-step transforms, P = M1 * 512): the same values in the order the passes walk them, so that a wave reads
+    // 64 consecutive entries instead of 64 cache lines (fill_big_twiddles):
+    const double2* twCol = nullptr;     // [k1][n2] = tw512[n2 k1]         (column-pass twiddle W_P^(n2 k1))
+    const double2* twSplit = nullptr;   // [k1][k2] = tw1024[k1 + M1 k2]   (real-FFT split of bin k1 + M1 k2)
 };
+// host: the two reordered tables of P entries each from tw512 / tw1024 (P > 4096)
+void fill_big_twiddles(const double2* tw512, const double2* tw1024, int P, double2* twCol, double2* twSplit);
 
 // Overlap-save framing + 1024-point real FFT of T blocks per channel into the frequency-domain delay
 // line (FDL) ring; also saves the last block as the next call's overlap history.

@@ -309,6 +309,9 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 // 7 operations per sample instead of 10).  Both band kinds share it.
 // ORDER 2: one second-order step instead (r (1 + e): relative error e^2 <= 2.2e-15 in r, <= 0.4 ... 2 e-15 in the result
 // for sat = 0.2 ... 1 -- the size of the other rounding errors of a band; one operation less).
+#ifndef CPQ_TP_BATCH_RCP
+#define CPQ_TP_BATCH_RCP 1      // one v_rcp_f64 per four samples in the small-signal output stage (A/B: tools/ab_tpv.sh)
+#endif
 template <int N, int ORDER = 3>
 __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 {
@@ -316,6 +319,23 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
     double den[N], r[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) den[j] = fma(y[j], y[j], 3.0);
+#if CPQ_TP_BATCH_RCP
+    if (N == 4 && ORDER == 2) {
+        // one reciprocal for the four denominators (v_rcp_f64 issues at a quarter of the FMA rate): 1 / (d0 d1 d2 d3),
+        // refined once, then multiplied back apart -- 27 issue slots for four samples instead of 36.  The denominators
+        // lie in [3, 3 + bound^2]: no over- or underflow in the products.
+        const double p01 = den[0] * den[1], p23 = den[2 % N] * den[3 % N];
+        const double pp = p01 * p23;
+        double q = __builtin_amdgcn_rcp(pp);
+        q = fma(fma(-pp, q, 1.0), q, q);
+        const double q01 = q * p23, q23 = q * p01;
+        y[0] *= fma(cb, q01 * den[1], ca);
+        y[1] *= fma(cb, q01 * den[0], ca);
+        y[2 % N] *= fma(cb, q23 * den[3 % N], ca);
+        y[3 % N] *= fma(cb, q23 * den[2 % N], ca);
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < N; ++j) r[j] = __builtin_amdgcn_rcp(den[j]);
 #pragma unroll
