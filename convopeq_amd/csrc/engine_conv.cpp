@@ -73,24 +73,39 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
         return CPQ_OK;
     }
     if (e->mainActive) {
-        {
-            ProfScope p(e, CPQ_K_RFFT_FWD);
-            cpq::launch_rfft_fwd_ols(e->stream, dIn, stride, e->hist[e->histSel], e->hist[e->histSel ^ 1], e->X, e->XDN,
-                                     tables(e), e->P, e->nCh, T, e->head, e->ringSlots);
-        }
-        {
-            ProfScope p(e, CPQ_K_FDL_MAC);
-            cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H, e->irSlot, e->Y, e->P, e->nCh,
-                                e->kMaxReal, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
-        }
-        if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {      // the cooperative kernel produces the packed (DC, Nyquist) bin itself
-            ProfScope p(e, CPQ_K_DCNYQ);
-            cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN, e->irSlot, e->Y, e->P, e->nCh, e->kMaxReal, e->ringSlots,
-                                      e->head, T, e->hRows);
-        }
-        {
-            ProfScope p(e, CPQ_K_RFFT_INV);
-            cpq::launch_rfft_inv_ols(e->stream, e->Y, dOut, stride, tables(e), e->P, e->nCh, T);
+        // the channels [c0, c0 + cnt): every buffer of the path is [channel][...]
+        auto window = [&](int c0, int cnt) {
+            const int64_t ring = (int64_t)c0 * e->ringSlots;
+            {
+                ProfScope p(e, CPQ_K_RFFT_FWD);
+                cpq::launch_rfft_fwd_ols(e->stream, dIn + c0 * stride, stride, e->hist[e->histSel] + (int64_t)c0 * e->P,
+                                         e->hist[e->histSel ^ 1] + (int64_t)c0 * e->P, e->X + ring * e->P, e->XDN + ring,
+                                         tables(e), e->P, cnt, T, e->head, e->ringSlots);
+            }
+            double2* y = e->Y + (int64_t)c0 * T * e->P;
+            {
+                ProfScope p(e, CPQ_K_FDL_MAC);
+                cpq::launch_fdl_mac(e->stream, e->macTile, e->X + ring * e->P, e->H, e->irSlot + c0, y, e->P, cnt,
+                                    e->kMaxReal, e->ringSlots, e->head, T, (int64_t)e->hRows * e->P, e->irPrivate);
+            }
+            if (cpq::fdl_mac_needs_dcnyq(e->macTile, T)) {      // the cooperative kernel produces the packed (DC, Nyquist) bin itself
+                ProfScope p(e, CPQ_K_DCNYQ);
+                cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN + ring, e->HDN, e->irSlot + c0, y, e->P, cnt, e->kMaxReal, e->ringSlots,
+                                          e->head, T, e->hRows);
+            }
+            {
+                ProfScope p(e, CPQ_K_RFFT_INV);
+                cpq::launch_rfft_inv_ols(e->stream, y, dOut + c0 * stride, stride, tables(e), e->P, cnt, T);
+            }
+        };
+        if (e->ovl.armed && e->groups.empty()) {
+            // two halves, so that the EQ of the first can start beside the convolution of the second (Overlap, engine_internal.hpp)
+            window(0, e->ovl.c0);
+            CPQ_HIP(e, hipEventRecord(e->ovl.convA, e->stream));
+            window(e->ovl.c0, e->nCh - e->ovl.c0);
+            e->ovl.convSplit = true;
+        } else {
+            window(0, e->nCh);
         }
         CPQ_HIP(e, hipGetLastError());
         e->head = (e->head + T) & (e->ringSlots - 1);

@@ -428,6 +428,9 @@ void cpq_engine_destroy(cpq_engine* e)
     }
     freeGroups(e);
     freePinnedRing(e);
+    if (e->ovl.side) (void)hipStreamDestroy(e->ovl.side);
+    if (e->ovl.convA) (void)hipEventDestroy(e->ovl.convA);
+    if (e->ovl.eqA) (void)hipEventDestroy(e->ovl.eqA);
     if (e->copyIn) {
         (void)hipStreamDestroy(e->copyIn);
         (void)hipStreamDestroy(e->copyOut);
@@ -545,9 +548,47 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order)
 
 
 // ------------------------------------------------------------------------ whole path
+// Does this call go through in two halves (Overlap, engine_internal.hpp)?  Only the plain configuration: kernel-level
+// convolver on the uniform path, then the EQ on the time-parallel kernels with nothing else between or beside them, long
+// calls, and enough channels that half of them still give every CU a workgroup of the cascade (which also keeps the cascade
+// off its band-pipelined stages, whose streams and events are per device).
+static bool overlapQualifies(cpq_engine* e, int n)
+{
+    auto& o = e->ovl;
+    // off unless CPQ_OVERLAP=1: measured SLOWER (11.8 against 10.5 ms per call of 256 streams, profiles/r03l_conv_eq_overlap.txt) --
+    // both sides need all four wave slots of a SIMD (128 registers each) for their own throughput, and sharing a CU halves both
+    if (o.enabled < 0) { const char* f = getenv("CPQ_OVERLAP"); o.enabled = (f && f[0] == '1') ? 1 : 0; }
+    if (!o.enabled) return false;
+    if (e->order != CPQ_ORDER_CONV_THEN_EQ || e->convBypassed || e->convLevel == CPQ_LEVEL_PROCESSOR) return false;
+    if (!e->mainActive || !e->groups.empty() || e->layered || e->anyDirect) return false;
+    if (e->anyAgc || e->anyEqBypass || e->anyEqReset || e->eqMode != CPQ_EQ_MODE_AUTO) return false;
+    for (char s : e->eqTpSafe) if (!s) return false;
+    for (char m : e->eqMidSide) if (m) return false;
+    for (size_t s = 0; s < e->gainRamp.size(); ++s) {
+        const auto& g = e->gainRamp[s];
+        if (!e->agcOnHost[s] && (g.remaining > 0 || std::fabs(g.target - g.wanted) > 1e-6 || g.current != g.wanted)) return false;
+    }
+    int nCu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) nCu = prop.multiProcessorCount; else (void)hipGetLastError(); }
+    if (e->nCh < 2 * nCu || (e->nCh & 3) || (n & 1) || n < 16 * 8192) return false;
+    if (!o.side) {
+        if (hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&o.convA, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&o.eqA, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            o.enabled = 0;
+            return false;
+        }
+    }
+    return true;
+}
+
 static int enqueueBoth(cpq_engine* e, const double* a, double* b, int n)
 {
     int rc = CPQ_OK;
+    struct Disarm { cpq_engine* e; ~Disarm() { e->ovl.armed = false; e->ovl.convSplit = false; } } disarm{ e };      // the kernel-level entry points never split
+    e->ovl.convSplit = false;
+    e->ovl.armed = overlapQualifies(e, n);
+    if (e->ovl.armed) { e->ovl.c0 = (e->nCh / 2) & ~1; e->ovl.uploadSeqAtArm = e->uploadSeq; }
     auto conv = [e](const double* x, double* y, int t) {
         return e->convLevel == CPQ_LEVEL_PROCESSOR ? enqueueConvProc(e, x, y, t) : enqueueConv(e, x, y, t);
     };

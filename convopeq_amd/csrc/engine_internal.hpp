@@ -144,6 +144,19 @@ struct cpq_engine {
     double* ofTp = nullptr;     // [streams][20][kSvfTpTableDoubles]
     void* svfChain = nullptr;   // [channels][<= 20 stages][svfChainSpans] hand-over words of the band-pipelined stages (time-parallel cascade), or none
     int svfChainSpans = 0;
+    // Two-half overlap of a call (engine_core.cpp: enqueueBoth): the convolver's kernels are HBM-bound, the EQ cascade is
+    // fp64-issue bound, so the call's channels go through in two halves -- conv(A), conv(B) on the engine's stream, EQ(A) on
+    // a side stream behind conv(A) and next to conv(B), EQ(B) behind conv(B) -- and the stream joins at the end of the EQ.
+    struct Overlap {
+        hipStream_t side = nullptr;
+        hipEvent_t convA = nullptr, eqA = nullptr;
+        bool armed = false;          // this call qualifies (decided in enqueueBoth)
+        bool convSplit = false;      // the convolver ran in two halves and recorded convA
+        int c0 = 0;                  // first channel of the second half (even: whole streams)
+        unsigned long long uploadSeqAtArm = 0;
+        int enabled = -1;            // CPQ_OVERLAP=1 (default off: measured slower, see overlapQualifies)
+    } ovl;
+    unsigned long long uploadSeq = 0;   // staged uploads so far (they are ordered on the engine's stream only)
     unsigned long long svfTicket = 0;   // one per time-parallel launch: marks the slots that launch wrote
     bool ofSet = false, ofTpSafe = true, ofInPath = false;
 
@@ -293,6 +306,13 @@ int fail(cpq_engine* e, int code, const char* fmt, ...);
 int nextPow2(int v);
 int64_t alignUp(int64_t v, int64_t a);
 cpq::FftTables tables(const cpq_engine* e);
+
+// the engine's launches go to another stream while one of these is alive (declare it BEFORE the ProfScope it should cover)
+struct StreamOverride {
+    cpq_engine* e; hipStream_t saved;
+    StreamOverride(cpq_engine* eng, hipStream_t s) : e(eng), saved(eng->stream) { e->stream = s; }
+    ~StreamOverride() { e->stream = saved; }
+};
 
 struct ProfScope {
     cpq_engine* e;

@@ -235,6 +235,7 @@ int zeroPairState(cpq_engine* e, PlanGroup& g, int pair)
 int stageUpload(cpq_engine* e, void* dst, const void* src, size_t bytes)
 {
     if (bytes == 0) return CPQ_OK;
+    ++e->uploadSeq;
     PinnedRing& r = e->pinned;
     if (!r.host) {
         r.cap = (size_t)8 << 20;

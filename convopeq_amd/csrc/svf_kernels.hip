@@ -818,6 +818,9 @@ __device__ __forceinline__ void tpv_span_await(const unsigned long long* flag, u
 #ifndef CPQ_TPV_PEAK
 #define CPQ_TPV_PEAK 1
 #endif
+#ifndef CPQ_TPV_RARE_UNROLLED
+#define CPQ_TPV_RARE_UNROLLED 0
+#endif
 #ifndef CPQ_TPV_HL
 #define CPQ_TPV_HL 1
 #endif
@@ -901,6 +904,17 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
             done = true;
         } else {
             // rare: a sample at or above the fastTanh clip threshold somewhere in the wave
+#if CPQ_TPV_RARE_UNROLLED
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                double v[4] = { x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3] };
+                if (mono) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
+                else      tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[4 * h + j] = v[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
 #pragma unroll 1
             for (int h = 0; h < 4; ++h) {
                 // rotate instead of indexing: x stays in registers
@@ -912,6 +926,7 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[12 + j] = v[j];
             }
+#endif
         }
     }
     if (!done) {
