@@ -48,7 +48,7 @@ struct NativeLayer {
     long long wPos = 0, rPos = 0;
     char* mem = nullptr;
     double2 *X = nullptr, *XDN = nullptr, *H = nullptr, *HDN = nullptr, *Y = nullptr, *tw = nullptr, *tw2 = nullptr, *twCol = nullptr, *twSplit = nullptr;
-    double *hist[2] = { nullptr, nullptr }, *acc[2] = { nullptr, nullptr }, *z = nullptr, *ring = nullptr, *gainDev = nullptr;
+    double *hist[2] = { nullptr, nullptr }, *acc[2] = { nullptr, nullptr }, *ring = nullptr, *gainDev = nullptr;
     double2* scratch = nullptr;   // four-step FFT workspace (P > 4096): [max(nCh * nbMax, K)][P]
 };
 

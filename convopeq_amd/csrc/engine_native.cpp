@@ -33,7 +33,6 @@ std::vector<BufItem> layerItems(NativeLayer& t)
         { (void**)&t.hist[1], (int64_t)t.P * (int64_t)sizeof(double), false },
         { (void**)&t.acc[0], (int64_t)t.accCap * (int64_t)sizeof(double), false },
         { (void**)&t.acc[1], (int64_t)t.accCap * (int64_t)sizeof(double), false },
-        { (void**)&t.z, (int64_t)t.nbMax * t.P * (int64_t)sizeof(double), false },
         { (void**)&t.ring, (int64_t)t.outRing * (int64_t)sizeof(double), false },
     };
 }
@@ -623,14 +622,14 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
             cpq::launch_fdl_mac_dcnyq(e->stream, t.XDN, t.HDN, g.irSlotDev, t.Y, t.P, nCh, t.K, t.ringSlots, t.head, nb, t.hRows);
         }
         {
+            // the finished blocks go where the reference puts them: layer 0 straight to the members' output rows (directOut:
+            // the output ring is passed by -- read and write positions advanced together on the host), otherwise into the
+            // layer's output ring / delay line at the replayed positions, written by the transform itself
             ProfScope p(e, CPQ_K_RFFT_INV);
             if (directOut) cpq::launch_rfft_inv_ols(e->stream, t.Y, directOut, (int64_t)n, tw, t.P, nCh, nb, t.scratch);
-            else           cpq::launch_rfft_inv_ols(e->stream, t.Y, t.z, (int64_t)t.nbMax * t.P, tw, t.P, nCh, nb, t.scratch);
+            else           cpq::launch_rfft_inv_ols_ring(e->stream, t.Y, t.ring, t.outRing, putPos, ringPos0, tw, t.P, nCh, nb, t.scratch);
         }
         ProfScope p(e, CPQ_K_MIX);
-        if (directOut) { /* nothing to store: the ring stays empty (read and write positions advanced together on the host) */ }
-        else if (putPos) cpq::launch_ring_put_blocks(e->stream, t.z, (int64_t)t.nbMax * t.P, t.P, nb, t.ring, t.outRing, putPos, nCh);
-        else cpq::launch_ring_put(e->stream, t.z, (int64_t)t.nbMax * t.P, nb * t.P, t.ring, t.outRing, ringPos0, nCh);
         cpq::launch_rows_copy(e->stream, t.acc[t.accSel], t.accCap, (int64_t)nb * t.P, t.acc[t.accSel ^ 1], t.accCap, 0, rem, nCh);
         t.head = (t.head + nb) & (t.ringSlots - 1);
         t.histSel ^= 1;

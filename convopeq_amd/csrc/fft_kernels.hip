@@ -225,8 +225,26 @@ __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ he
     wave_split_store(v, lds, wl, lane, H + (int64_t)k * kP, HDN + k);
 }
 
+// Where an inverse transform puts block t of channel c: the call's output rows, or (RING) a per-channel ring at the position
+// the block has there -- pos[t], or pos0 + t P when pos is null; a negative position drops the block (ringWrite /
+// delayLineWrite of the plan groups, src/MKLNonUniformConvolver.cpp:1341-1371, :1639-1648, fused into the transform's
+// stores).  i = even sample index inside the block.
+struct RingOut { double* ring; int mask; const long long* pos; long long pos0; };
+template <bool RING>
+__device__ __forceinline__ void store_block2(double* out, int64_t chStride, const RingOut& ro, int c, int t, int P, int i, double2 v)
+{
+    if (!RING) { *reinterpret_cast<double2*>(out + (int64_t)c * chStride + (int64_t)t * P + i) = v; return; }
+    const long long p = ro.pos ? ro.pos[t] : ro.pos0 + (long long)t * P;
+    if (p < 0) return;
+    double* r = ro.ring + (int64_t)c * (ro.mask + 1);
+    const long long a = p + i;
+    if ((p & 1) == 0) *reinterpret_cast<double2*>(r + (a & ro.mask)) = v;
+    else { r[a & ro.mask] = v.x; r[(a + 1) & ro.mask] = v.y; }
+}
+
+template <bool RING>
 __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__ Y, double* __restrict__ out,
-                                                     int64_t chStride, FftTables tw, int T)
+                                                     int64_t chStride, FftTables tw, int T, RingOut ro)
 {
     __shared__ double2 lds[kLdsPerWave];
     const int lane = threadIdx.x;
@@ -252,11 +270,10 @@ __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__
     }
     wave_cfft512<true>(v, lds, lane, wa, wb);
     // second half of the 1024-sample frame: z[n], n = lane + 64 r, r = 4..7  (NUC.cpp:1332)
-    double* o = out + (int64_t)c * chStride + (int64_t)t * kP;
     constexpr double s = 1.0 / 512.0;
 #pragma unroll
     for (int r = 4; r < 8; ++r)
-        *reinterpret_cast<double2*>(o + 2 * (lane + 64 * (r - 4))) = make_double2(v[r].x * s, v[r].y * s);
+        store_block2<RING>(out, chStride, ro, c, t, kP, 2 * (lane + 64 * (r - 4)), make_double2(v[r].x * s, v[r].y * s));
 }
 
 
@@ -355,8 +372,9 @@ __global__ __launch_bounds__(256) void k_ir_spectra_generic(const double* __rest
     split_store_generic(Z, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
 }
 
+template <bool RING>
 __global__ __launch_bounds__(256) void k_rfft_inv_ols_generic(const double2* __restrict__ Y, double* __restrict__ out,
-                                                              int64_t chStride, FftTables tw, int P, int T)
+                                                              int64_t chStride, FftTables tw, int P, int T, RingOut ro)
 {
     extern __shared__ double2 dyn[];
     double2* a = dyn;
@@ -378,11 +396,10 @@ __global__ __launch_bounds__(256) void k_rfft_inv_ols_generic(const double2* __r
     }
     __syncthreads();
     const double2* z = stockham<true>(a, b, P, tw.tw512);
-    double* o = out + (int64_t)c * chStride + (int64_t)t * P;
     const double s = 1.0 / (double)P;
     const int halfP = P >> 1;
     for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)      // second half of the 2P-sample frame
-        *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(z[n].x * s, z[n].y * s);
+        store_block2<RING>(out, chStride, ro, c, t, P, 2 * (n - halfP), make_double2(z[n].x * s, z[n].y * s));
 }
 
 }  // namespace
@@ -521,8 +538,9 @@ __global__ __launch_bounds__(512) void k_ir_spectra_wg(const double* __restrict_
     split_store_wg(dyn, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
 }
 
+template <bool RING>
 __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restrict__ Y, double* __restrict__ out,
-                                                         int64_t chStride, FftTables tw, int P, int T)
+                                                         int64_t chStride, FftTables tw, int P, int T, RingOut ro)
 {
     extern __shared__ double2 dyn[];
     const int c = blockIdx.x / T;
@@ -542,11 +560,10 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
     }
     __syncthreads();
     wg_cfft<true>(dyn, P, tw.tw512);
-    double* o = out + (int64_t)c * chStride + (int64_t)t * P;
     const double s = 1.0 / (double)P;
     const int halfP = P >> 1;
     for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)
-        *reinterpret_cast<double2*>(o + 2 * (n - halfP)) = make_double2(dyn[wgp(n)].x * s, dyn[wgp(n)].y * s);
+        store_block2<RING>(out, chStride, ro, c, t, P, 2 * (n - halfP), make_double2(dyn[wgp(n)].x * s, dyn[wgp(n)].y * s));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -699,8 +716,9 @@ __global__ __launch_bounds__(512, 4) void k_ir_spectra_p4(const double* __restri
     p4_forward_frame(v, dyn, &tabs, wk, H + (int64_t)k * kP4, HDN + k);
 }
 
+template <bool RING>
 __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __restrict__ Y, double* __restrict__ out,
-                                                          int64_t chStride, FftTables tw, int T, int split)
+                                                          int64_t chStride, FftTables tw, int T, int split, RingOut ro)
 {
     extern __shared__ double2 dyn[];
     __shared__ P4Tables tabs;
@@ -752,11 +770,17 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
         p4_twiddle<true>(v, &tabs, j);
         dft8<true>(v);
         // second half of the 8192-sample frame: x[n], n = j + 512 n1, n1 = 4..7 (NUC.cpp:1332)
-        double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
         constexpr double s = 1.0 / (double)kP4;
+        if (RING) {
 #pragma unroll
-        for (int q = 4; q < 8; ++q)
-            *reinterpret_cast<double2*>(o + 2 * (j + 512 * (q - 4))) = make_double2(v[q].x * s, v[q].y * s);
+            for (int q = 4; q < 8; ++q)
+                store_block2<true>(out, chStride, ro, c, t, kP4, 2 * (j + 512 * (q - 4)), make_double2(v[q].x * s, v[q].y * s));
+        } else {
+            double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
+#pragma unroll
+            for (int q = 4; q < 8; ++q)
+                *reinterpret_cast<double2*>(o + 2 * (j + 512 * (q - 4))) = make_double2(v[q].x * s, v[q].y * s);
+        }
     }
 }
 
@@ -973,8 +997,9 @@ __global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict_
 }
 
 // inverse column pass: M1-point inverse FFT over k1 per column, second half of the frame (n1 >= M1 / 2) to out, 1/M
+template <bool RING>
 __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict__ A, double* __restrict__ out,
-                                                      int64_t chStride, FftTables tw, int P, int T)
+                                                      int64_t chStride, FftTables tw, int P, int T, RingOut ro)
 {
     extern __shared__ double2 dyn[];
     const int M1 = P >> 9;
@@ -989,7 +1014,6 @@ __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict_
     for (int q = 0; q < 8; ++q) v[q] = a[(j + q * stride) * 512 + n2];
     col_fft<true>(v, dyn, M1, tw.tw512, j, col, kBigCols);
     const int c = tr / T, t = tr - c * T;
-    double* o = out + (int64_t)c * chStride + (int64_t)t * P;
     const double s = 1.0 / (double)P;
     const int halfM = P >> 1;
 #pragma unroll
@@ -998,7 +1022,7 @@ __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict_
         if (n1 >= (M1 >> 1)) {
             const double2 z = dyn[n1 * kBigCols + col];
             const int n = n1 * 512 + n2;
-            *reinterpret_cast<double2*>(o + 2 * (n - halfM)) = make_double2(z.x * s, z.y * s);
+            store_block2<RING>(out, chStride, ro, c, t, P, 2 * (n - halfM), make_double2(z.x * s, z.y * s));
         }
     }
 }
@@ -1115,30 +1139,45 @@ void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const do
     hipLaunchKernelGGL(k_spectrum_gain, dim3(nParts), dim3(256), 0, stream, H, HDN, gain, P);
 }
 
-void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P,
-                         int nCh, int T, double2* scratch)
+namespace {
+template <bool RING>
+void launch_inv(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P, int nCh, int T,
+                double2* scratch, RingOut ro)
 {
     if (P > 4096) {         // scratch [nCh * T][P]
         const int M1 = P >> 9;
         hipLaunchKernelGGL(k_big_rows_inv, dim3(nCh * T * ((M1 >> 1) + 1)), dim3(128), 0, stream, Y, scratch, tw, P);
-        hipLaunchKernelGGL(k_big_cols_inv, dim3(nCh * T * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2), stream,
-                           scratch, out, chStride, tw, P, T);
+        hipLaunchKernelGGL(k_big_cols_inv<RING>, dim3(nCh * T * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2), stream,
+                           scratch, out, chStride, tw, P, T, ro);
         return;
     }
     if (P == kP)
-        hipLaunchKernelGGL(k_rfft_inv_ols, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T);
+        hipLaunchKernelGGL(k_rfft_inv_ols<RING>, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T, ro);
     else if (P == kP4) {
         const int split = p4Split(nCh, T);
-        allowLargeLds(k_rfft_inv_ols_p4, wgLdsBytes(P));
-        hipLaunchKernelGGL(k_rfft_inv_ols_p4, dim3(nCh * split), dim3(512), wgLdsBytes(P), stream, Y, out, chStride, tw, T,
-                           split);
+        allowLargeLds(k_rfft_inv_ols_p4<RING>, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_inv_ols_p4<RING>, dim3(nCh * split), dim3(512), wgLdsBytes(P), stream, Y, out, chStride, tw, T,
+                           split, ro);
     } else if (P >= 1024) {
-        allowLargeLds(k_rfft_inv_ols_wg, wgLdsBytes(P));
-        hipLaunchKernelGGL(k_rfft_inv_ols_wg, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, Y, out, chStride,
-                           tw, P, T);
+        allowLargeLds(k_rfft_inv_ols_wg<RING>, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_inv_ols_wg<RING>, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, Y, out, chStride,
+                           tw, P, T, ro);
     } else
-        hipLaunchKernelGGL(k_rfft_inv_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
-                           stream, Y, out, chStride, tw, P, T);
+        hipLaunchKernelGGL(k_rfft_inv_ols_generic<RING>, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
+                           stream, Y, out, chStride, tw, P, T, ro);
+}
+}  // namespace
+
+void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P,
+                         int nCh, int T, double2* scratch)
+{
+    launch_inv<false>(stream, Y, out, chStride, tw, P, nCh, T, scratch, RingOut{});
+}
+
+void launch_rfft_inv_ols_ring(hipStream_t stream, const double2* Y, double* ring, int ringSize, const long long* pos,
+                              long long pos0, FftTables tw, int P, int nCh, int T, double2* scratch)
+{
+    launch_inv<true>(stream, Y, nullptr, 0, tw, P, nCh, T, scratch, RingOut{ ring, ringSize - 1, pos, pos0 });
 }
 
 }  // namespace cpq

@@ -59,6 +59,11 @@ void launch_fdl_mac_dcnyq(hipStream_t stream, const double2* XDN, const double2*
 // then stored permuted (element k1 * 512 + k2 = bin k1 + (P / 512) k2), consistently in all three launchers.
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw,
                          int P, int nCh, int T, double2* scratch = nullptr);
+// The same transform with its result stored straight into per-channel rings: block t of channel c at ring[c][(p_t + i) &
+// (ringSize - 1)], p_t = pos[t] (device table; negative: the block is dropped) or pos0 + t P when pos is null -- the
+// output-ring / delay-line write of a plan-group layer without the pass over the blocks in between.
+void launch_rfft_inv_ols_ring(hipStream_t stream, const double2* Y, double* ring, int ringSize, const long long* pos,
+                              long long pos0, FftTables tw, int P, int nCh, int T, double2* scratch = nullptr);
 
 // 20-band TPT-SVF cascade, lane = (channel, band), bands skewed in time across lanes.  streamPairs: one wave per
 // stream (its L and R channel) instead of 3 channels per wave -- required when a band has flag bits 4/5
