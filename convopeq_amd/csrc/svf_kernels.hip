@@ -335,6 +335,14 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
         y[3 % N] *= fma(cb, q23 * den[2 % N], ca);
         return;
     }
+    if (N == 2 && ORDER == 2) {          // the same for a pair: 15 slots for two samples instead of 18
+        const double pp = den[0] * den[1 % N];
+        double q = __builtin_amdgcn_rcp(pp);
+        q = fma(fma(-pp, q, 1.0), q, q);
+        y[0] *= fma(cb, q * den[1 % N], ca);
+        y[1 % N] *= fma(cb, q * den[0], ca);
+        return;
+    }
 #endif
 #pragma unroll
     for (int j = 0; j < N; ++j) r[j] = __builtin_amdgcn_rcp(den[j]);
@@ -810,7 +818,7 @@ __device__ __forceinline__ void tpv_span_await(const unsigned long long* flag, u
 // tuning of the pass (A/B with tools/ab_tpv.sh): samples per group of the small-signal output stage; order of its
 // reciprocal refinement; the seven-operation recurrence for bands with m0 == 1 and m2 == 0
 #ifndef CPQ_TPV_U
-#define CPQ_TPV_U 4
+#define CPQ_TPV_U 2
 #endif
 #ifndef CPQ_TPV_ORDER
 #define CPQ_TPV_ORDER 2
@@ -989,11 +997,22 @@ __device__ __forceinline__ void tpv_span_load(const double* src, double* buf, in
         wave_lds_sync();
     }
 }
+// How a span leaves the registers (A/B: tools/ab_tpv.sh, profiles/r03o_ab_eq_span_store.txt).  The lanes of quarter h pick
+// their eight 16-byte pieces out of the exchange buffer; collected in an array t[8] that is assigned under `if (quarter ==
+// mine)`, t[] enters the quarter loop undefined -- and with it left at that (0) the compiler kept a 32-register "don't care"
+// tuple alive across the whole SPAN loop, spilled and reloaded per span: 128 + 128 bytes of scratch traffic per lane and
+// span, as much HBM traffic again as the span itself (PMC 8.6 GB per launch against 4.3 GB algorithmic,
+// profiles/r03n_pmc_traffic.json).  2 (default): an empty asm defines the registers at the top of the function; 1: every
+// lane reads every quarter and selects; 3: no array, the lanes of a quarter store their pieces right away (32-byte runs).
+#ifndef CPQ_TPV_STORE
+#define CPQ_TPV_STORE 2
+#endif
 template <bool COHERENT>
 __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lane, const double (&x)[16], double gain)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
-    v2 t[8];
+#if CPQ_TPV_STORE == 3
+    // the lanes of quarter h store their eight 16-byte pieces right away (32 contiguous bytes per lane pair)
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -1004,9 +1023,43 @@ __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lan
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
+                double* p = dst + k * 128 + lane * 2;
+                if (COHERENT) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v2{ v.x, v.y }) : "memory");
+                else          __builtin_nontemporal_store(v2{ v.x, v.y }, reinterpret_cast<v2*>(p));
+            }
+        }
+        wave_lds_sync();
+    }
+    if (COHERENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    v2 t[8];
+#if CPQ_TPV_STORE == 2
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "=v"(t[k]));
+#endif
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<double2*>(buf + lane * kTpvQStride + 2 * j) = make_double2(x[4 * h + 2 * j] * gain, x[4 * h + 2 * j + 1] * gain);
+        wave_lds_sync();
+#if CPQ_TPV_STORE == 1
+        const bool mine = ((lane >> 1) & 3) == h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
+            if (h == 0) t[k] = v2{ v.x, v.y };
+            else        t[k] = v2{ mine ? v.x : t[k].x, mine ? v.y : t[k].y };
+        }
+#else
+        if (((lane >> 1) & 3) == h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
                 t[k] = v2{ v.x, v.y };
             }
         }
+#endif
         wave_lds_sync();
     }
     if (COHERENT) {
@@ -1029,6 +1082,7 @@ __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lan
 #pragma unroll
         for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(t[k], reinterpret_cast<v2*>(dst + k * 128 + lane * 2));
     }
+#endif
 }
 
 // Guarded run of the spans sp, sp + nGroups, ... of a channel: pieces of kTpvGuardPiece samples staged in the scratch area as
