@@ -632,6 +632,8 @@ __device__ __forceinline__ void p4_forward_frame(double2 (&v)[8], double2* dyn, 
 #pragma unroll
     for (int r = 0; r < 8; ++r) mine[lane + 64 * r] = v[r];
     __syncthreads();
+    // (five of the eight partner addresses are spilled and reloaded per frame -- the kernel sits at its 128 registers; rebuilding
+    // them per frame instead removes the scratch traffic and measured SLOWER, 1.15 -> 1.20-1.26 ms: profiles/r03q_ab_fft_partner.txt)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int k2 = lane + 64 * r;
@@ -740,11 +742,16 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
         // Y[4096 - k] of the real-FFT split: the second read is served by the L2 (the workgroup reads each row twice within
         // microseconds) and spares the LDS -- the bound of this kernel -- 16 accesses per lane and two workgroup barriers
         double2 pa[8], pb[8];
+        // (the partner offsets are rebuilt per frame from a value the compiler cannot see through: kept across the frame loop
+        // they cost 16 registers, which were spilled and reloaded per frame)
+        int laneP = lane;
+        asm volatile("" : "+v"(laneP));
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int k2 = lane + 64 * r;
+            const int k2p = laneP + 64 * r;
             pa[r] = y[k2];
-            pb[r] = yrow[w == 0 ? ((512 - k2) & 511) : (8 - w) * 512 + (511 - k2)];
+            pb[r] = yrow[w == 0 ? ((512 - k2p) & 511) : (8 - w) * 512 + (511 - k2p)];
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
