@@ -39,8 +39,9 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
             cpq::launch_rfft_fwd_ols(e->stream, dIn, stride, e->hist[e->histSel], e->hist[e->histSel ^ 1], e->X, e->XDN,
                                      tables(e), e->P, e->nCh, T, e->head, e->ringSlots);
         }
-        for (int l = 0; l < pl.num_layers; ++l) {
-            double* dst = (l == 0) ? dOut : e->layerOut + (int64_t)(l - 1) * e->nCh * stride;
+        // the tail layers first (natural time, into layerOut), then the reader's schedule for the call's callbacks, then layer
+        // 0, whose inverse transform adds what the reader reads as it stores the output (no separate pass over the output)
+        for (int l = pl.num_layers - 1; l >= 0; --l) {
             {
                 ProfScope p(e, CPQ_K_FDL_MAC);
                 cpq::launch_fdl_mac(e->stream, e->macTile, e->X, e->H + (int64_t)e->layerRow[l] * e->P, e->irSlot, e->Y,
@@ -51,20 +52,29 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
                 cpq::launch_fdl_mac_dcnyq(e->stream, e->XDN, e->HDN + e->layerRow[l], e->irSlot, e->Y, e->P, e->nCh,
                                           e->layerK[l], e->ringSlots, e->head, T, e->hRows);
             }
+            if (l > 0) {
+                ProfScope p(e, CPQ_K_RFFT_INV);
+                cpq::launch_rfft_inv_ols(e->stream, e->Y, e->layerOut + (int64_t)(l - 1) * e->nCh * stride, stride, tables(e), e->P, e->nCh, T);
+                continue;
+            }
+            {
+                ProfScope p(e, CPQ_K_MIX);
+                const int ppc1 = pl.parts_per_callback[1], ppc2 = nTail > 1 ? pl.parts_per_callback[2] : 1;
+                const int d1 = (pl.num_parts_ir[1] + ppc1 - 1) / ppc1 - 1;
+                const int d2 = nTail > 1 ? (pl.num_parts_ir[2] + ppc2 - 1) / ppc2 - 1 : 0;
+                cpq::launch_tail_schedule(e->stream, e->tailState, e->tailSched, n / e->B, e->B, nTail, pl.part_size[1], pl.output_delay[1], d1,
+                                          nTail > 1 ? pl.part_size[2] : e->B, nTail > 1 ? pl.output_delay[2] : 0, d2);
+            }
             {
                 ProfScope p(e, CPQ_K_RFFT_INV);
-                cpq::launch_rfft_inv_ols(e->stream, e->Y, dst, stride, tables(e), e->P, e->nCh, T);
+                cpq::launch_rfft_inv_ols_tail(e->stream, e->Y, dOut, stride, tables(e), e->P, e->nCh, T, nullptr, e->layerOut, e->tailRing,
+                                              e->tailRingSlots, e->tailState, e->tailSched, n / e->B, e->B, nTail, pl.gain[1],
+                                              nTail > 1 ? pl.gain[2] : 0.0);
             }
-        }
-        {
-            ProfScope p(e, CPQ_K_MIX);
-            const int ppc1 = pl.parts_per_callback[1], ppc2 = nTail > 1 ? pl.parts_per_callback[2] : 1;
-            const int d1 = (pl.num_parts_ir[1] + ppc1 - 1) / ppc1 - 1;
-            const int d2 = nTail > 1 ? (pl.num_parts_ir[2] + ppc2 - 1) / ppc2 - 1 : 0;
-            cpq::launch_tail_layers(e->stream, e->tailState, e->tailSched, e->layerOut, e->tailRing, dOut, e->nCh,
-                                    (int)stride, e->B, e->tailRingSlots, nTail, pl.part_size[1], pl.output_delay[1], d1,
-                                    nTail > 1 ? pl.part_size[2] : e->B, nTail > 1 ? pl.output_delay[2] : 0, d2,
-                                    pl.gain[1], nTail > 1 ? pl.gain[2] : 0.0);
+            {
+                ProfScope p(e, CPQ_K_MIX);
+                cpq::launch_tail_append(e->stream, e->tailState, e->layerOut, e->tailRing, e->nCh, (int)stride, e->tailRingSlots, nTail);
+            }
         }
         addDirect();
         CPQ_HIP(e, hipGetLastError());

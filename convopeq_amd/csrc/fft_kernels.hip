@@ -225,15 +225,47 @@ __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ he
     wave_split_store(v, lds, wl, lane, H + (int64_t)k * kP, HDN + k);
 }
 
-// Where an inverse transform puts block t of channel c: the call's output rows, or (RING) a per-channel ring at the position
-// the block has there -- pos[t], or pos0 + t P when pos is null; a negative position drops the block (ringWrite /
-// delayLineWrite of the plan groups, src/MKLNonUniformConvolver.cpp:1341-1371, :1639-1648, fused into the transform's
-// stores).  i = even sample index inside the block.
-struct RingOut { double* ring; int mask; const long long* pos; long long pos0; };
-template <bool RING>
-__device__ __forceinline__ void store_block2(double* out, int64_t chStride, const RingOut& ro, int c, int t, int P, int i, double2 v)
+// Where an inverse transform puts block t of channel c (i = even sample index inside the block):
+//   MODE 0: the call's output rows;
+//   MODE 1: a per-channel ring at the position the block has there -- pos[t], or pos0 + t P when pos is null; a negative
+//           position drops the block (ringWrite / delayLineWrite of the plan groups, src/MKLNonUniformConvolver.cpp:1341-1371,
+//           :1639-1648, fused into the transform's stores);
+//   MODE 2: the output rows PLUS what the replayed delay-line reader of the tail layers adds at those samples (layered
+//           mode, mix_kernels.hip: k_tail_schedule has filled sched for the call; the additions come from this call's
+//           natural-time tail outputs where the sample lies inside the call, from the layer's ring where it is older) --
+//           the read-modify-write pass over the call's output that k_layer_combine would make is gone.
+struct OutSpec {
+    double* ring; int mask; const long long* pos; long long pos0;                                  // MODE 1
+    const double* layerOut; const double* tailRing; const long long* tailState; const long long* sched;      // MODE 2
+    int nCb, B, log2B, tailMask, nTail, nChAll, nSamples; double g1, g2;
+};
+template <int MODE>
+__device__ __forceinline__ void store_block2(double* out, int64_t chStride, const OutSpec& ro, int c, int t, int P, int i, double2 v)
 {
-    if (!RING) { *reinterpret_cast<double2*>(out + (int64_t)c * chStride + (int64_t)t * P + i) = v; return; }
+    if (MODE == 0) { *reinterpret_cast<double2*>(out + (int64_t)c * chStride + (int64_t)t * P + i) = v; return; }
+    if (MODE == 2) {
+        const long long g0 = ro.tailState[3];          // TailState::g0: global index of the call's first sample
+        auto tail = [&](int n, double y) {
+            const int cbk = n >> ro.log2B, j = n & (ro.B - 1);          // (whole-block engines: B is a power of two)
+            for (int l = 0; l < ro.nTail; ++l) {
+                const long long s = ro.sched[(long long)l * ro.nCb + cbk];
+                if (s >= 0) {
+                    const double g = l == 0 ? ro.g1 : ro.g2;
+                    const long long idx = s + j;
+                    const double x = idx >= g0 ? ro.layerOut[((long long)l * ro.nChAll + c) * ro.nSamples + (idx - g0)]
+                                               : ro.tailRing[((long long)l * ro.nChAll + c) * (ro.tailMask + 1) + (idx & ro.tailMask)];
+                    // delayLineReadAdd: dst += src (gain within 1e-12 of 1) else dst += src * gain (:1673-1676)
+                    y = (fabs(g - 1.0) < 1.0e-12) ? (y + x) : (y + x * g);
+                }
+            }
+            return y;
+        };
+        const int n0 = t * P + i;
+        v.x = tail(n0, v.x);
+        v.y = tail(n0 + 1, v.y);
+        *reinterpret_cast<double2*>(out + (int64_t)c * chStride + (int64_t)t * P + i) = v;
+        return;
+    }
     const long long p = ro.pos ? ro.pos[t] : ro.pos0 + (long long)t * P;
     if (p < 0) return;
     double* r = ro.ring + (int64_t)c * (ro.mask + 1);
@@ -242,9 +274,9 @@ __device__ __forceinline__ void store_block2(double* out, int64_t chStride, cons
     else { r[a & ro.mask] = v.x; r[(a + 1) & ro.mask] = v.y; }
 }
 
-template <bool RING>
+template <int MODE>
 __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__ Y, double* __restrict__ out,
-                                                     int64_t chStride, FftTables tw, int T, RingOut ro)
+                                                     int64_t chStride, FftTables tw, int T, OutSpec ro)
 {
     __shared__ double2 lds[kLdsPerWave];
     const int lane = threadIdx.x;
@@ -273,7 +305,7 @@ __global__ __launch_bounds__(64) void k_rfft_inv_ols(const double2* __restrict__
     constexpr double s = 1.0 / 512.0;
 #pragma unroll
     for (int r = 4; r < 8; ++r)
-        store_block2<RING>(out, chStride, ro, c, t, kP, 2 * (lane + 64 * (r - 4)), make_double2(v[r].x * s, v[r].y * s));
+        store_block2<MODE>(out, chStride, ro, c, t, kP, 2 * (lane + 64 * (r - 4)), make_double2(v[r].x * s, v[r].y * s));
 }
 
 
@@ -372,9 +404,9 @@ __global__ __launch_bounds__(256) void k_ir_spectra_generic(const double* __rest
     split_store_generic(Z, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
 }
 
-template <bool RING>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_rfft_inv_ols_generic(const double2* __restrict__ Y, double* __restrict__ out,
-                                                              int64_t chStride, FftTables tw, int P, int T, RingOut ro)
+                                                              int64_t chStride, FftTables tw, int P, int T, OutSpec ro)
 {
     extern __shared__ double2 dyn[];
     double2* a = dyn;
@@ -399,7 +431,7 @@ __global__ __launch_bounds__(256) void k_rfft_inv_ols_generic(const double2* __r
     const double s = 1.0 / (double)P;
     const int halfP = P >> 1;
     for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)      // second half of the 2P-sample frame
-        store_block2<RING>(out, chStride, ro, c, t, P, 2 * (n - halfP), make_double2(z[n].x * s, z[n].y * s));
+        store_block2<MODE>(out, chStride, ro, c, t, P, 2 * (n - halfP), make_double2(z[n].x * s, z[n].y * s));
 }
 
 }  // namespace
@@ -538,9 +570,9 @@ __global__ __launch_bounds__(512) void k_ir_spectra_wg(const double* __restrict_
     split_store_wg(dyn, P, tw.tw1024, H + (int64_t)k * P, HDN + k);
 }
 
-template <bool RING>
+template <int MODE>
 __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restrict__ Y, double* __restrict__ out,
-                                                         int64_t chStride, FftTables tw, int P, int T, RingOut ro)
+                                                         int64_t chStride, FftTables tw, int P, int T, OutSpec ro)
 {
     extern __shared__ double2 dyn[];
     const int c = blockIdx.x / T;
@@ -563,7 +595,7 @@ __global__ __launch_bounds__(512) void k_rfft_inv_ols_wg(const double2* __restri
     const double s = 1.0 / (double)P;
     const int halfP = P >> 1;
     for (int n = halfP + threadIdx.x; n < P; n += blockDim.x)
-        store_block2<RING>(out, chStride, ro, c, t, P, 2 * (n - halfP), make_double2(dyn[wgp(n)].x * s, dyn[wgp(n)].y * s));
+        store_block2<MODE>(out, chStride, ro, c, t, P, 2 * (n - halfP), make_double2(dyn[wgp(n)].x * s, dyn[wgp(n)].y * s));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -718,9 +750,9 @@ __global__ __launch_bounds__(512, 4) void k_ir_spectra_p4(const double* __restri
     p4_forward_frame(v, dyn, &tabs, wk, H + (int64_t)k * kP4, HDN + k);
 }
 
-template <bool RING>
+template <int MODE>
 __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __restrict__ Y, double* __restrict__ out,
-                                                          int64_t chStride, FftTables tw, int T, int split, RingOut ro)
+                                                          int64_t chStride, FftTables tw, int T, int split, OutSpec ro)
 {
     extern __shared__ double2 dyn[];
     __shared__ P4Tables tabs;
@@ -778,10 +810,10 @@ __global__ __launch_bounds__(512, 4) void k_rfft_inv_ols_p4(const double2* __res
         dft8<true>(v);
         // second half of the 8192-sample frame: x[n], n = j + 512 n1, n1 = 4..7 (NUC.cpp:1332)
         constexpr double s = 1.0 / (double)kP4;
-        if (RING) {
+        if (MODE != 0) {
 #pragma unroll
             for (int q = 4; q < 8; ++q)
-                store_block2<true>(out, chStride, ro, c, t, kP4, 2 * (j + 512 * (q - 4)), make_double2(v[q].x * s, v[q].y * s));
+                store_block2<MODE>(out, chStride, ro, c, t, kP4, 2 * (j + 512 * (q - 4)), make_double2(v[q].x * s, v[q].y * s));
         } else {
             double* o = out + (int64_t)c * chStride + (int64_t)t * kP4;
 #pragma unroll
@@ -1004,9 +1036,9 @@ __global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict_
 }
 
 // inverse column pass: M1-point inverse FFT over k1 per column, second half of the frame (n1 >= M1 / 2) to out, 1/M
-template <bool RING>
+template <int MODE>
 __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict__ A, double* __restrict__ out,
-                                                      int64_t chStride, FftTables tw, int P, int T, RingOut ro)
+                                                      int64_t chStride, FftTables tw, int P, int T, OutSpec ro)
 {
     extern __shared__ double2 dyn[];
     const int M1 = P >> 9;
@@ -1029,7 +1061,7 @@ __global__ __launch_bounds__(512) void k_big_cols_inv(const double2* __restrict_
         if (n1 >= (M1 >> 1)) {
             const double2 z = dyn[n1 * kBigCols + col];
             const int n = n1 * 512 + n2;
-            store_block2<RING>(out, chStride, ro, c, t, P, 2 * (n - halfM), make_double2(z.x * s, z.y * s));
+            store_block2<MODE>(out, chStride, ro, c, t, P, 2 * (n - halfM), make_double2(z.x * s, z.y * s));
         }
     }
 }
@@ -1147,30 +1179,30 @@ void launch_spectrum_gain(hipStream_t stream, double2* H, double2* HDN, const do
 }
 
 namespace {
-template <bool RING>
+template <int MODE>
 void launch_inv(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P, int nCh, int T,
-                double2* scratch, RingOut ro)
+                double2* scratch, OutSpec ro)
 {
     if (P > 4096) {         // scratch [nCh * T][P]
         const int M1 = P >> 9;
         hipLaunchKernelGGL(k_big_rows_inv, dim3(nCh * T * ((M1 >> 1) + 1)), dim3(128), 0, stream, Y, scratch, tw, P);
-        hipLaunchKernelGGL(k_big_cols_inv<RING>, dim3(nCh * T * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2), stream,
+        hipLaunchKernelGGL(k_big_cols_inv<MODE>, dim3(nCh * T * (512 / bigCols(M1))), dim3(bigCols(M1) * M1 / 8), (size_t)M1 * bigCols(M1) * sizeof(double2), stream,
                            scratch, out, chStride, tw, P, T, ro);
         return;
     }
     if (P == kP)
-        hipLaunchKernelGGL(k_rfft_inv_ols<RING>, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T, ro);
+        hipLaunchKernelGGL(k_rfft_inv_ols<MODE>, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T, ro);
     else if (P == kP4) {
         const int split = p4Split(nCh, T);
-        allowLargeLds(k_rfft_inv_ols_p4<RING>, wgLdsBytes(P));
-        hipLaunchKernelGGL(k_rfft_inv_ols_p4<RING>, dim3(nCh * split), dim3(512), wgLdsBytes(P), stream, Y, out, chStride, tw, T,
+        allowLargeLds(k_rfft_inv_ols_p4<MODE>, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_inv_ols_p4<MODE>, dim3(nCh * split), dim3(512), wgLdsBytes(P), stream, Y, out, chStride, tw, T,
                            split, ro);
     } else if (P >= 1024) {
-        allowLargeLds(k_rfft_inv_ols_wg<RING>, wgLdsBytes(P));
-        hipLaunchKernelGGL(k_rfft_inv_ols_wg<RING>, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, Y, out, chStride,
+        allowLargeLds(k_rfft_inv_ols_wg<MODE>, wgLdsBytes(P));
+        hipLaunchKernelGGL(k_rfft_inv_ols_wg<MODE>, dim3(nCh * T), dim3(P / 8), wgLdsBytes(P), stream, Y, out, chStride,
                            tw, P, T, ro);
     } else
-        hipLaunchKernelGGL(k_rfft_inv_ols_generic<RING>, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
+        hipLaunchKernelGGL(k_rfft_inv_ols_generic<MODE>, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
                            stream, Y, out, chStride, tw, P, T, ro);
 }
 }  // namespace
@@ -1178,13 +1210,28 @@ void launch_inv(hipStream_t stream, const double2* Y, double* out, int64_t chStr
 void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P,
                          int nCh, int T, double2* scratch)
 {
-    launch_inv<false>(stream, Y, out, chStride, tw, P, nCh, T, scratch, RingOut{});
+    launch_inv<0>(stream, Y, out, chStride, tw, P, nCh, T, scratch, OutSpec{});
 }
 
 void launch_rfft_inv_ols_ring(hipStream_t stream, const double2* Y, double* ring, int ringSize, const long long* pos,
                               long long pos0, FftTables tw, int P, int nCh, int T, double2* scratch)
 {
-    launch_inv<true>(stream, Y, nullptr, 0, tw, P, nCh, T, scratch, RingOut{ ring, ringSize - 1, pos, pos0 });
+    OutSpec os{};
+    os.ring = ring; os.mask = ringSize - 1; os.pos = pos; os.pos0 = pos0;
+    launch_inv<1>(stream, Y, nullptr, 0, tw, P, nCh, T, scratch, os);
+}
+
+void launch_rfft_inv_ols_tail(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P, int nCh,
+                              int T, double2* scratch, const double* layerOut, const double* tailRing, int tailRingSize,
+                              const void* tailState, const long long* sched, int nCallbacks, int B, int nTail, double g1, double g2)
+{
+    OutSpec os{};
+    os.layerOut = layerOut; os.tailRing = tailRing; os.tailState = reinterpret_cast<const long long*>(tailState); os.sched = sched;
+    os.log2B = 0;
+    while ((1 << os.log2B) < B) ++os.log2B;
+    os.nCb = nCallbacks; os.B = B; os.tailMask = tailRingSize - 1; os.nTail = nTail; os.nChAll = nCh; os.nSamples = (int)chStride;
+    os.g1 = g1; os.g2 = g2;
+    launch_inv<2>(stream, Y, out, chStride, tw, P, nCh, T, scratch, os);
 }
 
 }  // namespace cpq

@@ -112,13 +112,6 @@ void launch_agc_apply(hipStream_t stream, double* data, int64_t chStride, int S,
 void launch_gain_ramp(hipStream_t stream, double* data, int64_t chStride, int S, int B, int T, const double* gains,
                       const int* on);
 
-// Layered (time-varying) reference semantics: replay of the reference's tail delay-line reader on per-layer
-// natural-time convolutions.  state: 3 long long (callback counter, read cursors), sched: [nTail][T] long long,
-// layerOut: [nTail][nCh][nSamples], ring: [nTail][nCh][ringSlots]; out already holds the layer-0 convolution.
-void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,
-                        double* out, int nCh, int nSamples, int B, int ringSlots, int nTail, int pl1, int ol1, int d1,
-                        int pl2, int ol2, int d2, double g1, double g2);
-
 // FilterSpec tail layers at the reference's partition size: input accumulation, delay-line write, delay-line read-add
 void launch_rows_copy(hipStream_t stream, const double* src, int64_t srcStride, int64_t srcOff, double* dst,
                       int64_t dstStride, int64_t dstOff, int n, int nCh);
@@ -126,7 +119,15 @@ void launch_ring_put(hipStream_t stream, const double* z, int64_t zStride, int n
                      long long pos, int nCh);
 void launch_ring_add(hipStream_t stream, double* out, int64_t outStride, int n, int B, const double* ring, int ringSize,
                      const long long* sched, double gain, int nCh);
-// replay of the delay-line reader for the T callbacks of a call (state: 3 long long; sched: [nTail][T], -1 = skip)
+// Layered mode with the reader's additions inside the layer-0 inverse transform: the schedule first (launch_tail_schedule),
+// then launch_rfft_inv_ols_tail writes out = layer-0 convolution + what the reader adds (from layerOut / the rings), then
+// launch_tail_append stores what later calls may still read into the rings.
+void launch_rfft_inv_ols_tail(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int P, int nCh,
+                              int T, double2* scratch, const double* layerOut, const double* tailRing, int tailRingSize,
+                              const void* tailState, const long long* sched, int nCallbacks, int B, int nTail, double g1, double g2);
+void launch_tail_append(hipStream_t stream, const void* state, const double* layerOut, double* ring, int nCh, int nSamples,
+                        int ringSlots, int nTail);
+// replay of the delay-line reader for the T callbacks of a call (state: 4 long long; sched: [nTail][T], -1 = skip)
 void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,
                           int pl2, int ol2, int d2);
 

@@ -110,54 +110,10 @@ __global__ void k_tail_schedule(TailState* st, long long* __restrict__ sched, in
     if (l == 0) { st->cb = cb0 + T; st->g0 = cb0 * (long long)B; }
 }
 
-// The reader's additions straight from this call's natural-time tail outputs where the sample it wants lies inside the
-// call (global index >= g0: all of a long call but its first output_delay or so), from the layer's ring where it is older.
-// One workgroup per (callback, channel): the callback's read positions are uniform, the samples stream through as pairs
-// (the tail streams are read as scalars: a read position may be odd).
-__global__ __launch_bounds__(256) void k_layer_combine(double* out, const double* __restrict__ layerOut,
-                                                       const double* __restrict__ ring, const TailState* __restrict__ st,
-                                                       const long long* __restrict__ sched, int nCh, int nSamples,
-                                                       int T, int B, int ringMask, int nTail, double g1, double g2)
-{
-    const int cbk = blockIdx.x, c = blockIdx.y;
-    double* o = out + (long long)c * nSamples + (long long)cbk * B;
-    const long long g0 = st->g0;
-    const long long s0 = sched[cbk], s1 = nTail > 1 ? sched[(long long)T + cbk] : -1;
-    if (s0 < 0 && s1 < 0) return;                                 // this callback reads nothing
-    const double* cur0 = layerOut + (long long)c * nSamples;
-    const double* cur1 = layerOut + ((long long)nCh + c) * nSamples;
-    const double* old0 = ring + (long long)c * (ringMask + 1);
-    const double* old1 = ring + ((long long)nCh + c) * (ringMask + 1);
-    // delayLineReadAdd: dst += src (gain within 1e-12 of 1) else dst += src * gain (:1673-1676)
-    const bool unit0 = fabs(g1 - 1.0) < 1.0e-12, unit1 = fabs(g2 - 1.0) < 1.0e-12;
-    auto tail = [&](int j, double y) {
-        if (s0 >= 0) {
-            const long long idx = s0 + j;
-            const double t = idx >= g0 ? cur0[idx - g0] : old0[idx & ringMask];
-            y = unit0 ? (y + t) : (y + t * g1);
-        }
-        if (s1 >= 0) {
-            const long long idx = s1 + j;
-            const double t = idx >= g0 ? cur1[idx - g0] : old1[idx & ringMask];
-            y = unit1 ? (y + t) : (y + t * g2);
-        }
-        return y;
-    };
-    if ((B & 1) == 0 && (nSamples & 1) == 0) {
-        for (int j = threadIdx.x * 2; j < B; j += 512) {
-            double2 y = *reinterpret_cast<const double2*>(o + j);
-            y.x = tail(j, y.x);
-            y.y = tail(j + 1, y.y);
-            *reinterpret_cast<double2*>(o + j) = y;
-        }
-    } else {
-        for (int j = threadIdx.x; j < B; j += 256) o[j] = tail(j, o[j]);
-    }
-}
-
 // what later calls may still read of this call's tail outputs goes into the per-layer rings at (global sample index &
 // mask): everything from the layer's read cursor on (the reader never steps back), at most one ring's worth.  Runs behind
-// k_layer_combine, which still reads the older contents.
+// the layer-0 inverse transform, whose stores add the reader's samples (fft_kernels.hip: store_block2<2>) and still read
+// the older contents.
 __global__ __launch_bounds__(256) void k_tail_append(const double* __restrict__ layerOut, double* __restrict__ ring,
                                                      const TailState* __restrict__ st, int nCh, int nSamples, int ringMask)
 {
@@ -560,20 +516,6 @@ void launch_gain_ramp(hipStream_t stream, double* data, int64_t chStride, int S,
     hipLaunchKernelGGL(k_agc_ramp, dim3(bx, 2 * S), dim3(256), 0, stream, data, chStride, gains, on, B, T);
 }
 
-void launch_tail_layers(hipStream_t stream, void* state, long long* sched, const double* layerOut, double* ring,
-                        double* out, int nCh, int nSamples, int B, int ringSlots, int nTail, int pl1, int ol1, int d1,
-                        int pl2, int ol2, int d2, double g1, double g2)
-{
-    const int T = nSamples / B;
-    TailState* st = reinterpret_cast<TailState*>(state);
-    // the reader's schedule for the call's callbacks, its additions, then what later calls may still read into the rings
-    hipLaunchKernelGGL(k_tail_schedule, dim3(1), dim3(64), 0, stream, st, sched, T, B, nTail, make_int2(pl1, ol1),
-                       make_int2(pl2, ol2), d1, d2);
-    hipLaunchKernelGGL(k_layer_combine, dim3(T, nCh), dim3(256), 0, stream, out, layerOut, ring, st, sched, nCh, nSamples, T, B,
-                       ringSlots - 1, nTail, g1, g2);
-    hipLaunchKernelGGL(k_tail_append, dim3(8, nCh * nTail), dim3(256), 0, stream, layerOut, ring, st, nCh, nSamples, ringSlots - 1);
-}
-
 void launch_convproc_mix(hipStream_t stream, const double* wet, double* out, int64_t chStride, int nCh, int nSamples,
                          const double* gains, const double* ring, int ringSize, long long pos0, const int* dNew,
                          const int* dOld, const int* xLen, const double* xGains, int xCap, int wetValid,
@@ -684,6 +626,13 @@ void launch_ring_add_chunks(hipStream_t stream, double* out, int64_t outStride, 
     if (n <= 0 || nCh <= 0) return;
     hipLaunchKernelGGL(k_ring_add_chunks, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, chMap, n, q, ring,
                        ringSize - 1, sched, gain);
+}
+
+void launch_tail_append(hipStream_t stream, const void* state, const double* layerOut, double* ring, int nCh, int nSamples,
+                        int ringSlots, int nTail)
+{
+    hipLaunchKernelGGL(k_tail_append, dim3(8, nCh * nTail), dim3(256), 0, stream, layerOut, ring, reinterpret_cast<const TailState*>(state),
+                       nCh, nSamples, ringSlots - 1);
 }
 
 void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int T, int B, int nTail, int pl1, int ol1, int d1,

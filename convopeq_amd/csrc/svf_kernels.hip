@@ -1359,7 +1359,7 @@ namespace {
 // its bands' rows of `state` and its slices run in order.  (N + G - 1) / (N G) of the single-stage time at best
 // (profiles/r03d_eq_stage_sweep.txt).  The same pipeline inside ONE launch is the STAGED kernel above.
 struct StagePipe {
-    static constexpr int kMaxStages = 4, kMaxSlices = 16;
+    static constexpr int kMaxStages = 5, kMaxSlices = 32;
     hipStream_t side[kMaxStages - 1] = {};
     hipEvent_t done[kMaxStages][kMaxSlices] = {};
     hipEvent_t fork = nullptr;
