@@ -39,6 +39,7 @@ struct ProfileSlot {
 struct NativeLayer {
     int P = 0, K = 0, kPad = 0, hRows = 0, ringSlots = 0, nbMax = 0, accCap = 0, outRing = 0;
     int head = 0, histSel = 0, accSel = 0, fill = 0;     // FDL ring head, ping-pong selectors, input fill (inputPos)
+    int fftAhead = 0;           // blocks of this call already transformed straight from the call's input (groupsAppend), 0 = none
     double gain = 1.0;          // tail-layer gain applied by the delay-line reader
     int ppc = 1, outputDelay = 0;       // partsPerCallback (:988-994), outputDelaySamples (:1005-1024)
     // host replay of the reference's integer state: layer 0 -- samples written to / read from the output ring

@@ -576,19 +576,33 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
         if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
-        // every layer accumulates the same input (Add(), :1431-1446): one pass over it
+        // every layer accumulates the same input (Add(), :1431-1446): one pass over it.  A layer whose accumulator is
+        // empty and for which the call is whole partitions needs no accumulation at all when the group's rows are the
+        // call's rows: its forward transforms run right here, straight from the call's input (before anything can write
+        // dOut, which may alias dIn), and runLayerBlocks continues behind them.
+        const bool rowsAreCallRows = g.identityMap && g.usedCh == e->nCh;
         double* dst[3];
         int64_t stride[3], off[3];
-        int nl = 0;
+        int nl = 0, li = 0;
         for (NativeLayer& t : g.layers) {
-            if (nl == 3) break;
+            if (li++ == 3) break;
+            t.fftAhead = 0;
+            if (rowsAreCallRows && t.fill == 0 && n % t.P == 0 && n / t.P <= t.nbMax) {
+                ProfScope p(e, CPQ_K_RFFT_FWD);
+                cpq::launch_rfft_fwd_ols(e->stream, dIn, (int64_t)n, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN,
+                                         cpq::FftTables{ t.tw, t.tw2, t.twCol, t.twSplit }, t.P, g.usedCh, n / t.P, t.head, t.ringSlots, t.scratch);
+                t.fftAhead = n / t.P;
+                continue;
+            }
             dst[nl] = t.acc[t.accSel];
             stride[nl] = t.accCap;
             off[nl] = t.fill;
             ++nl;
         }
-        ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_rows_gather_multi(e->stream, dIn, n, g.chMapDev, nl, dst, stride, off, n, g.usedCh);
+        if (nl > 0) {
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_rows_gather_multi(e->stream, dIn, n, g.chMapDev, nl, dst, stride, off, n, g.usedCh);
+        }
     }
     CPQ_HIP(e, hipGetLastError());
     return CPQ_OK;
@@ -607,11 +621,12 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
     const int nCh = g.usedCh;
     if (nb > 0) {
         const cpq::FftTables tw{ t.tw, t.tw2, t.twCol, t.twSplit };
-        {
+        if (t.fftAhead != nb) {        // (else: transformed straight from the call's input in groupsAppend)
             ProfScope p(e, CPQ_K_RFFT_FWD);
             cpq::launch_rfft_fwd_ols(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN, tw,
                                      t.P, nCh, nb, t.head, t.ringSlots, t.scratch);
         }
+        t.fftAhead = 0;
         {
             ProfScope p(e, CPQ_K_FDL_MAC);
             cpq::launch_fdl_mac(e->stream, e->macTile, t.X, t.H, g.irSlotDev, t.Y, t.P, nCh, t.K, t.ringSlots, t.head, nb,

@@ -1003,21 +1003,26 @@ __global__ __launch_bounds__(128) void k_big_rows_inv(const double2* __restrict_
                                                       int P)
 {
     __shared__ double2 lds[2][kLdsPerWave];
+    __shared__ double2 rows[2][512];
     const int M1 = P >> 9;
     const int nPairs = (M1 >> 1) + 1;
     const int tr = blockIdx.x / nPairs, k1 = blockIdx.x - tr * nPairs;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int krow = (w == 0) ? k1 : ((M1 - k1) & (M1 - 1));
-    const int prow = (M1 - krow) & (M1 - 1);
     const double2* y = Y + (int64_t)tr * P + krow * 512;
-    const double2* ym = Y + (int64_t)tr * P + prow * 512;
     const double2 y0 = Y[(int64_t)tr * P];
+    // the partner row (M1 - krow) is the other wave's own row (k1 = 0 and M1 / 2: both waves hold the same row): exchanged
+    // through LDS like in the forward pass instead of a second read of it from L2
+    double2 own[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { own[r] = y[lane + 64 * r]; rows[w][lane + 64 * r] = own[r]; }
+    __syncthreads();
     double2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int k2 = lane + 64 * r;
-        const double2 yk = y[k2];
-        const double2 yp = ym[krow == 0 ? ((512 - k2) & 511) : (511 - k2)];
+        const double2 yk = own[r];
+        const double2 yp = rows[w ^ 1][krow == 0 ? ((512 - k2) & 511) : (511 - k2)];
         const double2 e = make_double2(0.5 * (yk.x + yp.x), 0.5 * (yk.y - yp.y));
         const double2 d = make_double2(0.5 * (yk.x - yp.x), 0.5 * (yk.y + yp.y));
         const double2 wk = tw.twSplit[krow * 512 + k2];

@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace cpq {
 
@@ -1414,6 +1415,11 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
             if (envStages > 0 && envSlices > 0) { if (nSpans8 >= envStages) { nStages = envStages; nSlices = envSlices; } }
             else if (envStages < 1 && 2 * nCh <= nCu && nSpans8 >= 16) { nStages = 4; nSlices = 16; }      // measured best (profiles/r03d_eq_stage_sweep.txt)
         }
+        // the side streams and events are per device, shared by every engine on it: one engine's launch sequence at a time
+        // (a stream wait captures the event's record of the moment it is enqueued, so reuse by the next engine is safe)
+        static std::mutex pipeMutex;
+        std::unique_lock<std::mutex> pipeLock(pipeMutex, std::defer_lock);
+        if (nSlices > 0) pipeLock.lock();
         StagePipe* pipe = nSlices > 0 ? stagePipe() : nullptr;
         if (!pipe && !inKernel) nStages = 1;
         if (pipe) {
