@@ -599,12 +599,16 @@ def main():
             "k_rfft_fwd_ols": sum(n_ch * nb * (pl * 8 + pl * 16) for pl, _, nb in layers),
             "k_fdl_mac": sum((n_ch * (kl + nb - 1) + ir_mult * kl + n_ch * nb) * pl * 16 for pl, kl, nb in mac_layers),
             "k_fdl_mac_dcnyq": sum(n_ch * (kl + nb - 1 + nb) * 16 + ir_mult * kl * 16 for pl, kl, nb in mac_layers),
-            "k_rfft_inv_ols": sum(n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb in mac_layers),
+            # layered mode: the layer-0 inverse transform also reads what the replayed delay-line reader adds (8 B per sample
+            # and tail layer, from the tail layers' outputs)
+            "k_rfft_inv_ols": sum(n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb in mac_layers) + (n_ch * n * 8 * n_tail if layered else 0),
             "k_svf_cascade_tp": n_ch * n * 16,
             "k_svf_cascade": n_ch * n * 16,
-            # native schedule: delay-line write / read-add of the tail layers; layered mode: per tail layer its output read,
-            # ring written and read (24 B per sample) + the call's output read and written
-            "k_convproc_mix": n_ch * n * (24 * n_tail + 16) if layered else n_ch * n * 16 * max(0, len(layers) - 1),
+            # native schedule: the delay-line read-add of the tail layers over the call's output (read + write once, 8 B per
+            # sample and tail layer from the rings; the ring writes are inside the inverse transforms); layered mode: only what
+            # later calls may still read is appended to the rings (at most one output_delay + partition per tail layer: small)
+            "k_convproc_mix": (n_ch * 16 * sum(min(n, plan.output_delay[l] + 2 * plan.part_size[l]) for l in range(1, plan.num_layers)) if layered
+                               else n_ch * n * (16 + 8 * max(0, len(layers) - 1)) if len(layers) > 1 else 0),
         }
         # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF: the reference's band kernel is 17 flops of linear
         # recurrence (10 instructions, 7 of them FMAs) + 16 of output stage (fastTanh blend with one division counted as one,
