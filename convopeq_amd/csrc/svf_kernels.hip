@@ -1245,32 +1245,37 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, (WAVES == 6 ? 3 : 4)) voi
         reinterpret_cast<double2*>(&sh.P[b][0][0])[q] = reinterpret_cast<const double2*>(&tb[b].t[0].P[0][0])[q];
     }
     __syncthreads();
-    double* buf = sh.scratch + wave * 64 * kTpvQStride;
+    double* buf = sh.scratch + waveU * 64 * kTpvQStride;
 
     int sp = 0;
 #pragma unroll 1
     for (; sp < nSpans; ++sp) {
-        const double* src = inCh + (int64_t)sp * spanLen + wave * 1024;
+        const double* src = inCh + (int64_t)sp * spanLen + waveU * 1024;
         double x[16];
+        // (the per-lane addresses of the span I/O are rebuilt per span from the lane count behind an opaque zero, like the
+        // thread index inside the band loop: kept across the band loops they were the kernel's last spilled registers)
+        int laneIo;
+        { int z = 0; asm volatile("" : "+s"(z)); laneIo = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z)); }
+        const int tidS = (waveU << 6) + laneIo;           // (= tid, for the same reason)
         if (STAGED && awaitFlags) {           // the span as the stage before this one left it
-            if (tid == 0) tpv_span_await(awaitFlags + sp, ticket);
+            if (tidS == 0) tpv_span_await(awaitFlags + sp, ticket);
             __syncthreads();
 #if CPQ_TPV_HL
-            tpv_span_load<true>(src, buf, lane, x);
+            tpv_span_load<true>(src, buf, laneIo, x);
 #else
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            tpv_span_load<false>(src, buf, lane, x);
+            tpv_span_load<false>(src, buf, laneIo, x);
 #endif
         } else {
-            tpv_span_load<false>(src, buf, lane, x);
+            tpv_span_load<false>(src, buf, laneIo, x);
         }
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
-        if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
-        if (tid == 0) sh.flag = 0;
+        if (tidS < kBands * 2) bad |= !(fabs(sState[tidS]) < kTpInputBound);
+        if (tidS == 0) sh.flag = 0;
         __syncthreads();
-        if (__any(bad) && lane == 0) atomicOr(&sh.flag, 1);
+        if (__any(bad) && laneIo == 0) atomicOr(&sh.flag, 1);
         __syncthreads();
         if (sh.flag != 0) break;
 
@@ -1299,7 +1304,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, (WAVES == 6 ? 3 : 4)) voi
                 const unsigned other = mask & ~same;
                 const unsigned run = other ? (same & ((other & (0u - other)) - 1u)) : same;     // bands below the first one of another class
                 const unsigned rest = mask & ~run;
-#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, tid, waveU, nThreads, prefetch)
+#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, tidS, waveU, nThreads, prefetch)
                 if (cls == 2)        CPQ_RUN(2, false);
                 else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
                 else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }
@@ -1307,27 +1312,30 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, (WAVES == 6 ? 3 : 4)) voi
                 mask = rest;
             }
         }
+        { int z = 0; asm volatile("" : "+s"(z)); laneIo = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z)); }
 #if CPQ_TPV_HS
-        if (STAGED && publishFlags) tpv_span_store<true>(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
-        else                        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
+        if (STAGED && publishFlags) tpv_span_store<true>(outCh + (int64_t)sp * spanLen + waveU * 1024, buf, laneIo, x, gain);
+        else                        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + waveU * 1024, buf, laneIo, x, gain);
 #else
-        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + wave * 1024, buf, lane, x, gain);
+        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + waveU * 1024, buf, laneIo, x, gain);
         if (STAGED && publishFlags) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
         __syncthreads();                      // the last thread's end states are in sNext; every wave's stores are out
-        if (STAGED && publishFlags && tid == 0) tpv_span_publish(publishFlags + sp, ticket);
+        if (STAGED && publishFlags && waveU == 0 && laneIo == 0) tpv_span_publish(publishFlags + sp, ticket);
         { double* t = sState; sState = sNext; sNext = t; }
     }
+    int tidE;            // (= tid, rebuilt: see laneIo)
+    { int z = 0; asm volatile("" : "+s"(z)); tidE = (waveU << 6) + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z)); }
     if (sp < nSpans) {
         // cold: this span and the later ones through the guarded recurrence (states advance in sState).  The span's wait
         // for the stage before has been done above; the guarded loop waits again, which returns at once.
         tpv_guarded_spans(sh, sp, nSpans, spanLen, inCh, outCh, sState, cf, activeMask, kinds, sat, gain, awaitFlags,
-                          publishFlags, ticket, tid, nThreads);
+                          publishFlags, ticket, tidE, nThreads);
     }
     __syncthreads();
     // the call's end states (only this launch's / stage's bands are written: another stage has the other bands of the
     // channel)
-    if (nSpans > 0 && tid < kBands * 2 && ((activeMask >> (tid >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
+    if (nSpans > 0 && tidE < kBands * 2 && ((activeMask >> (tidE >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tidE] = sState[tidE];
 }
 
 }  // namespace
