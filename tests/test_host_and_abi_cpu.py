@@ -181,3 +181,22 @@ def test_oracle_df2t_matches_scipy_lfilter(oracle):
         ref = lfilter([s.b0, s.b1, s.b2], [1.0, s.a1, s.a2], ref)
     # the 18 Hz high-pass has poles at |z| = 0.998: any fp64 evaluation order sits ~2e-13 from the exact result
     assert np.abs(yl - ref).max() < 2e-12 and np.array_equal(yl, yr)
+
+
+def test_multi_device_host_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """INTEGRATION.md's multi-GPU host loop (one engine per device, one worker thread each) compiles against the C header
+    alone, links against the library's exports, and -- without a GPU -- reports CPQ_ERR_NO_DEVICE per device instead of
+    computing anything."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "convopeq_amd")
+    exe = tmp_path / "multi_device_host"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "examples", "multi_device_host.cpp"), "-o", str(exe),
+                           "-L", lib_dir, "-lconvopeq_mi355x", "-Wl,-rpath," + lib_dir, "-pthread"])
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the example would run for real")
+    r = subprocess.run([str(exe), "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("status -2") == 2 and "engines created: 0 of 2" in r.stdout, r.stdout
