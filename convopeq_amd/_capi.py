@@ -168,6 +168,7 @@ SYMBOLS = {
     "cpq_profile_reset": (C.c_int32, [_E]),
     "cpq_profile_read": (C.c_int32, [_E, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cpq_diag_partition_fft": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "cpq_diag_eq_chain_status": (C.c_int32, [_E, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cpq_kernel_name": (C.c_char_p, [C.c_int32]),
 }
 

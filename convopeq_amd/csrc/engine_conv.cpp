@@ -108,15 +108,7 @@ int enqueueConv(cpq_engine* e, const double* dIn, double* dOut, int n)
                 cpq::launch_rfft_inv_ols(e->stream, y, dOut + c0 * stride, stride, tables(e), e->P, cnt, T);
             }
         };
-        if (e->ovl.armed && e->groups.empty()) {
-            // two halves, so that the EQ of the first can start beside the convolution of the second (Overlap, engine_internal.hpp)
-            window(0, e->ovl.c0);
-            CPQ_HIP(e, hipEventRecord(e->ovl.convA, e->stream));
-            window(e->ovl.c0, e->nCh - e->ovl.c0);
-            e->ovl.convSplit = true;
-        } else {
-            window(0, e->nCh);
-        }
+        window(0, e->nCh);
         CPQ_HIP(e, hipGetLastError());
         e->head = (e->head + T) & (e->ringSlots - 1);
         e->histSel ^= 1;

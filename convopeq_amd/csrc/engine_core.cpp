@@ -148,6 +148,21 @@ const char* cpq_kernel_name(int32_t id)
 // ------------------------------------------------------------------ diagnostics
 // The partition FFT kernels in isolation (tests/test_gpu_fft.py): forward of every overlap-save frame from a silent history,
 // inverse of the same spectra.  Own device buffers and twiddles, the null stream; no engine.
+int32_t cpq_diag_eq_chain_status(cpq_engine* e, uint32_t* launches, uint32_t* gaveUp)
+{
+    if (!e || !launches || !gaveUp) return CPQ_ERR_INVALID_ARG;
+    *launches = 0;
+    *gaveUp = 0;
+    if (!e->svfChain || e->svfChainSpans <= 0) return CPQ_OK;
+    (void)hipSetDevice(e->device);
+    uint32_t hdr[4] = { 0, 0, 0, 0 };          // generation, finished workgroups, ticket, error (svf_kernels.hip: TpvChainHeader)
+    CPQ_HIP(e, hipStreamSynchronize(e->stream));
+    CPQ_HIP(e, hipMemcpy(hdr, e->svfChain, sizeof(hdr), hipMemcpyDeviceToHost));
+    *launches = hdr[0];
+    *gaveUp = hdr[3];
+    return CPQ_OK;
+}
+
 int32_t cpq_diag_partition_fft(int32_t P, int32_t nCh, int32_t T, const double* in, double* spectra, double* out)
 {
     if (P < 64 || P > 131072 || (P & (P - 1)) || nCh <= 0 || T <= 0 || !in || !spectra || !out) return CPQ_ERR_INVALID_ARG;
@@ -328,6 +343,12 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
     // ---- arena layout
     struct Item { void** ptr; int64_t bytes; };
     const int64_t nCh = e->nCh;
+    {
+        int nCu = 0;
+        if (hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); nCu = 0; }
+        e->svfChainGrid = 2 * nCu;          // the span kernel keeps 76 KB of LDS: two workgroups per CU
+    }
+    const bool chained = nCh < e->svfChainGrid && e->maxCall >= 2 * 8192;
     Item items[] = {
         { (void**)&e->X, nCh * e->ringSlots * e->P * (int64_t)sizeof(double2) },
         { (void**)&e->XDN, nCh * e->ringSlots * (int64_t)sizeof(double2) },
@@ -351,11 +372,11 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->ofSatGain, nCh * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofState, nCh * kBands * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
-        // hand-over words between the band-pipelined stages of one channel (time-parallel cascade, svf_kernels.hip): only
-        // engines whose channels alone leave room for a second workgroup per channel ever use them
-        { (void**)&e->svfChain, nCh <= 256 ? (int64_t)cpq::svf_chain_bytes((int)nCh, e->maxCall) : 0 },
+        // chained spans of the time-parallel cascade (svf_kernels.hip): header + the band states handed from span to span;
+        // only engines with fewer channels than the chip holds workgroups of that kernel (two per CU) use them
+        { (void**)&e->svfChain, chained ? (int64_t)cpq::svf_chain_bytes((int)nCh, e->maxCall) : 0 },
     };
-    e->svfChainSpans = nCh <= 256 ? (int)(cpq::svf_chain_bytes(1, e->maxCall) / cpq::svf_chain_bytes(1, 0)) : 0;
+    e->svfChainSpans = chained ? cpq::svf_chain_spans(e->maxCall) : 0;
     int64_t total = 0;
     for (const Item& it : items) total += alignUp(it.bytes, 256);
     if (hipMalloc((void**)&e->arena, (size_t)total) != hipSuccess) {
@@ -428,9 +449,6 @@ void cpq_engine_destroy(cpq_engine* e)
     }
     freeGroups(e);
     freePinnedRing(e);
-    if (e->ovl.side) (void)hipStreamDestroy(e->ovl.side);
-    if (e->ovl.convA) (void)hipEventDestroy(e->ovl.convA);
-    if (e->ovl.eqA) (void)hipEventDestroy(e->ovl.eqA);
     if (e->copyIn) {
         (void)hipStreamDestroy(e->copyIn);
         (void)hipStreamDestroy(e->copyOut);
@@ -548,47 +566,9 @@ int32_t cpq_engine_set_order(cpq_engine* e, int32_t order)
 
 
 // ------------------------------------------------------------------------ whole path
-// Does this call go through in two halves (Overlap, engine_internal.hpp)?  Only the plain configuration: kernel-level
-// convolver on the uniform path, then the EQ on the time-parallel kernels with nothing else between or beside them, long
-// calls, and enough channels that half of them still give every CU a workgroup of the cascade (which also keeps the cascade
-// off its band-pipelined stages, whose streams and events are per device).
-static bool overlapQualifies(cpq_engine* e, int n)
-{
-    auto& o = e->ovl;
-    // off unless CPQ_OVERLAP=1: measured SLOWER (11.8 against 10.5 ms per call of 256 streams, profiles/r03l_conv_eq_overlap.txt) --
-    // both sides need all four wave slots of a SIMD (128 registers each) for their own throughput, and sharing a CU halves both
-    if (o.enabled < 0) { const char* f = getenv("CPQ_OVERLAP"); o.enabled = (f && f[0] == '1') ? 1 : 0; }
-    if (!o.enabled) return false;
-    if (e->order != CPQ_ORDER_CONV_THEN_EQ || e->convBypassed || e->convLevel == CPQ_LEVEL_PROCESSOR) return false;
-    if (!e->mainActive || !e->groups.empty() || e->layered || e->anyDirect) return false;
-    if (e->anyAgc || e->anyEqBypass || e->anyEqReset || e->eqMode != CPQ_EQ_MODE_AUTO) return false;
-    for (char s : e->eqTpSafe) if (!s) return false;
-    for (char m : e->eqMidSide) if (m) return false;
-    for (size_t s = 0; s < e->gainRamp.size(); ++s) {
-        const auto& g = e->gainRamp[s];
-        if (!e->agcOnHost[s] && (g.remaining > 0 || std::fabs(g.target - g.wanted) > 1e-6 || g.current != g.wanted)) return false;
-    }
-    int nCu = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) nCu = prop.multiProcessorCount; else (void)hipGetLastError(); }
-    if (e->nCh < 2 * nCu || (e->nCh & 3) || (n & 1) || n < 16 * 8192) return false;
-    if (!o.side) {
-        if (hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&o.convA, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&o.eqA, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            o.enabled = 0;
-            return false;
-        }
-    }
-    return true;
-}
-
 static int enqueueBoth(cpq_engine* e, const double* a, double* b, int n)
 {
     int rc = CPQ_OK;
-    struct Disarm { cpq_engine* e; ~Disarm() { e->ovl.armed = false; e->ovl.convSplit = false; } } disarm{ e };      // the kernel-level entry points never split
-    e->ovl.convSplit = false;
-    e->ovl.armed = overlapQualifies(e, n);
-    if (e->ovl.armed) { e->ovl.c0 = (e->nCh / 2) & ~1; e->ovl.uploadSeqAtArm = e->uploadSeq; }
     auto conv = [e](const double* x, double* y, int t) {
         return e->convLevel == CPQ_LEVEL_PROCESSOR ? enqueueConvProc(e, x, y, t) : enqueueConv(e, x, y, t);
     };

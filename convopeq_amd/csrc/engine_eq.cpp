@@ -11,38 +11,10 @@ int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t strid
                    bool streamPairs = false)
 {
     const int nTp = tp ? (n & ~1) : 0;            // the time-parallel kernels take any even number of samples (chunks of two at the least); a last odd sample goes to the sequential kernel
-    if (e->ovl.convSplit) {
-        // The convolver ran in two halves (Overlap, engine_internal.hpp).  First half: on the side stream, behind its own
-        // convolution only; second half: on the engine's stream, behind everything; the engine's stream then waits for the
-        // side stream.  Only when this launch is the next thing the call does with these channels -- nothing has been
-        // uploaded on the engine's stream since the call began, whole call on the time-parallel kernels --: otherwise the
-        // one launch below, which is ordered behind both halves anyway.
-        e->ovl.convSplit = false;
-        if (idTp == CPQ_K_SVF_TP && nTp == n && e->uploadSeq == e->ovl.uploadSeqAtArm) {
-            const int c0 = e->ovl.c0;
-            auto half = [&](int cA, int cnt) {
-                ProfScope p(e, idTp);
-                cpq::launch_svf_cascade_tp(e->stream, dIn + cA * stride, dOut + cA * stride, stride, cnt, nTp,
-                                           coef + (int64_t)cA * kBands * 6, flags + (int64_t)cA * kBands, satGain + (int64_t)cA * 2,
-                                           state + (int64_t)cA * kBands * 2, tables + (int64_t)(cA / 2) * kBands * cpq::kSvfTpTableDoubles,
-                                           nullptr, 0, nullptr);
-            };
-            CPQ_HIP(e, hipStreamWaitEvent(e->ovl.side, e->ovl.convA, 0));
-            {
-                StreamOverride so(e, e->ovl.side);
-                half(0, c0);
-                CPQ_HIP(e, hipEventRecord(e->ovl.eqA, e->ovl.side));
-            }
-            half(c0, e->nCh - c0);
-            CPQ_HIP(e, hipStreamWaitEvent(e->stream, e->ovl.eqA, 0));
-            CPQ_HIP(e, hipGetLastError());
-            return CPQ_OK;
-        }
-    }
     if (nTp > 0) {
         ProfScope p(e, idTp);
         cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables,
-                                   e->svfChainSpans > 0 ? e->svfChain : nullptr, e->svfChainSpans, &e->svfTicket);
+                                   e->svfChainSpans > 0 ? e->svfChain : nullptr, e->svfChainSpans, e->svfChainGrid);
     }
     if (n > nTp) {
         ProfScope p(e, idSeq);

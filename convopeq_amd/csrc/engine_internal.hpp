@@ -143,22 +143,10 @@ struct cpq_engine {
     double* ofSatGain = nullptr;
     double* ofState = nullptr;  // [nCh][20][2]  w1 w2
     double* ofTp = nullptr;     // [streams][20][kSvfTpTableDoubles]
-    void* svfChain = nullptr;   // [channels][<= 20 stages][svfChainSpans] hand-over words of the band-pipelined stages (time-parallel cascade), or none
+    void* svfChain = nullptr;   // chained spans of the time-parallel cascade: header + [channels][svfChainSpans][20][4] granules, or none
     int svfChainSpans = 0;
-    // Two-half overlap of a call (engine_core.cpp: enqueueBoth): the convolver's kernels are HBM-bound, the EQ cascade is
-    // fp64-issue bound, so the call's channels go through in two halves -- conv(A), conv(B) on the engine's stream, EQ(A) on
-    // a side stream behind conv(A) and next to conv(B), EQ(B) behind conv(B) -- and the stream joins at the end of the EQ.
-    struct Overlap {
-        hipStream_t side = nullptr;
-        hipEvent_t convA = nullptr, eqA = nullptr;
-        bool armed = false;          // this call qualifies (decided in enqueueBoth)
-        bool convSplit = false;      // the convolver ran in two halves and recorded convA
-        int c0 = 0;                  // first channel of the second half (even: whole streams)
-        unsigned long long uploadSeqAtArm = 0;
-        int enabled = -1;            // CPQ_OVERLAP=1 (default off: measured slower, see overlapQualifies)
-    } ovl;
+    int svfChainGrid = 0;       // workgroups of the span kernel the device holds at once (2 per CU)
     unsigned long long uploadSeq = 0;   // staged uploads so far (they are ordered on the engine's stream only)
-    unsigned long long svfTicket = 0;   // one per time-parallel launch: marks the slots that launch wrote
     bool ofSet = false, ofTpSafe = true, ofInPath = false;
 
     // run-time state

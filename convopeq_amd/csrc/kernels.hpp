@@ -78,13 +78,16 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 // for each chunk length LC in kSvfTpLc ({16, 2} at 4 waves per channel): Mk[6][4] = A^(LC 2^k), Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)),
 // G[16][2] = C A^i.
 // geometry constants kSvfTpWaves / kSvfTpLc / kSvfTpTableDoubles: host_design.hpp (shared with the table builder)
-// chain / chainSpans / ticket: hand-over slots for several workgroups per channel (svf_chain_bytes(nCh, largest call)
-// bytes, zero-initialised once; ticket = the engine's launch counter), or nullptr: one workgroup per channel.
+// chain / chainSpans / chainGrid: chained spans for engines with fewer channels than the chip holds workgroups of the span
+// kernel (chainGrid = 2 per CU): the (span, channel) pairs of a call are dealt to chainGrid workgroups, a band's state is
+// handed from span to span through `chain` (svf_chain_bytes(channels, largest call) bytes, zero-initialised once,
+// chainSpans = svf_chain_spans(largest call); used by one launch at a time).  nullptr / 0: one workgroup per channel.
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh,
                            int nSamples, const double* coef, const int* flags, const double* satGain,
                            double* state, const void* tables, void* chain = nullptr, int chainSpans = 0,
-                           unsigned long long* ticket = nullptr);
+                           int chainGrid = 0);
 size_t svf_chain_bytes(int nCh, int maxSamples);
+int svf_chain_spans(int maxSamples);
 
 // Processor-level dry/wet stage (ConvolverProcessor::process): out = sanitize(wet) * wetG + dryDelayed * dryG over one
 // range of a call.  The dry signal is read from the delay ring ([nCh][ringSize], the call's input already written at

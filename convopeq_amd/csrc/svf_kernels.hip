@@ -17,9 +17,6 @@
 // This file is compiled with -ffp-contract=off: fused operations appear only where written as fma().
 #include "kernels.hpp"
 
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
 
 namespace cpq {
 
@@ -310,9 +307,6 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 // 7 operations per sample instead of 10).  Both band kinds share it.
 // ORDER 2: one second-order step instead (r (1 + e): relative error e^2 <= 2.2e-15 in r, <= 0.4 ... 2 e-15 in the result
 // for sat = 0.2 ... 1 -- the size of the other rounding errors of a band; one operation less).
-#ifndef CPQ_TP_BATCH_RCP
-#define CPQ_TP_BATCH_RCP 1      // one v_rcp_f64 per four samples in the small-signal output stage (A/B: tools/ab_tpv.sh)
-#endif
 template <int N, int ORDER = 3>
 __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 {
@@ -320,7 +314,6 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
     double den[N], r[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) den[j] = fma(y[j], y[j], 3.0);
-#if CPQ_TP_BATCH_RCP
     if (N == 4 && ORDER == 2) {
         // one reciprocal for the four denominators (v_rcp_f64 issues at a quarter of the FMA rate): 1 / (d0 d1 d2 d3),
         // refined once, then multiplied back apart -- 27 issue slots for four samples instead of 36.  The denominators
@@ -344,7 +337,6 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
         y[1 % N] *= fma(cb, q * den[0], ca);
         return;
     }
-#endif
 #pragma unroll
     for (int j = 0; j < N; ++j) r[j] = __builtin_amdgcn_rcp(den[j]);
 #pragma unroll
@@ -439,15 +431,76 @@ __device__ __forceinline__ TpLanePowers tp_load_powers(const double* __restrict_
     return p;
 }
 
+// ---- geometry and hand-over of the vector-form kernel (k_svf_cascade_tpv, below); tp_scan carries the hand-over
+constexpr int kTpvWaves = 8;                    // waves of the span kernel
+constexpr int kTpvSpan = kTpvWaves * 1024;      // samples per span
+constexpr unsigned kTpvApplyGain = 1u << 31;    // bandFilter bit: this launch applies the channel's output gain
+constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
+constexpr int kTpvGuardPiece = 2048;    // samples per staged piece of the guarded path
+constexpr int kTpvU = 2;                // samples per group of the small-signal output stage (one v_rcp_f64 per group)
+constexpr unsigned kTpvSpinLimit = 1u << 22;    // polls of a hand-over before the launch gives up (seconds; a guarded span takes milliseconds)
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define CPQ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// header of the chain buffer (64 bytes), then the granules [channel][chainSpans][band][4]
+struct TpvChainHeader { unsigned gen, done, ticket, error, pad[12]; };
+static_assert(sizeof(TpvChainHeader) == 64, "chain header");
+
+// hand-over of one task (all wave-uniform)
+struct TpvLink {
+    const unsigned long long* poll;   // granules [band][4] of the same channel's span before this one; nullptr: first span
+    unsigned long long* pub;          // granules of this span; nullptr: last span of the call
+    unsigned epoch;
+    int* flag;                        // LDS: != 0 once a start state outside the proven range has arrived (1 + band)
+    unsigned* error;                  // header word: a poll gave up
+};
+
+// lanes 0 ... 3 of the calling wave read one granule each until all four carry this launch's epoch
+__device__ __forceinline__ void tpv_poll_state(const unsigned long long* g, unsigned epoch, int lane, double& sx, double& sy, unsigned* error)
+{
+    unsigned long long v = 0;
+    bool ok = lane >= 4;
+    for (unsigned spins = 0;; ++spins) {
+        if (!ok) {
+            v = __hip_atomic_load((const gu64*)(g + lane), CPQ_RLX_AGENT);
+            ok = (unsigned)(v >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        // bounded: a launch that cannot make progress (a bug) sets the error word and runs out on whatever it reads
+        if ((spins & 1023u) == 1023u &&
+            (spins >= kTpvSpinLimit || __hip_atomic_load((const gu32*)error, CPQ_RLX_AGENT) != 0u)) {
+            if (lane == 0) __hip_atomic_store((gu32*)error, 1u, CPQ_RLX_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const int h = (int)(unsigned)v;
+    sx = __hiloint2double(__builtin_amdgcn_readlane(h, 1), __builtin_amdgcn_readlane(h, 0));
+    sy = __hiloint2double(__builtin_amdgcn_readlane(h, 3), __builtin_amdgcn_readlane(h, 2));
+}
+// one lane: the four granules of a band's end state
+__device__ __forceinline__ void tpv_publish_state(unsigned long long* g, unsigned epoch, double sx, double sy)
+{
+    const unsigned long long e = (unsigned long long)epoch << 32;
+    __hip_atomic_store((gu64*)(g + 0), e | (unsigned)__double2loint(sx), CPQ_RLX_AGENT);
+    __hip_atomic_store((gu64*)(g + 1), e | (unsigned)__double2hiint(sx), CPQ_RLX_AGENT);
+    __hip_atomic_store((gu64*)(g + 2), e | (unsigned)__double2loint(sy), CPQ_RLX_AGENT);
+    __hip_atomic_store((gu64*)(g + 3), e | (unsigned)__double2hiint(sy), CPQ_RLX_AGENT);
+}
+
 // ONE workgroup barrier per band: the wave totals go through wtot[parity] (the caller flips the parity per band, so a
 // wave that is already in the next band writes the other half while slow waves still read this one) and the span's
 // end state goes to sNext while every wave reads the start state from sCur (the caller swaps the two per span).
 // Plate != nullptr: the per-lane powers are loaded from there right where they are used (register-tight callers: the
 // loads then wait on L2 behind the other waves of the SIMD) and pw is ignored.
-template <int NTHREADS = kTpChunks>
+// CHAINED (link != nullptr): the span's start state of band b arrives from the workgroup that has the span before (four
+// lanes of wave 0 poll for it in front of the barrier), the end state is published to the workgroup that has the span behind.
+template <int NTHREADS = kTpChunks, bool CHAINED = false>
 __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, double& s0y, const double* Mall, int b,
-                                        const TpLanePowers& pw, double* wtot, const double* sCur, double* sNext, int tid,
-                                        const double* __restrict__ Plate = nullptr, int endTid = -1)
+                                        const TpLanePowers& pw, double* wtot, double* sCur, double* sNext, int tid,
+                                        const double* __restrict__ Plate = nullptr, int endTid = -1, const TpvLink* link = nullptr)
 {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the chain below branches on it
@@ -494,32 +547,21 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     }
     if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
     if (Plate) { pc01 = Pl[lane * 2]; pc23 = Pl[lane * 2 + 1]; }
+    if (CHAINED && link->poll && wave == 0) {
+        double px, py;
+        tpv_poll_state(link->poll + b * 4, link->epoch, lane, px, py, link->error);
+        if (lane == 0) {
+            sCur[2 * b] = px;
+            sCur[2 * b + 1] = py;
+            // outside the range the host proved guard-free: the span is run again on the guarded path (tpv_fast_span)
+            if (!(fabs(px) < kTpInputBound && fabs(py) < kTpInputBound) && *link->flag == 0) *link->flag = 1 + b;
+        }
+    }
     __syncthreads();
     // state at the start of this wave's segment: the span's start state carried through the totals of the waves before it
     double bx = sCur[2 * b], by = sCur[2 * b + 1];
     const double2 mw01 = Mb2[12], mw23 = Mb2[13];
     const double mw0 = mw01.x, mw1 = mw01.y, mw2 = mw23.x, mw3 = mw23.y;
-#if CPQ_TP_CHAIN_PRELOAD
-    if (Plate && (NTHREADS ? NTHREADS : (int)blockDim.x) <= 512) {
-        // the totals of the waves before this one, all requested at once (one LDS latency instead of one per step: the last
-        // wave's chain of seven steps is on the critical path of every band), kept apart from the per-lane power loads below
-        // so that the 28 registers are free again before those are issued
-        __builtin_amdgcn_sched_barrier(0);
-        double2 tt[7];
-#pragma unroll
-        for (int w = 0; w < 7; ++w) tt[w] = *reinterpret_cast<const double2*>(wtot + 2 * w);
-#pragma unroll
-        for (int w = 0; w < 7; ++w) {
-            if (w < wave) {          // wave-uniform
-                const double nx = fma(mw1, by, fma(mw0, bx, tt[w].x));
-                const double ny = fma(mw3, by, fma(mw2, bx, tt[w].y));
-                bx = nx;
-                by = ny;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    } else
-#endif
     for (int w = 0; w < wave; ++w) {
         const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
         const double nx = fma(mw1, by, fma(mw0, bx, tx));
@@ -533,7 +575,11 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
     s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
     if (lane == 0) { s0x = bx; s0y = by; }
     // end of the span: the state behind the last chunk (endTid >= 0: behind chunk endTid -- a span whose tail is padding)
-    if (tid == (endTid >= 0 ? endTid : (NTHREADS ? NTHREADS : (int)blockDim.x) - 1)) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }
+    if (tid == (endTid >= 0 ? endTid : (NTHREADS ? NTHREADS : (int)blockDim.x) - 1)) {
+        sNext[2 * b] = sx;
+        sNext[2 * b + 1] = sy;
+        if (CHAINED && link->pub && *link->flag == 0) tpv_publish_state(link->pub + b * 4, link->epoch, sx, sy);
+    }
 }
 
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
@@ -783,77 +829,26 @@ __global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, 
 //   (2) ONE pass over the 16 samples runs the reference recurrence from the true start state, applies the output stage
 //       and feeds the next band's E x: no zero-state run, no state-response fix-up, no cross-lane traffic inside a band.
 // Band coefficients are wave-uniform SGPR operands, the E rows come from LDS as broadcast reads, the per-lane scan powers
-// are requested one band ahead.  Span I/O: coalesced 16-byte accesses, transposed to chunk-per-lane through the wave's
-// own padded LDS buffer (two halves of eight samples); the next span's lines are requested into L2 while the bands run.
-// WAVES > 0: whole spans of WAVES x 1024 samples, the workgroup walks the spans of its channel (STAGED: several
-// workgroups per channel, each with a run of the bands, below); WAVES = 0: ONE span of blockDim.x / 64 (1 ... 7)
-// waves x 1024 samples (what a call leaves after its whole spans).
-// A span whose input or start state is outside the range for which the host proved the reference's guards idle ends the
-// fast loop: that span and the workgroup's later ones go through the one-thread guarded recurrence behind the loop
-// (cold code, kept out of the band loop's register allocation).
-
-// Band-pipelined stages (STAGED; engines with fewer channels than the chip has room for workgroups): the cascade is a
-// pipeline in the band index too, so nStages workgroups share one channel, workgroup g running bands [g, g + 1) * 20 /
-// nStages over ALL spans, one span behind workgroup g - 1 -- it reads what that one stored (in `out`, in place) and
-// stores its own result over it.  One release / acquire pair per span and stage (an earlier form that split the SPANS
-// over the workgroups handed the band states over instead, 20 pairs per span, and lost more to the L2 write-backs than
-// it gained: profiles/r03b_eq_chained_spans.txt).  Blocks are numbered stage-major: a consumer only ever waits for a
-// workgroup with a lower block index, which the dispatcher has placed before it -- resident or finished, whatever else
-// runs on the chip.
-// Hand-over between the stages of one launch (band-pipelined stages, below): one 64-bit word per (channel, stage, span),
-// holding the launch's ticket once that stage has stored that span.  Tickets differ from launch to launch, so the words
-// are never cleared.  The accesses are relaxed: the fast path moves the span itself with agent-scope accesses and needs
-// no fence (tpv_span_load), the guarded path puts its own fences around them.
-#ifndef CPQ_TPV_FLAG_FENCED
-#define CPQ_TPV_FLAG_FENCED 1
-#endif
-__device__ __forceinline__ void tpv_span_publish(unsigned long long* flag, unsigned long long ticket)
-{
-    __hip_atomic_store(flag, ticket, CPQ_TPV_FLAG_FENCED ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void tpv_span_await(const unsigned long long* flag, unsigned long long ticket)
-{
-    while (__hip_atomic_load(flag, CPQ_TPV_FLAG_FENCED ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(8);
-}
-
-// tuning of the pass (A/B with tools/ab_tpv.sh): samples per group of the small-signal output stage; order of its
-// reciprocal refinement; the seven-operation recurrence for bands with m0 == 1 and m2 == 0
-#ifndef CPQ_TPV_U
-#define CPQ_TPV_U 2
-#endif
-#ifndef CPQ_TPV_ORDER
-#define CPQ_TPV_ORDER 2
-#endif
-#ifndef CPQ_TPV_PEAK
-#define CPQ_TPV_PEAK 1
-#endif
-#ifndef CPQ_TPV_RARE_UNROLLED
-#define CPQ_TPV_RARE_UNROLLED 0
-#endif
-#ifndef CPQ_TPV_HL
-#define CPQ_TPV_HL 1
-#endif
-#ifndef CPQ_TPV_HS
-#define CPQ_TPV_HS 1
-#endif
-#ifndef CPQ_TPV_LAUNDER
-#define CPQ_TPV_LAUNDER 1
-#endif
-#ifndef CPQ_TP_CHAIN_PRELOAD
-#define CPQ_TP_CHAIN_PRELOAD 0
-#endif
-#ifndef CPQ_TPV_PREFETCH
-#define CPQ_TPV_PREFETCH 0      // bands before the end of a span at which the next span is requested into L2; 0 = never: it buys 2.5 % of the kernel time for 1.35 ... 1.56 x the HBM traffic (profiles/r03e_ab_eq_prefetch.txt)
-#endif
-#ifndef CPQ_TPV_WAVES
-#define CPQ_TPV_WAVES 8
-#endif
-constexpr int kTpvWaves = CPQ_TPV_WAVES;          // waves of the span kernel
-constexpr int kTpvSpan = kTpvWaves * 1024;      // samples per span
-constexpr unsigned kTpvApplyGain = 1u << 31;      // bandFilter bit: this launch applies the channel's output gain (the last stage)
-constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
-constexpr int kTpvGuardPiece = 2048;    // samples per staged piece of the guarded path
-
+// live in LDS.  Span I/O: coalesced 16-byte accesses, transposed to chunk-per-lane through the wave's own padded LDS
+// buffer (four quarters of four samples).
+// WAVES > 0: whole spans of WAVES x 1024 samples; one workgroup per channel walks the spans of its channel, or (CHAINED)
+// the spans of all channels are dealt to the workgroups through a ticket, below.  WAVES = 0: ONE span of blockDim.x / 64
+// (1 ... 7) waves x 1024 samples (what a call leaves after its whole spans).
+// A span whose input or start state is outside the range for which the host proved the reference's guards idle goes
+// through the one-thread guarded recurrence (cold code, kept out of the band loop's register allocation).
+//
+// Chained spans (CHAINED; engines with fewer channels than the chip has room for workgroups).  A band's state at the
+// end of span s is its state at the start of span s + 1: with the bands of a span run one behind the other, span s + 1
+// can follow span s ONE BAND behind, on another workgroup.  The (span, channel) pairs are tasks in span-major order,
+// taken by the workgroups through an atomic ticket: a task only ever waits for the task of the same channel one span
+// earlier, whose ticket is lower and therefore already held by a running (or finished) workgroup -- no deadlock whatever
+// the grid, the residency or the dispatch order.  The hand-over per (channel, span, band) is the band's end state, two
+// doubles, as four 8-byte granules {epoch : 32 | half a double : 32}, each written by ONE write-through (sc1) store and
+// polled with sc1 loads by four lanes of the consumer's first wave: the data is the flag, no fence on either side
+// (a release / acquire pair per band writes back / invalidates the XCD's whole L2 and cost more than the chaining gained,
+// profiles/r03b_eq_chained_spans.txt).  The epoch is the launch's generation, kept in device memory (header of the chain
+// buffer: the last workgroup of a launch to finish advances it), so the granules are never cleared and a captured launch
+// replays correctly.
 // what the kernel keeps in LDS (8 waves: 76 KB, two workgroups per CU)
 template <int MAXW>
 struct TpvShared {
@@ -866,7 +861,8 @@ struct TpvShared {
     double stateA[kBands * 2], stateB[kBands * 2];
     alignas(16) double wtot[2 * 2 * MAXW];
     int flag;
-    int bandBad[kBands];
+    int task;                                                  // chained spans: the task the workgroup took; the launch's epoch
+    unsigned epoch;
 };
 
 // One band over the lane's 16 samples from its true start state.  KIND 0 / 3: SVF band, general / with m0 == 1 and m2 == 0
@@ -894,36 +890,25 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
 #pragma unroll
         for (int j = 0; j < 16; ++j) small &= (int)(fabs(x[j]) < 4.5);      // a NaN fails and takes the general code
         if (smallOk && __all(small)) {
-            // CPQ_TPV_U at a time, kept apart in the schedule: sixteen evaluations in flight at once do not fit the registers
+            // kTpvU at a time, kept apart in the schedule: sixteen evaluations in flight at once do not fit the registers
 #pragma unroll
-            for (int h = 0; h < 16 / CPQ_TPV_U; ++h) {
-                double v[CPQ_TPV_U];
+            for (int h = 0; h < 16 / kTpvU; ++h) {
+                double v[kTpvU];
 #pragma unroll
-                for (int j = 0; j < CPQ_TPV_U; ++j) v[j] = x[CPQ_TPV_U * h + j];
-                if (SAT) tp_nonlinear_small<CPQ_TPV_U, CPQ_TPV_ORDER>(v, smallC1);
+                for (int j = 0; j < kTpvU; ++j) v[j] = x[kTpvU * h + j];
+                if (SAT) tp_nonlinear_small<kTpvU, 2>(v, smallC1);
 #pragma unroll
-                for (int j = 0; j < CPQ_TPV_U; ++j) {
-                    const double2 ee = *reinterpret_cast<const double2*>(En + 2 * (CPQ_TPV_U * h + j));
+                for (int j = 0; j < kTpvU; ++j) {
+                    const double2 ee = *reinterpret_cast<const double2*>(En + 2 * (kTpvU * h + j));
                     e0 = fma(ee.x, v[j], e0);
                     e1 = fma(ee.y, v[j], e1);
-                    x[CPQ_TPV_U * h + j] = v[j];
+                    x[kTpvU * h + j] = v[j];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             done = true;
         } else {
             // rare: a sample at or above the fastTanh clip threshold somewhere in the wave
-#if CPQ_TPV_RARE_UNROLLED
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                double v[4] = { x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3] };
-                if (mono) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
-                else      tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[4 * h + j] = v[j];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
 #pragma unroll 1
             for (int h = 0; h < 4; ++h) {
                 // rotate instead of indexing: x stays in registers
@@ -935,7 +920,6 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[12 + j] = v[j];
             }
-#endif
         }
     }
     if (!done) {
@@ -953,34 +937,12 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
 // span <-> registers: 8 coalesced 16-byte accesses per lane, transposed through the wave's LDS buffer in four quarters
 // (samples 4 h ... 4 h + 3 of every chunk: 64 rows of kTpvQStride).  Lane l of access k holds samples 2 (l & 7), + 1 of
 // chunk 8 k + (l >> 3): the lanes with ((l >> 1) & 3) == h belong to quarter h.
-// COHERENT (the hand-over between band-pipelined stages): the accesses carry the agent-scope bit, i.e. they go past the
-// L2 of this XCD to where the other XCDs see them -- what an agent-scope atomic access does, 16 bytes wide.  The stages
-// then need no release / acquire fence around the hand-over: a fence writes back, or invalidates, the whole L2 of the XCD,
-// and with hundreds of workgroups doing that per span it cost several times the kernel (profiles/r03h_eq_staged_kernel.txt).
-template <bool COHERENT>
 __device__ __forceinline__ void tpv_span_load(const double* src, double* buf, int lane, double (&x)[16])
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
     v2 t[8];
-    if (COHERENT) {
-        const double* p0 = src + lane * 2;
-        const double* p1 = p0 + 4 * 128;
-        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
-                     "global_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
-                     "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
-                     "global_load_dwordx4 %4, %9, off sc1\n\t"
-                     "global_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
-                     "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
-                     : "v"(p0), "v"(p1)
-                     : "memory");
-    } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = __builtin_nontemporal_load(reinterpret_cast<const v2*>(src + k * 128 + lane * 2));
-    }
+    for (int k = 0; k < 8; ++k) t[k] = __builtin_nontemporal_load(reinterpret_cast<const v2*>(src + k * 128 + lane * 2));
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         if (((lane >> 1) & 3) == h) {
@@ -998,61 +960,22 @@ __device__ __forceinline__ void tpv_span_load(const double* src, double* buf, in
         wave_lds_sync();
     }
 }
-// How a span leaves the registers (A/B: tools/ab_tpv.sh, profiles/r03o_ab_eq_span_store.txt).  The lanes of quarter h pick
-// their eight 16-byte pieces out of the exchange buffer; collected in an array t[8] that is assigned under `if (quarter ==
-// mine)`, t[] enters the quarter loop undefined -- and with it left at that (0) the compiler kept a 32-register "don't care"
-// tuple alive across the whole SPAN loop, spilled and reloaded per span: 128 + 128 bytes of scratch traffic per lane and
-// span, as much HBM traffic again as the span itself (PMC 8.6 GB per launch against 4.3 GB algorithmic,
-// profiles/r03n_pmc_traffic.json).  2 (default): an empty asm defines the registers at the top of the function; 1: every
-// lane reads every quarter and selects; 3: no array, the lanes of a quarter store their pieces right away (32-byte runs).
-#ifndef CPQ_TPV_STORE
-#define CPQ_TPV_STORE 2
-#endif
-template <bool COHERENT>
+// The lanes of quarter h pick their eight 16-byte pieces out of the exchange buffer into t[8], assigned under `if (quarter
+// == mine)`.  t[] would enter the quarter loop undefined, and the compiler then keeps a 32-register "don't care" tuple alive
+// across the whole SPAN loop, spilled and reloaded per span (as much HBM traffic again as the span itself:
+// profiles/r03n_pmc_traffic.json, r03o_ab_eq_span_store.txt); an empty asm defines the registers at the top of the function.
 __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lane, const double (&x)[16], double gain)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
-#if CPQ_TPV_STORE == 3
-    // the lanes of quarter h store their eight 16-byte pieces right away (32 contiguous bytes per lane pair)
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            *reinterpret_cast<double2*>(buf + lane * kTpvQStride + 2 * j) = make_double2(x[4 * h + 2 * j] * gain, x[4 * h + 2 * j + 1] * gain);
-        wave_lds_sync();
-        if (((lane >> 1) & 3) == h) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
-                double* p = dst + k * 128 + lane * 2;
-                if (COHERENT) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v2{ v.x, v.y }) : "memory");
-                else          __builtin_nontemporal_store(v2{ v.x, v.y }, reinterpret_cast<v2*>(p));
-            }
-        }
-        wave_lds_sync();
-    }
-    if (COHERENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     v2 t[8];
-#if CPQ_TPV_STORE == 2
 #pragma unroll
     for (int k = 0; k < 8; ++k) asm volatile("" : "=v"(t[k]));
-#endif
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             *reinterpret_cast<double2*>(buf + lane * kTpvQStride + 2 * j) = make_double2(x[4 * h + 2 * j] * gain, x[4 * h + 2 * j + 1] * gain);
         wave_lds_sync();
-#if CPQ_TPV_STORE == 1
-        const bool mine = ((lane >> 1) & 3) == h;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
-            if (h == 0) t[k] = v2{ v.x, v.y };
-            else        t[k] = v2{ mine ? v.x : t[k].x, mine ? v.y : t[k].y };
-        }
-#else
         if (((lane >> 1) & 3) == h) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1060,72 +983,34 @@ __device__ __forceinline__ void tpv_span_store(double* dst, double* buf, int lan
                 t[k] = v2{ v.x, v.y };
             }
         }
-#endif
         wave_lds_sync();
     }
-    if (COHERENT) {
-        double* p0 = dst + lane * 2;
-        double* p1 = p0 + 4 * 128;
-        // (waits for the stores to be acknowledged: the flag that announces them goes out behind the barrier that follows)
-        asm volatile("global_store_dwordx4 %8, %0, off sc1\n\t"
-                     "global_store_dwordx4 %8, %1, off offset:1024 sc1\n\t"
-                     "global_store_dwordx4 %8, %2, off offset:2048 sc1\n\t"
-                     "global_store_dwordx4 %8, %3, off offset:3072 sc1\n\t"
-                     "global_store_dwordx4 %9, %4, off sc1\n\t"
-                     "global_store_dwordx4 %9, %5, off offset:1024 sc1\n\t"
-                     "global_store_dwordx4 %9, %6, off offset:2048 sc1\n\t"
-                     "global_store_dwordx4 %9, %7, off offset:3072 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     :
-                     : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(p0), "v"(p1)
-                     : "memory");
-    } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(t[k], reinterpret_cast<v2*>(dst + k * 128 + lane * 2));
-    }
-#endif
+    for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(t[k], reinterpret_cast<v2*>(dst + k * 128 + lane * 2));
 }
 
-// Guarded run of the spans sp, sp + nGroups, ... of a channel: pieces of kTpvGuardPiece samples staged in the scratch area as
-// [chunk][sample], one thread runs the reference recurrence with every guard, band by band.  Chained spans: the start
-// states arrive band by band from the span before, the end states are published band by band (skipPub = bands of the
-// first span that the fast path already published before it found a start state out of range).
+// Guarded run of ONE span: pieces of kTpvGuardPiece samples staged in the scratch area as [chunk][sample], one thread runs
+// the reference recurrence with every guard, band by band; the states advance in sState.
 template <class SH>
-__device__ void tpv_guarded_spans(SH& sh, int sp, int nSpans, int spanLen, const double* inCh, double* outCh,
-                                  double* sState, const double* cf, unsigned activeMask, unsigned long long kinds, double sat,
-                                  double gain, const unsigned long long* awaitFlags, unsigned long long* publishFlags,
-                                  unsigned long long ticket, int tid, int nThreads)
+__device__ void tpv_guarded_span(SH& sh, int spanLen, const double* src, double* dst, double* sState, const double* cf,
+                                 unsigned activeMask, unsigned long long kinds, double sat, double gain, int tid, int nThreads)
 {
-    for (; sp < nSpans; ++sp) {
-        if (awaitFlags) {                     // (staged: the span as the stage before this one left it)
-            if (tid == 0) tpv_span_await(awaitFlags + sp, ticket);
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        for (int base = 0; base < spanLen; base += kTpvGuardPiece) {
-            const int cnt = (spanLen - base < kTpvGuardPiece) ? spanLen - base : kTpvGuardPiece;
-            const double* src = inCh + (int64_t)sp * spanLen + base;
-            double* dst = outCh + (int64_t)sp * spanLen + base;
-            __syncthreads();
-            for (int j = tid; j < cnt; j += nThreads) sh.scratch[(j >> 4) * kTpStride + (j & 15)] = src[j];
-            __syncthreads();
-            if (tid == 0) {
-                for (unsigned m = activeMask; m; m &= m - 1) {
-                    const int b = __builtin_ctz(m);
-                    const int kind = (int)((kinds >> (2 * b)) & 3);
-                    if (kind == 2)      tp_band_guarded<2>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
-                    else if (kind == 1) tp_band_guarded<1>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
-                    else                tp_band_guarded<0>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
-                }
+    for (int base = 0; base < spanLen; base += kTpvGuardPiece) {
+        const int cnt = (spanLen - base < kTpvGuardPiece) ? spanLen - base : kTpvGuardPiece;
+        __syncthreads();
+        for (int j = tid; j < cnt; j += nThreads) sh.scratch[(j >> 4) * kTpStride + (j & 15)] = src[base + j];
+        __syncthreads();
+        if (tid == 0) {
+            for (unsigned m = activeMask; m; m &= m - 1) {
+                const int b = __builtin_ctz(m);
+                const int kind = (int)((kinds >> (2 * b)) & 3);
+                if (kind == 2)      tp_band_guarded<2>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
+                else if (kind == 1) tp_band_guarded<1>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
+                else                tp_band_guarded<0>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
             }
-            __syncthreads();
-            for (int j = tid; j < cnt; j += nThreads) dst[j] = sh.scratch[(j >> 4) * kTpStride + (j & 15)] * gain;
         }
-        if (publishFlags) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            if (tid == 0) tpv_span_publish(publishFlags + sp, ticket);
-        }
+        __syncthreads();
+        for (int j = tid; j < cnt; j += nThreads) dst[base + j] = sh.scratch[(j >> 4) * kTpStride + (j & 15)] * gain;
     }
     __syncthreads();
 }
@@ -1137,13 +1022,22 @@ __device__ __forceinline__ double tpv_uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
+// the lane's index in its wave / the thread index, rebuilt from the lane count behind a value the compiler cannot see
+// through: kept in a register across the band loops they end up in scratch (the kernel sits at the 128-register limit)
+__device__ __forceinline__ int tpv_lane_id()
+{
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+}
+
 // The bands of `run` (one class: CLS 0 = SVF, 3 = SVF with output v0 + m1 v1, 2 = DF-II-T) over the span held in x: per band the scan of the chunk end
 // states, then the pass.  e0 / e1: E x of the run's first band on entry, of the first band of `rest` (the bands behind
 // the run) on exit.
-template <int CLS, bool SAT, int NT, class SH>
+template <int CLS, bool SAT, int NT, bool CHAINED, class SH>
 __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double& e1, int& par, unsigned run, unsigned rest,
                                              unsigned monoMask, SH& sh, double* sState, double* sNext, const double* __restrict__ cf,
-                                             double sat, int tid, int waveU, int nThreads, const double* prefetch)
+                                             double sat, int waveU, int nThreads, const TpvLink& link)
 {
     const double oneMinusSat = tpv_uniform(1.0 - sat);
     const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
@@ -1154,84 +1048,41 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
         const int b = __builtin_ctz(run);
         run &= run - 1;
         const int nb = run ? __builtin_ctz(run) : (rest ? __builtin_ctz(rest) : b);     // last band: its E x result is not used
-        // CPQ_TPV_PREFETCH bands before the end of the span: one 4-byte load per 128-byte line pulls the workgroup's next span
-        // into L2 (early enough to hide the HBM latency, late enough to still be there when the span load asks for it: issued
-        // at the start of the span it doubled the kernel's HBM reads, profiles/r03e_ab_eq_prefetch.txt)
-        if (CPQ_TPV_PREFETCH && prefetch && __builtin_popcount(run | rest) == CPQ_TPV_PREFETCH - 1)
-            (void)*reinterpret_cast<const volatile int*>(prefetch);
         double s0x, s0y;
-#if CPQ_TPV_LAUNDER
-        // the thread index and the LDS addresses derived from it are cheap to rebuild and expensive to keep: held across the
-        // band loop they end up in scratch (the kernel sits at the 128-register limit) and every band then waits for their
-        // reloads.  Rebuilt per band from the wave number (a scalar) and the lane count, behind a value the compiler cannot
-        // see through so that it does not hoist the lot out of the loop again.
-        int zero = 0;
-        asm volatile("" : "+s"(zero));
-        const int tidL = (waveU << 6) + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
-#else
-        const int tidL = tid;
-#endif
-        tp_scan<NT>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tidL, &sh.P[b][0][0]);
+        // (the thread index and the LDS addresses derived from it are rebuilt per band: tpv_lane_id)
+        const int tidL = (waveU << 6) + tpv_lane_id();
+        tp_scan<NT, CHAINED>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tidL, &sh.P[b][0][0], -1, &link);
         par ^= 1;
         tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1);
     }
 }
 
-template <int WAVES, bool STAGED>
-__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, (WAVES == 6 ? 3 : 4)) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
-                                                                              int nSpans, int nStages, const double* __restrict__ coef,
-                                                                              const int* __restrict__ flags,
-                                                                              const double* __restrict__ satGain,
-                                                                              double* __restrict__ state,
-                                                                              const TpBandTables* __restrict__ tables,
-                                                                              unsigned long long* handover,
-                                                                              unsigned long long ticket, unsigned bandFilter)
+// band masks of one channel: active bands of this launch; DF-II-T sections; SVF bands with the scalar fastTanh; SVF bands
+// whose output is v0 + m1 v1 (every peaking band).  Wave-uniform by construction; said so, they live in scalar registers
+// (left in vector registers they were spilled and reloaded inside the band loop).
+struct TpvBands { unsigned active, df, mono, peak; unsigned long long kinds; };
+__device__ __forceinline__ TpvBands tpv_band_masks(const int* __restrict__ flags, const double* __restrict__ cf, int c, unsigned bandFilter)
 {
-    constexpr int kMaxWaves = WAVES ? WAVES : 7;
-    constexpr int kNT = WAVES * 64;                           // 0: blockDim.x
-    __shared__ TpvShared<kMaxWaves> sh;
-    const int tid = threadIdx.x, nThreads = WAVES ? kNT : (int)blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    // staged: blocks [stage][channel]; stage g has the bands [g, g + 1) * 20 / nStages and applies the gain if it is the last
-    const int nChGrid = STAGED ? (int)gridDim.x / nStages : (int)gridDim.x;
-    const int stage = STAGED ? (int)blockIdx.x / nChGrid : 0;
-    const int c = (int)blockIdx.x - stage * nChGrid;
-    if (STAGED) {
-        const int per = kBands / nStages;
-        bandFilter = (((1u << per) - 1u) << (stage * per)) | (stage == nStages - 1 ? kTpvApplyGain : 0u);
-    }
-    const unsigned long long* awaitFlags = (STAGED && stage > 0) ? handover + ((int64_t)c * nStages + stage - 1) * nSpans : nullptr;
-    unsigned long long* publishFlags = (STAGED && stage < nStages - 1) ? handover + ((int64_t)c * nStages + stage) * nSpans : nullptr;
-    const int spanLen = nThreads * 16;
-    const double* __restrict__ cf = coef + (int64_t)c * kBands * 6;
-    const TpBandTables* __restrict__ tb = tables + (int64_t)(c >> 1) * kBands;
-    const int waveU = __builtin_amdgcn_readfirstlane(wave);
-    const double sat = tpv_uniform(satGain[c * 2]), gain = tpv_uniform((bandFilter & kTpvApplyGain) ? satGain[c * 2 + 1] : 1.0);
-    double* outCh = out + (int64_t)c * chStride;
-    const double* inCh = (STAGED && stage > 0) ? outCh : in + (int64_t)c * chStride;     // later stages work in place on `out`
-    unsigned activeMask = 0;                                  // bit b: band b is active
-    unsigned long long kinds = 0;                             // 2 bits per band: 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
+    TpvBands m = { 0, 0, 0, 0, 0 };      // kinds: 2 bits per band: 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
     for (int b = 0; b < kBands; ++b) {
         const int f = flags[c * kBands + b];
-        activeMask |= ((unsigned)(f & 1) << b) & bandFilter;      // bandFilter: the bands of this launch / stage
-        kinds |= (unsigned long long)((f >> 1) & 3) << (2 * b);
+        m.active |= ((unsigned)(f & 1) << b) & bandFilter;      // bandFilter: the bands of this launch
+        m.kinds |= (unsigned long long)((f >> 1) & 3) << (2 * b);
     }
-    // DF-II-T sections; SVF bands with the scalar fastTanh; SVF bands whose output is v0 + m1 v1 (every peaking band)
-    unsigned dfMask = 0, monoMask = 0, peakMask = 0;
     for (int b = 0; b < kBands; ++b) {
-        dfMask |= (unsigned)(((kinds >> (2 * b)) & 3) == 2) << b;
-        monoMask |= (unsigned)(((kinds >> (2 * b)) & 3) == 1) << b;
-        peakMask |= (unsigned)(CPQ_TPV_PEAK && ((kinds >> (2 * b)) & 3) != 2 && cf[b * 6 + 3] == 1.0 && cf[b * 6 + 5] == 0.0) << b;
+        m.df |= (unsigned)(((m.kinds >> (2 * b)) & 3) == 2) << b;
+        m.mono |= (unsigned)(((m.kinds >> (2 * b)) & 3) == 1) << b;
+        m.peak |= (unsigned)(((m.kinds >> (2 * b)) & 3) != 2 && cf[b * 6 + 3] == 1.0 && cf[b * 6 + 5] == 0.0) << b;
     }
-    // wave-uniform by construction; said so, they live in scalar registers (left in vector registers they were spilled and
-    // reloaded inside the band loop)
-    activeMask = __builtin_amdgcn_readfirstlane(activeMask);
-    dfMask = __builtin_amdgcn_readfirstlane(dfMask);
-    monoMask = __builtin_amdgcn_readfirstlane(monoMask);
-    peakMask = __builtin_amdgcn_readfirstlane(peakMask);
-    double* sState = sh.stateA;
-    double* sNext = sh.stateB;
-    if (tid < kBands * 2) { sh.stateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sh.stateB[tid] = sh.stateA[tid]; }
+    m.active = __builtin_amdgcn_readfirstlane(m.active);
+    m.df = __builtin_amdgcn_readfirstlane(m.df);
+    m.mono = __builtin_amdgcn_readfirstlane(m.mono);
+    m.peak = __builtin_amdgcn_readfirstlane(m.peak);
+    return m;
+}
+template <class SH>
+__device__ __forceinline__ void tpv_load_tables(SH& sh, const TpBandTables* __restrict__ tb, int tid, int nThreads)
+{
     for (int i = tid; i < kBands * 28; i += nThreads) {
         const int b = i / 28, q = i % 28;
         sh.M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
@@ -1244,98 +1095,198 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, (WAVES == 6 ? 3 : 4)) voi
         const int b = i >> 7, q = i & 127;
         reinterpret_cast<double2*>(&sh.P[b][0][0])[q] = reinterpret_cast<const double2*>(&tb[b].t[0].P[0][0])[q];
     }
-    __syncthreads();
+}
+
+// One span on the fast path: load, range check, the band loop, store.  Returns 0 when done; 1 when the span's input (or,
+// checkStates, a start state in sState) is outside the proven range: nothing has been stored or published; CHAINED: 2 + b
+// when the start state of band b arrived out of range: the bands from b
+// on have not been published, nothing has been stored -- the caller runs the span again on the guarded path.
+template <int NT, bool CHAINED, class SH>
+__device__ __forceinline__ int tpv_fast_span(SH& sh, const double* srcW, double* dstW, const TpvBands& bm, const double* __restrict__ cf,
+                                             double sat, double gain, double* sState, double* sNext, bool checkStates, int waveU,
+                                             int nThreads, const TpvLink& link)
+{
     double* buf = sh.scratch + waveU * 64 * kTpvQStride;
+    double x[16];
+    // (the per-lane addresses of the span I/O are rebuilt per span, like the thread index inside the band loop: kept across
+    // the band loops they were the kernel's last spilled registers)
+    int laneIo = tpv_lane_id();
+    const int tidS = (waveU << 6) + laneIo;           // (= threadIdx.x, for the same reason)
+    tpv_span_load(srcW, buf, laneIo, x);
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
+    if (checkStates && tidS < kBands * 2) bad |= !(fabs(sState[tidS]) < kTpInputBound);
+    if (tidS == 0) sh.flag = 0;
+    __syncthreads();
+    if (__any(bad) && laneIo == 0) atomicOr(&sh.flag, 1);
+    __syncthreads();
+    if (sh.flag != 0) return 1;
 
-    int sp = 0;
-#pragma unroll 1
-    for (; sp < nSpans; ++sp) {
-        const double* src = inCh + (int64_t)sp * spanLen + waveU * 1024;
-        double x[16];
-        // (the per-lane addresses of the span I/O are rebuilt per span from the lane count behind an opaque zero, like the
-        // thread index inside the band loop: kept across the band loops they were the kernel's last spilled registers)
-        int laneIo;
-        { int z = 0; asm volatile("" : "+s"(z)); laneIo = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z)); }
-        const int tidS = (waveU << 6) + laneIo;           // (= tid, for the same reason)
-        if (STAGED && awaitFlags) {           // the span as the stage before this one left it
-            if (tidS == 0) tpv_span_await(awaitFlags + sp, ticket);
-            __syncthreads();
-#if CPQ_TPV_HL
-            tpv_span_load<true>(src, buf, laneIo, x);
-#else
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            tpv_span_load<false>(src, buf, laneIo, x);
-#endif
-        } else {
-            tpv_span_load<false>(src, buf, laneIo, x);
+    // ---- the band loop: runs of one band class (an EQ channel is all SVF bands, an OutputFilter channel all DF-II-T
+    // sections: one run), each in a loop body of its own
+    if (bm.active) {
+        double e0 = 0.0, e1 = 0.0;
+        {
+            const double* E = &sh.E[__builtin_ctz(bm.active)][0][0];     // the first band's E x on the raw input
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double2 ee = *reinterpret_cast<const double2*>(E + 2 * j);
+                e0 = fma(ee.x, x[j], e0);
+                e1 = fma(ee.y, x[j], e1);
+            }
         }
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
-        if (tidS < kBands * 2) bad |= !(fabs(sState[tidS]) < kTpInputBound);
-        if (tidS == 0) sh.flag = 0;
-        __syncthreads();
-        if (__any(bad) && laneIo == 0) atomicOr(&sh.flag, 1);
-        __syncthreads();
-        if (sh.flag != 0) break;
+        int par = 0;
+        unsigned mask = bm.active;
+#pragma unroll 1
+        while (mask) {
+            const int bFirst = __builtin_ctz(mask);
+            const int cls = ((bm.df >> bFirst) & 1) ? 2 : (((bm.peak >> bFirst) & 1) ? 3 : 0);
+            const unsigned same = mask & (cls == 2 ? bm.df : (cls == 3 ? bm.peak : ~(bm.df | bm.peak)));
+            const unsigned other = mask & ~same;
+            const unsigned run = other ? (same & ((other & (0u - other)) - 1u)) : same;     // bands below the first one of another class
+            const unsigned rest = mask & ~run;
+#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, NT, CHAINED>(x, e0, e1, par, run, rest, bm.mono, sh, sState, sNext, cf, sat, waveU, nThreads, link)
+            if (cls == 2)        CPQ_RUN(2, false);
+            else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
+            else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }
+#undef CPQ_RUN
+            mask = rest;
+        }
+    }
+    if (CHAINED) {
+        // (set by the poller in front of a band's barrier: every thread is past that barrier here.  Nothing has been stored:
+        // the caller's second run may read the input in place)
+        const int f = sh.flag;
+        if (f != 0) { __syncthreads(); return 1 + f; }
+    }
+    laneIo = tpv_lane_id();
+    tpv_span_store(dstW, buf, laneIo, x, gain);
+    __syncthreads();                      // the last thread's end states are in sNext; every wave's stores are out
+    return 0;
+}
 
-        // ---- the band loop: runs of one band class (an EQ channel is all SVF bands, an OutputFilter channel all DF-II-T
-        // sections: one run), each in a loop body of its own
-        if (activeMask) {
-            double e0 = 0.0, e1 = 0.0;
-            {
-                const double* E = &sh.E[__builtin_ctz(activeMask)][0][0];     // the first band's E x on the raw input
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double2 ee = *reinterpret_cast<const double2*>(E + 2 * j);
-                    e0 = fma(ee.x, x[j], e0);
-                    e1 = fma(ee.y, x[j], e1);
+template <int WAVES, bool CHAINED>
+__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
+                                                                              int nSpans, int nCh, const double* __restrict__ coef,
+                                                                              const int* __restrict__ flags,
+                                                                              const double* __restrict__ satGain,
+                                                                              double* __restrict__ state,
+                                                                              const TpBandTables* __restrict__ tables,
+                                                                              unsigned long long* chain, int chainSpans,
+                                                                              unsigned bandFilter)
+{
+    constexpr int kMaxWaves = WAVES ? WAVES : 7;
+    constexpr int kNT = WAVES * 64;                           // 0: blockDim.x
+    __shared__ TpvShared<kMaxWaves> sh;
+    const int tid = threadIdx.x, nThreads = WAVES ? kNT : (int)blockDim.x;
+    const int waveU = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int spanLen = nThreads * 16;
+
+    if (!CHAINED) {
+        const int c = (int)blockIdx.x;
+        const double* __restrict__ cf = coef + (int64_t)c * kBands * 6;
+        const TpBandTables* __restrict__ tb = tables + (int64_t)(c >> 1) * kBands;
+        const double sat = tpv_uniform(satGain[c * 2]), gain = tpv_uniform((bandFilter & kTpvApplyGain) ? satGain[c * 2 + 1] : 1.0);
+        double* outCh = out + (int64_t)c * chStride;
+        const double* inCh = in + (int64_t)c * chStride;
+        const TpvBands bm = tpv_band_masks(flags, cf, c, bandFilter);
+        double* sState = sh.stateA;
+        double* sNext = sh.stateB;
+        if (tid < kBands * 2) { sh.stateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sh.stateB[tid] = sh.stateA[tid]; }
+        tpv_load_tables(sh, tb, tid, nThreads);
+        __syncthreads();
+        const TpvLink link = { nullptr, nullptr, 0u, nullptr, nullptr };
+
+        int sp = 0;
+#pragma unroll 1
+        for (; sp < nSpans; ++sp) {
+            if (tpv_fast_span<kNT, false>(sh, inCh + (int64_t)sp * spanLen + waveU * 1024, outCh + (int64_t)sp * spanLen + waveU * 1024,
+                                          bm, cf, sat, gain, sState, sNext, true, waveU, nThreads, link) != 0)
+                break;
+            { double* t = sState; sState = sNext; sNext = t; }
+        }
+        const int tidE = (waveU << 6) + tpv_lane_id();            // (= tid, rebuilt: see tpv_lane_id)
+        // cold: this span and the later ones through the guarded recurrence (states advance in sState)
+        for (; sp < nSpans; ++sp)
+            tpv_guarded_span(sh, spanLen, inCh + (int64_t)sp * spanLen, outCh + (int64_t)sp * spanLen, sState, cf, bm.active, bm.kinds,
+                             sat, gain, tidE, nThreads);
+        __syncthreads();
+        // the call's end states (only this launch's bands are written)
+        if (nSpans > 0 && tidE < kBands * 2 && ((bm.active >> (tidE >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tidE] = sState[tidE];
+    } else {
+        TpvChainHeader* hdr = reinterpret_cast<TpvChainHeader*>(chain);
+        unsigned long long* gran = chain + sizeof(TpvChainHeader) / sizeof(unsigned long long);
+        if (tid == 0) sh.epoch = __hip_atomic_load((const gu32*)&hdr->gen, CPQ_RLX_AGENT) + 1u;
+        const int nTasks = nSpans * nCh;
+        int cur = -1;                     // channel whose tables are in LDS
+        TpvBands bm = { 0, 0, 0, 0, 0 };
+#pragma unroll 1
+        for (;;) {
+            __syncthreads();              // the task before is done with sh (tables, states, task word)
+            if (tid == 0) sh.task = (int)__hip_atomic_fetch_add((gu32*)&hdr->ticket, 1u, CPQ_RLX_AGENT);
+            __syncthreads();
+            const int q = __builtin_amdgcn_readfirstlane(sh.task);
+            if (q >= nTasks) break;
+            const unsigned epoch = __builtin_amdgcn_readfirstlane(sh.epoch);
+            const int sp = q / nCh, c = q - sp * nCh;
+            const double* __restrict__ cf = coef + (int64_t)c * kBands * 6;
+            const double sat = tpv_uniform(satGain[c * 2]), gain = tpv_uniform((bandFilter & kTpvApplyGain) ? satGain[c * 2 + 1] : 1.0);
+            const int tidT = (waveU << 6) + tpv_lane_id();
+            if (c != cur) {
+                bm = tpv_band_masks(flags, cf, c, bandFilter);
+                tpv_load_tables(sh, tables + (int64_t)(c >> 1) * kBands, tidT, nThreads);
+                cur = c;
+            }
+            // first span of the call: the start states are the channel's stored states; later spans receive them band by band
+            if (sp == 0 && tidT < kBands * 2) sh.stateA[tidT] = state[(int64_t)c * kBands * 2 + tidT];
+            __syncthreads();
+            unsigned long long* g = gran + ((int64_t)c * chainSpans + sp) * (kBands * 4);
+            const TpvLink link = { sp > 0 ? g - kBands * 4 : nullptr, sp + 1 < nSpans ? g : nullptr, epoch, &sh.flag, &hdr->error };
+            const double* src = in + (int64_t)c * chStride + (int64_t)sp * spanLen;
+            double* dst = out + (int64_t)c * chStride + (int64_t)sp * spanLen;
+            const int r = tpv_fast_span<kNT, true>(sh, src + waveU * 1024, dst + waveU * 1024, bm, cf, sat, gain, sh.stateA, sh.stateB,
+                                                   sp == 0, waveU, nThreads, link);
+            const int tidE = (waveU << 6) + tpv_lane_id();
+            if (r != 0) {
+                // cold: the span on the guarded path.  Its start states: all of them from the span before (that workgroup has
+                // then finished the span), or the stored ones; its end states are published for the bands the fast path has not
+                // published (r >= 2: the bands below r - 2 went out before the out-of-range state arrived, from good states).
+                if (link.poll && waveU == 0) {
+                    for (unsigned m = bm.active; m; m &= m - 1) {
+                        const int b = __builtin_ctz(m);
+                        double sx, sy;
+                        tpv_poll_state(link.poll + b * 4, epoch, tidE, sx, sy, link.error);
+                        if (tidE == 0) { sh.stateA[2 * b] = sx; sh.stateA[2 * b + 1] = sy; }
+                    }
+                } else if (!link.poll && tidE < kBands * 2) {
+                    sh.stateA[tidE] = state[(int64_t)c * kBands * 2 + tidE];
+                }
+                __syncthreads();
+                tpv_guarded_span(sh, spanLen, src, dst, sh.stateA, cf, bm.active, bm.kinds, sat, gain, tidE, nThreads);
+                if (tidE < kBands * 2) sh.stateB[tidE] = sh.stateA[tidE];
+                __syncthreads();
+                if (link.pub && tidE == 0) {
+                    for (unsigned m = bm.active; m; m &= m - 1) {
+                        const int b = __builtin_ctz(m);
+                        if (r >= 2 && b < r - 2) continue;
+                        tpv_publish_state(link.pub + b * 4, epoch, sh.stateB[2 * b], sh.stateB[2 * b + 1]);
+                    }
                 }
             }
-            // the next span of this workgroup is requested into L2 while the last bands run (tpv_band_run)
-            const double* prefetch = (CPQ_TPV_PREFETCH && !STAGED && sp + 1 < nSpans) ? src + spanLen + lane * 16 : nullptr;
-            int par = 0;
-            unsigned mask = activeMask;
-#pragma unroll 1
-            while (mask) {
-                const int bFirst = __builtin_ctz(mask);
-                const int cls = ((dfMask >> bFirst) & 1) ? 2 : (((peakMask >> bFirst) & 1) ? 3 : 0);
-                const unsigned same = mask & (cls == 2 ? dfMask : (cls == 3 ? peakMask : ~(dfMask | peakMask)));
-                const unsigned other = mask & ~same;
-                const unsigned run = other ? (same & ((other & (0u - other)) - 1u)) : same;     // bands below the first one of another class
-                const unsigned rest = mask & ~run;
-#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, kNT>(x, e0, e1, par, run, rest, monoMask, sh, sState, sNext, cf, sat, tidS, waveU, nThreads, prefetch)
-                if (cls == 2)        CPQ_RUN(2, false);
-                else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
-                else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }
-#undef CPQ_RUN
-                mask = rest;
+            // last span of the call: the end states (in stateB, band by band) are the channel's stored states
+            if (sp + 1 == nSpans && tidE < kBands * 2 && ((bm.active >> (tidE >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tidE] = sh.stateB[tidE];
+        }
+        // the last workgroup to get here resets the ticket and advances the generation for the next launch
+        if (tid == 0) {
+            const unsigned epoch = sh.epoch;
+            if (__hip_atomic_fetch_add((gu32*)&hdr->done, 1u, CPQ_RLX_AGENT) == gridDim.x - 1u) {
+                __hip_atomic_store((gu32*)&hdr->ticket, 0u, CPQ_RLX_AGENT);
+                __hip_atomic_store((gu32*)&hdr->done, 0u, CPQ_RLX_AGENT);
+                __hip_atomic_store((gu32*)&hdr->gen, epoch, CPQ_RLX_AGENT);
             }
         }
-        { int z = 0; asm volatile("" : "+s"(z)); laneIo = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z)); }
-#if CPQ_TPV_HS
-        if (STAGED && publishFlags) tpv_span_store<true>(outCh + (int64_t)sp * spanLen + waveU * 1024, buf, laneIo, x, gain);
-        else                        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + waveU * 1024, buf, laneIo, x, gain);
-#else
-        tpv_span_store<false>(outCh + (int64_t)sp * spanLen + waveU * 1024, buf, laneIo, x, gain);
-        if (STAGED && publishFlags) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-        __syncthreads();                      // the last thread's end states are in sNext; every wave's stores are out
-        if (STAGED && publishFlags && waveU == 0 && laneIo == 0) tpv_span_publish(publishFlags + sp, ticket);
-        { double* t = sState; sState = sNext; sNext = t; }
     }
-    int tidE;            // (= tid, rebuilt: see laneIo)
-    { int z = 0; asm volatile("" : "+s"(z)); tidE = (waveU << 6) + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z)); }
-    if (sp < nSpans) {
-        // cold: this span and the later ones through the guarded recurrence (states advance in sState).  The span's wait
-        // for the stage before has been done above; the guarded loop waits again, which returns at once.
-        tpv_guarded_spans(sh, sp, nSpans, spanLen, inCh, outCh, sState, cf, activeMask, kinds, sat, gain, awaitFlags,
-                          publishFlags, ticket, tidE, nThreads);
-    }
-    __syncthreads();
-    // the call's end states (only this launch's / stage's bands are written: another stage has the other bands of the
-    // channel)
-    if (nSpans > 0 && tidE < kBands * 2 && ((activeMask >> (tidE >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tidE] = sState[tidE];
 }
 
 }  // namespace
@@ -1351,50 +1302,16 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
                            coef, flags, satGain, state);
 }
 
-}  // namespace cpq
-
-namespace cpq {
+int svf_chain_spans(int maxSamples) { return maxSamples / kTpvSpan + 1; }
 size_t svf_chain_bytes(int nCh, int maxSamples)
 {
-    // hand-over words of the band-pipelined stages: [channel][stage <= 20][span]
-    return (size_t)nCh * (size_t)(maxSamples / kTpvSpan + 1) * kBands * sizeof(unsigned long long);
+    // header + granules [channel][span][band][4] of the chained spans
+    return sizeof(TpvChainHeader) + (size_t)nCh * (size_t)svf_chain_spans(maxSamples) * kBands * 4 * sizeof(unsigned long long);
 }
-
-namespace {
-// Band-pipelined stages for engines whose channels alone do not fill the chip: the 20 bands are dealt to G stages, the
-// call's whole spans to N time slices, and stage g works on slice i while stage g - 1 is already on slice i + 1 -- each
-// stage a launch of its own (one workgroup per channel, `bandFilter` = its bands) on a stream of its own, ordered by
-// events: stage g of slice i behind stage g - 1 of slice i and behind stage g of slice i - 1 (same stream).  Stage g owns
-// its bands' rows of `state` and its slices run in order.  (N + G - 1) / (N G) of the single-stage time at best
-// (profiles/r03d_eq_stage_sweep.txt).  The same pipeline inside ONE launch is the STAGED kernel above.
-struct StagePipe {
-    static constexpr int kMaxStages = 5, kMaxSlices = 32;
-    hipStream_t side[kMaxStages - 1] = {};
-    hipEvent_t done[kMaxStages][kMaxSlices] = {};
-    hipEvent_t fork = nullptr;
-    bool ok = false;
-};
-StagePipe* stagePipe()
-{
-    static StagePipe pipes[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    StagePipe& p = pipes[dev];
-    if (!p.ok) {
-        bool good = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
-        for (int g = 0; g < StagePipe::kMaxStages - 1 && good; ++g) good = hipStreamCreateWithFlags(&p.side[g], hipStreamNonBlocking) == hipSuccess;
-        for (int g = 0; g < StagePipe::kMaxStages && good; ++g)
-            for (int i = 0; i < StagePipe::kMaxSlices && good; ++i) good = hipEventCreateWithFlags(&p.done[g][i], hipEventDisableTiming) == hipSuccess;
-        if (!good) { (void)hipGetLastError(); return nullptr; }
-        p.ok = true;
-    }
-    return &p;
-}
-}  // namespace
 
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
                            const double* coef, const int* flags, const double* satGain, double* state,
-                           const void* tables, void* chain, int chainSpans, unsigned long long* ticket)
+                           const void* tables, void* chain, int chainSpans, int chainGrid)
 {
     static_assert(sizeof(TpBandTables) == kSvfTpTableDoubles * sizeof(double), "host/device table layout");
     // whole 8192-sample spans on the eight-wave kernel, what is left as one span of 1 ... 7 waves x 1024 samples, and a
@@ -1404,66 +1321,25 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
     int done = 0;
     const int nSpans8 = nSamples / kTpvSpan;
     if (nSpans8 > 0) {
-        static int nCu = 0, envStages = -1, envSlices = 0;      // experiments: CPQ_SVF_STAGES=G[,N]
-        if (envStages < 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            nCu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-            envStages = 0;
-            if (const char* f = getenv("CPQ_SVF_STAGES")) { envStages = atoi(f); if (const char* c = strchr(f, ',')) envSlices = atoi(c + 1); }
-        }
-        // At most half as many channels as CUs: band-pipelined stages.  (One workgroup alone on a CU already runs at ~85 % of
-        // the rate of two sharing it, so with more channels than that there is nothing to gain.)  By default as 4 stages x
-        // 16 time slices of event-ordered launches (StagePipe above); CPQ_SVF_STAGES=G selects the single staged launch
-        // instead, which measured no faster at any stream count (profiles/r03h_eq_staged_kernel.txt).
-        const bool inKernel = envStages > 1 && envSlices == 0 && kBands % envStages == 0 && chain && ticket && nSpans8 <= chainSpans && nSpans8 >= 2;
-        int nStages = inKernel ? envStages : 1;
-        int nSlices = 0;
-        if (!inKernel) {
-            if (envStages > 0 && envSlices > 0) { if (nSpans8 >= envStages) { nStages = envStages; nSlices = envSlices; } }
-            else if (envStages < 1 && 2 * nCh <= nCu && nSpans8 >= 16) { nStages = 4; nSlices = 16; }      // measured best (profiles/r03d_eq_stage_sweep.txt)
-        }
-        // the side streams and events are per device, shared by every engine on it: one engine's launch sequence at a time
-        // (a stream wait captures the event's record of the moment it is enqueued, so reuse by the next engine is safe)
-        static std::mutex pipeMutex;
-        std::unique_lock<std::mutex> pipeLock(pipeMutex, std::defer_lock);
-        if (nSlices > 0) pipeLock.lock();
-        StagePipe* pipe = nSlices > 0 ? stagePipe() : nullptr;
-        if (!pipe && !inKernel) nStages = 1;
-        if (pipe) {
-            if (nStages > StagePipe::kMaxStages) nStages = StagePipe::kMaxStages;
-            if (nSlices > StagePipe::kMaxSlices) nSlices = StagePipe::kMaxSlices;
-            if (nSlices > nSpans8) nSlices = nSpans8;
-            const int bandsPerStage = kBands / nStages;
-            (void)hipEventRecord(pipe->fork, stream);
-            for (int g = 1; g < nStages; ++g) (void)hipStreamWaitEvent(pipe->side[g - 1], pipe->fork, 0);
-            for (int i = 0; i < nSlices; ++i) {
-                const int sp0 = (int)((long long)nSpans8 * i / nSlices), sp1 = (int)((long long)nSpans8 * (i + 1) / nSlices);
-                for (int g = 0; g < nStages; ++g) {
-                    hipStream_t st = g == 0 ? stream : pipe->side[g - 1];
-                    if (g > 0) (void)hipStreamWaitEvent(st, pipe->done[g - 1][i], 0);
-                    const unsigned filter = (((1u << bandsPerStage) - 1u) << (g * bandsPerStage)) | (g == nStages - 1 ? kTpvApplyGain : 0u);      // the channel gain goes on once, behind the last band
-                    // stage 0 reads the call's input, the later stages what the stage before left in `out`
-                    const double* src = (g == 0 ? in : out) + (int64_t)sp0 * kTpvSpan;
-                    hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, st, src, out + (int64_t)sp0 * kTpvSpan, chStride,
-                                       sp1 - sp0, 1, coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0ull, filter);
-                    (void)hipEventRecord(pipe->done[g][i], st);
-                }
-            }
-            for (int g = 1; g < nStages; ++g) (void)hipStreamWaitEvent(stream, pipe->done[g][nSlices - 1], 0);
-        } else if (nStages > 1) {
-            hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, true>), dim3(nCh * nStages), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8,
-                               nStages, coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain), ++*ticket, kAllBands);
+        // Fewer channels than the chip holds workgroups of this kernel (chainGrid = 2 per CU): chained spans, the (span,
+        // channel) tasks dealt to chainGrid workgroups.  Otherwise one workgroup per channel.
+        // (with a workgroup per channel already on every slot chaining gains 4 % on the kernel alone, nothing in the pipeline, and
+        // loses 4 % at 1024 streams: profiles/r04a_eq_chained_spans.txt)
+        if (chain && nCh < chainGrid && nSpans8 >= 2 && nSpans8 <= chainSpans) {
+            const int nTasks = nSpans8 * nCh;
+            hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, true>), dim3(nTasks < chainGrid ? nTasks : chainGrid), dim3(kTpvWaves * 64), 0, stream,
+                               in, out, chStride, nSpans8, nCh, coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain),
+                               chainSpans, kAllBands);
         } else {
-            hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8, 1,
-                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0ull, kAllBands);
+            hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8, nCh,
+                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands);
         }
         done = nSpans8 * kTpvSpan;
     }
     const int nWaves = (nSamples - done) / 1024;
     if (nWaves > 0) {
-        hipLaunchKernelGGL((k_svf_cascade_tpv<0, false>), dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, 1,
-                           coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0ull, kAllBands);
+        hipLaunchKernelGGL((k_svf_cascade_tpv<0, false>), dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, nCh,
+                           coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands);
         done += nWaves * 1024;
     }
     if (nSamples > done)

@@ -314,3 +314,10 @@ class BatchedEngine:
             self._ck(self._lib.cpq_profile_read(self._h, kid, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    def eq_chain_status(self):
+        """(chained launches of the EQ / output-filter cascade so far, hand-over gave up flag) -- diagnostics for tests"""
+        n = C.c_uint32()
+        bad = C.c_uint32()
+        self._ck(self._lib.cpq_diag_eq_chain_status(self._h, C.byref(n), C.byref(bad)))
+        return n.value, bad.value

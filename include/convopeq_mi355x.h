@@ -463,6 +463,11 @@ const char* cpq_kernel_name(int32_t kernel_id);
  * Needs a gfx950 device; no engine.  For tests of the FFT kernel families in isolation. */
 int32_t     cpq_diag_partition_fft(int32_t partition, int32_t n_channels, int32_t n_blocks, const double* in,
                                    double* spectra, double* out);
+/* Chained spans of the EQ / output-filter cascade (engines with fewer channels than the device holds workgroups of the span
+ * kernel: the spans of a call are dealt to the workgroups and a band's state is handed from span to span inside the launch).
+ * Synchronises the engine's stream; *launches = chained launches so far (0: this engine never chains), *gave_up != 0 when a
+ * hand-over ever ran into its poll bound (a defect: results of that launch are not valid).  For tests. */
+int32_t     cpq_diag_eq_chain_status(cpq_engine* e, uint32_t* launches, uint32_t* gave_up);
 
 #ifdef __cplusplus
 }
