@@ -323,6 +323,100 @@ def newest_pmc_summary():
     return c[-1] if c else None
 
 
+def load_sq_issue_util(path, kernel, running, waves_per_simd=4):
+    """VALU issue-slot utilisation of `kernel` from a committed SQ-counter summary (tools/summarize_sq.py):
+    SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of a wave's cycles in which it issues a VALU instruction; times the waves
+    a SIMD holds = the share of the SIMD's VALU issue slots in use.  Same provenance rule as load_pmc_traffic."""
+    src = {"file": os.path.relpath(path, ROOT) if path else None, "match": False}
+    if not path or not os.path.exists(path):
+        src["reason"] = "no SQ-counter summary found"
+        return None, src
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception as ex:       # noqa: BLE001
+        src["reason"] = f"unreadable: {ex}"
+        return None, src
+    tag = d.get("_config")
+    if not tag:
+        src["reason"] = "summary carries no _config tag"
+        return None, src
+    src["measured_on"] = tag
+    mism = [k for k in ("streams", "ir_len", "block", "blocks_per_call", "partition", "schedule", "eq", "kernel_sources")
+            if tag.get(k) != running.get(k)]
+    if mism:
+        src["reason"] = "differs from this run in: " + ", ".join(mism)
+        return None, src
+    for nme in {"k_svf_cascade_tp": ["k_svf_cascade_tpv", "k_svf_cascade_tp"], "k_fdl_mac": ["k_fdl_mac_wg", "k_fdl_mac"]}.get(kernel, [kernel]):
+        c = d.get(nme)
+        if isinstance(c, dict) and "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
+            src.update({"match": True, "kernel": nme, "waves_per_simd": waves_per_simd})
+            return round(c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"] * waves_per_simd, 4), src
+    src["reason"] = f"kernel {kernel} not in the summary"
+    return None, src
+
+
+def newest_sq_summary():
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))
+    return c[-1] if c else None
+
+
+# ----------------------------------------------------------------------------- algorithmic bytes / flops (DESIGN.md section 4)
+def launch_plan(n, layers):
+    """layers: [(partition, partitions of the IR)].  A layer's kernels launch when a partition of it has filled: a call of n
+    samples carries n / P partitions -- a whole number of them per launch, one launch per call, when n >= P; one partition
+    per launch every P / n calls otherwise (the streaming regimes: a 4096-sample tail layer under 512-sample calls runs
+    every eighth call).  -> [(P, K, partitions per launch, launches per call)]"""
+    out = []
+    for pl, kl in layers:
+        nb = max(1, n // pl)
+        out.append((pl, kl, nb, (n / pl) / nb))
+    return out
+
+
+def mac_launch_bytes(n_ch, ir_rows_mult, pl, kl, nb):
+    """k_fdl_mac, one launch producing nb output rows per channel: every FDL row, IR row and output row once."""
+    return (n_ch * (kl + nb - 1) + ir_rows_mult * kl + n_ch * nb) * pl * 16
+
+
+def algorithmic_bytes_per_step(n_ch, n, ir_rows_mult, fft_layers, mac_layers, layered_tail=None, native_tails=0):
+    """HBM bytes one call (step) of n samples needs per kernel family if every row / sample is moved once.
+    fft_layers / mac_layers: launch_plan() lists (they differ in layered mode: one transform grid, one MAC per layer).
+    layered_tail: (n_tail, [min(n, output_delay + 2 P) per tail layer]) in layered mode; native_tails: tail layers of a plan
+    group (their delay-line read-add passes over the call's output)."""
+    b = {
+        "k_rfft_fwd_ols": sum(lps * n_ch * nb * (pl * 8 + pl * 16) for pl, _, nb, lps in fft_layers),
+        "k_fdl_mac": sum(lps * mac_launch_bytes(n_ch, ir_rows_mult, pl, kl, nb) for pl, kl, nb, lps in mac_layers),
+        "k_fdl_mac_dcnyq": sum(lps * (n_ch * (kl + nb - 1 + nb) * 16 + ir_rows_mult * kl * 16) for pl, kl, nb, lps in mac_layers),
+        "k_rfft_inv_ols": sum(lps * n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb, lps in mac_layers),
+        "k_svf_cascade_tp": n_ch * n * 16,
+        "k_svf_cascade": n_ch * n * 16,
+        "k_convproc_mix": 0,
+    }
+    if layered_tail:
+        n_tail, spans = layered_tail
+        # the layer-0 inverse transform also reads what the replayed delay-line reader adds (8 B per sample and tail layer);
+        # only what later calls may still read is appended to the rings
+        b["k_rfft_inv_ols"] += n_ch * n * 8 * n_tail
+        b["k_convproc_mix"] = n_ch * 16 * sum(spans)
+    elif native_tails > 0:
+        # the delay-line read-add of the tail layers over the call's output (read + write once, 8 B per sample and tail layer
+        # from the rings; the ring writes are inside the inverse transforms)
+        b["k_convproc_mix"] = n_ch * n * (16 + 8 * native_tails)
+    return b
+
+
+def svf_flop_model(saturation):
+    """fp64 operations per band-sample in the reference's arithmetic (processBandStereo, EQProcessor.Processing.cpp:228-262):
+    the linear recurrence is 10 instructions, 7 of them FMAs = 17 flops.  With saturation > 0 the output stage adds the
+    fastTanh blend: 9 arithmetic flops (x^2, numerator 2, denominator 2, one division counted as one, blend 3) + 7 slots of
+    min / max / compare / select (argument clamp 2, output guard 2, +-100 clamp 2, select 1).  At saturation 0 the blend is
+    skipped (`if sat > 0`): the guard and the clamp remain (4 slots, no arithmetic)."""
+    if saturation > 0.0:
+        return {"slots": 33.0, "arithmetic": 26.0}
+    return {"slots": 21.0, "arithmetic": 17.0}
+
+
 # ----------------------------------------------------------------------------- launcher
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -449,6 +543,7 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N>1)")
     ap.add_argument("--stub-step", action="store_true", help="test-only: launcher / reduction self-test without a GPU")
     ap.add_argument("--pmc-json", default=None, help="PMC summary for roofline.traffic (default: newest profiles/r*_pmc_traffic.json)")
+    ap.add_argument("--sq-json", default=None, help="SQ-counter summary for roofline.valu_issue_util (default: newest profiles/r*_sq_counters.json)")
     args = ap.parse_args(argv)
     if args.streams <= 0:
         args.streams = STREAMS_CONFIG2 if args.gpus <= 1 else STREAMS_CONFIG5_SHARE
@@ -542,8 +637,22 @@ def main():
         eng.profile_enable(True)        # pre-creates the event pool: no hipEventCreate inside the timed region
         eng.profile_reset()
 
+    # Per-kernel times come from HIP events the library records around every kernel scope on the engine's stream.  Around
+    # long calls they are free (8 scopes per 10 ms); around 512-sample calls every event costs the stream ~10 us of
+    # serialisation -- more than the kernels between them (profiles/r04c_streaming_timeline.txt) -- so for calls below 65536
+    # samples the timed region runs WITHOUT them and the same K steps are repeated with them for the per-kernel numbers.
     host_side = {}
-    my_elapsed, elapsed = timed_steps(step, torch.cuda.synchronize, dist, args.steps, args.warmup, start_profile, host_side)
+    separate_profile = n < 65536
+    my_elapsed, elapsed = timed_steps(step, torch.cuda.synchronize, dist, args.steps, args.warmup,
+                                      None if separate_profile else start_profile, host_side)
+    profiled_elapsed = None
+    if separate_profile:
+        start_profile()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        profiled_elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
 
     # The same MAC path with ONE partition per call (the reference's own call pattern): every FDL and IR row is
@@ -581,43 +690,31 @@ def main():
         # algorithmic HBM bytes per launch: every row / sample a kernel needs is moved once
         spec_bytes = P * 16
         ir_rows = (2 if args.shared_ir else n_ch) * k_parts
-        # layers the convolver actually runs: (partition size, partitions, partitions per step)
-        if args.schedule == "nuc":
-            layers = [(plan.part_size[l], plan.num_parts_ir[l], n / plan.part_size[l]) for l in range(plan.num_layers)]
+        # layers the convolver actually runs: (partition size, partitions of the IR) -> launch_plan()
+        if args.schedule == "nuc" or args.call_mode == "any":
+            layer_list = [(plan.part_size[l], plan.num_parts_ir[l]) for l in range(plan.num_layers)]
         else:
-            layers = [(P, k_parts, Tp)]
+            layer_list = [(P, k_parts)]
+        layers = launch_plan(n, layer_list)
         ir_mult = 2 if args.shared_ir else n_ch
         # time-varying plans under reference semantics (a tail partition longer than the IR before it: blocks >= 1024 at the
         # defaults) run in layered mode on the uniform grid: one forward FFT, then per layer a MAC over that layer's partitions
-        # and an inverse FFT, and the replayed delay-line reader (k_tail_*: reads every tail layer's output, writes and reads
-        # its ring, read-modify-writes the call's output)
+        # and an inverse FFT, and the replayed delay-line reader
         n_tail = plan.num_layers - 1
         layered = (args.schedule == "uniform" and not args.exact and args.call_mode == "blocks" and
                    any(plan.part_size[l] > plan.output_delay[l] for l in range(1, plan.num_layers)))
-        mac_layers = [(P, (plan.len[l] + P - 1) // P, Tp) for l in range(plan.num_layers)] if layered else layers
-        alg_bytes = {      # per STEP; one launch per step and kernel under the uniform schedule
-            "k_rfft_fwd_ols": sum(n_ch * nb * (pl * 8 + pl * 16) for pl, _, nb in layers),
-            "k_fdl_mac": sum((n_ch * (kl + nb - 1) + ir_mult * kl + n_ch * nb) * pl * 16 for pl, kl, nb in mac_layers),
-            "k_fdl_mac_dcnyq": sum(n_ch * (kl + nb - 1 + nb) * 16 + ir_mult * kl * 16 for pl, kl, nb in mac_layers),
-            # layered mode: the layer-0 inverse transform also reads what the replayed delay-line reader adds (8 B per sample
-            # and tail layer, from the tail layers' outputs)
-            "k_rfft_inv_ols": sum(n_ch * nb * (pl * 16 + pl * 8) for pl, _, nb in mac_layers) + (n_ch * n * 8 * n_tail if layered else 0),
-            "k_svf_cascade_tp": n_ch * n * 16,
-            "k_svf_cascade": n_ch * n * 16,
-            # native schedule: the delay-line read-add of the tail layers over the call's output (read + write once, 8 B per
-            # sample and tail layer from the rings; the ring writes are inside the inverse transforms); layered mode: only what
-            # later calls may still read is appended to the rings (at most one output_delay + partition per tail layer: small)
-            "k_convproc_mix": (n_ch * 16 * sum(min(n, plan.output_delay[l] + 2 * plan.part_size[l]) for l in range(1, plan.num_layers)) if layered
-                               else n_ch * n * (16 + 8 * max(0, len(layers) - 1)) if len(layers) > 1 else 0),
-        }
-        # fp64 operations per step (FMA = 2): MAC 8 per complex MAC; SVF: the reference's band kernel is 17 flops of linear
-        # recurrence (10 instructions, 7 of them FMAs) + 16 of output stage (fastTanh blend with one division counted as one,
-        # the guards and clamps) = 33 flops per band-sample
-        # the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex MAC (Gauss), the tile kernels 4
+        mac_layers = launch_plan(n, [(P, (plan.len[l] + P - 1) // P) for l in range(plan.num_layers)]) if layered else layers
+        alg_bytes = algorithmic_bytes_per_step(
+            n_ch, n, ir_mult, layers, mac_layers,
+            layered_tail=(n_tail, [min(n, plan.output_delay[l] + 2 * plan.part_size[l]) for l in range(1, plan.num_layers)]) if layered else None,
+            native_tails=0 if layered else max(0, len(layers) - 1))
+        # fp64 operations per step (FMA = 2): the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex
+        # MAC (Gauss), the tile kernels 4; SVF: svf_flop_model()
         mac_flop = lambda nb: 6.0 if nb >= 48 else 8.0
         n_bands = 20 if args.eq_preset == "bench" else len(load_autoeq_preset()["filters"])
-        alg_flops = {"k_fdl_mac": sum(mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb in mac_layers),
-                     "k_svf_cascade_tp": 33.0 * n_bands * n_ch * n}
+        svf_model = svf_flop_model(args.saturation)
+        alg_flops = {"k_fdl_mac": sum(lps * mac_flop(nb) * n_ch * nb * kl * pl for pl, kl, nb, lps in mac_layers),
+                     "k_svf_cascade_tp": svf_model["slots"] * n_bands * n_ch * n}
         per_kernel = {}
         for name, (cnt, ms) in prof.items():
             if cnt == 0:
@@ -630,6 +727,8 @@ def main():
                                 "achieved_gbs": round(alg_bytes[name] / step_s / 1e9, 1)}
             if name in alg_flops:
                 per_kernel[name]["fp64_tflops"] = round(alg_flops[name] / step_s / 1e12, 2)
+            if name == "k_svf_cascade_tp":
+                per_kernel[name]["fp64_tflops_arithmetic"] = round(alg_flops[name] * svf_model["arithmetic"] / svf_model["slots"] / step_s / 1e12, 2)
         tot = {k: v["avg_launch_ms"] * v["launches"] for k, v in per_kernel.items()}
         dominant = max(tot, key=tot.get)
         co_dominant = sorted(k for k in tot if tot[k] >= 0.9 * tot[dominant])
@@ -650,16 +749,24 @@ def main():
             hbm_regime = {"kernel": "k_fdl_mac", "blocks_per_call": P // B, "algorithmic_bytes_per_launch": b1,
                           "avg_launch_ms": round(ms1 / cnt1, 4), "achieved": round(gbs1, 1),
                           "frac": round(gbs1 / HBM_PEAK_GBS, 4), "launches": cnt1, "traffic": tr1}
-        flop_per_byte = alg_flops["k_fdl_mac"] / alg_bytes["k_fdl_mac"]
+        flop_per_byte = alg_flops["k_fdl_mac"] / alg_bytes["k_fdl_mac"] if alg_bytes["k_fdl_mac"] else 0.0
         ridge = FP64_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
         traffic, traffic_src = load_pmc_traffic(pmc_path, dominant, running)
         if dominant.startswith("k_svf"):
             # 16 B of HBM per sample against ~35 fp64 instructions per band-sample: the fp64 vector issue rate bounds it
+            issue_util, issue_src = load_sq_issue_util(args.sq_json or newest_sq_summary(), dominant, running)
             roof = {"kernel": dominant, "bound": "fp64_vector", "achieved": dk.get("fp64_tflops"),
                     "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round((dk.get("fp64_tflops") or 0.0) / FP64_VECTOR_PEAK_TFLOPS, 4),
+                    # the same with the arithmetic operations only (no min / max / compare / select slots)
+                    "flops_per_band_sample": svf_model,
+                    "achieved_arithmetic": dk.get("fp64_tflops_arithmetic"),
+                    "frac_arithmetic": round((dk.get("fp64_tflops_arithmetic") or 0.0) / FP64_VECTOR_PEAK_TFLOPS, 4),
+                    # what the SQ counters say about the same kernel: share of the SIMDs' VALU issue slots in use
+                    "valu_issue_util": issue_util, "valu_issue_util_source": issue_src,
                     "note": "k_svf_cascade_tp is fp64-issue bound, not HBM bound: 20 sequential nonlinear bands per sample, "
-                            "33 flops per band-sample in the reference's arithmetic against 16 B of HBM traffic per sample; fp64 "
+                            f"{svf_model['slots']:.0f} operation slots ({svf_model['arithmetic']:.0f} of them arithmetic) per band-sample in the "
+                            "reference's arithmetic against 16 B of HBM traffic per sample; fp64 "
                             "MFMA and VALU share one datapath on gfx950 (profiles/r02a_ubench_fp64_valu_mfma_coexec.txt)",
                     "hbm_kernel": {"kernel": "k_fdl_mac", "achieved": per_kernel["k_fdl_mac"]["achieved_gbs"] if "k_fdl_mac" in per_kernel else None,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -682,6 +789,9 @@ def main():
             "mac_flop_per_byte": round(flop_per_byte, 2), "ridge_flop_per_byte": round(ridge, 2),
             "hbm_regime": hbm_regime,
         })
+        # a fraction above 1 is an accounting error (more algorithmic bytes or flops charged than the kernel can have moved)
+        fracs = [roof.get("frac"), (roof.get("hbm_kernel") or {}).get("frac"), (hbm_regime or {}).get("frac"), roof.get("frac_arithmetic")]
+        roof["accounting_ok"] = all(f is None or f <= 1.0 for f in fracs)
         config_name = ("configs[1]" if (world == 1 and S == STREAMS_CONFIG2 and L == 131072 and B == 512) else
                        "configs[4] per-GPU share (8192 streams / 8 GPUs)" if (S == STREAMS_CONFIG5_SHARE and L == 131072 and B == 512) else
                        "modified")
@@ -709,7 +819,7 @@ def main():
                              f"{'h' if args.exact else 'h_eff (reference NUC semantics at blk 512)'}, "
                              f"{T} blocks ({n} samples) per call = {Tp} partitions per FDL pass") if args.schedule == "uniform"
                             else ("non-uniform (the reference's own layer plan run natively): " +
-                                  " + ".join(f"{kl} x {pl}" for pl, kl, _ in layers) + f" partitions, {T} blocks per call"),
+                                  " + ".join(f"{kl} x {pl}" for pl, kl, _, _ in layers) + f" partitions, {T} blocks per call"),
                 "partition": P,
                 "eq": use_eq, "eq_preset": args.eq_preset if use_eq else None, "saturation": args.saturation if use_eq else None,
                 "pcm_scale": args.pcm_scale,
@@ -727,6 +837,10 @@ def main():
             # plan groups launch several kernels per scope) and the host time of one enqueue (includes the host replay of the
             # reference's Add / Get bookkeeping under CPQ_CALLS_ANY / the native schedule)
             "kernel_scopes_per_step": round(sum(v[0] for v in prof.values()) / max(args.steps, 1), 2),
+            # calls below 65536 samples: `value` / `ms_per_step` are timed without the library's event profiling, the
+            # per-kernel numbers come from a second pass of the same K steps with it (ms per step of that pass here)
+            "kernel_times_from": ("second pass of the same steps with event profiling on" if separate_profile else "the timed region"),
+            "ms_per_step_profiled_pass": round(profiled_elapsed / args.steps * 1e3, 4) if profiled_elapsed else None,
             "host_enqueue_us_per_step": round(host_side.get("enqueue_s", 0.0) / max(args.steps, 1) * 1e6, 1),
             "call_mode": args.call_mode,
             "setup_s": round(setup_s, 2),

@@ -29,3 +29,45 @@ def test_bench_algorithmic_bytes_formula():
     """(2S (K+T-1) + nIR K + 2S T) * P * 16 bytes per k_fdl_mac launch at config 2."""
     n_ch, k, t, p = 512, 259, 64, 512
     assert (n_ch * (k + t - 1) + n_ch * k + n_ch * t) * p * 16 == 2705326080
+
+
+def test_bench_launch_plan_and_streaming_bytes():
+    """The native schedule under one 512-sample block per call (the reference's own call pattern,
+    src/convolver/ConvolverProcessor.Runtime.cpp:659-682): layer 0 (12 x 512) launches every call, layer 1 (31 x 4096) once
+    every 8 calls -- a call is charged an eighth of that launch (= the reference's 4 partitions per callback,
+    src/MKLNonUniformConvolver.cpp:988-994), not all 31 partitions (round 3 charged them all: roofline.frac 3.7)."""
+    b = _bench()
+    lp = b.launch_plan(512, [(512, 12), (4096, 31)])
+    assert lp == [(512, 12, 1, 1.0), (4096, 31, 1, 0.125)]
+    n_ch = 512
+    mac = b.algorithmic_bytes_per_step(n_ch, 512, n_ch, lp, lp, native_tails=1)["k_fdl_mac"]
+    l0 = (n_ch * 12 + n_ch * 12 + n_ch) * 512 * 16            # 12 FDL rows + 12 IR rows + 1 output row per channel
+    l1 = (n_ch * 31 + n_ch * 31 + n_ch) * 4096 * 16
+    assert mac == l0 + l1 / 8 and 3.5e8 < mac < 3.8e8         # ~ 360 MB per call (DESIGN section 5), not 2.2 GB
+    # whole-call launches: 1024 blocks per call on the uniform schedule at P = 4096, K = 33: one launch of 128 partitions
+    lp = b.launch_plan(524288, [(4096, 33)])
+    assert lp == [(4096, 33, 128, 1.0)]
+    assert b.algorithmic_bytes_per_step(n_ch, 524288, n_ch, lp, lp)["k_fdl_mac"] == (n_ch * (33 + 127) + n_ch * 33 + n_ch * 128) * 4096 * 16
+    # a 480-sample quantum against 512-sample layer-0 partitions: 15 launches per 16 calls
+    lp = b.launch_plan(480, [(512, 12)])
+    assert lp[0][2] == 1 and abs(lp[0][3] - 0.9375) < 1e-12
+    # config 2 at T = 64, P = 512 (round-1 schedule): the figure DESIGN section 4 quotes
+    lp = b.launch_plan(64 * 512, [(512, 259)])
+    assert b.algorithmic_bytes_per_step(n_ch, 64 * 512, n_ch, lp, lp)["k_fdl_mac"] == 2705326080
+
+
+def test_bench_svf_flop_model_follows_the_saturation_setting():
+    b = _bench()
+    assert b.svf_flop_model(0.2) == {"slots": 33.0, "arithmetic": 26.0}
+    assert b.svf_flop_model(0.0) == {"slots": 21.0, "arithmetic": 17.0}      # no fastTanh blend at saturation 0 (`if sat > 0`)
+
+
+def test_fraction_check_flags_accounting_errors():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sp", os.path.join(ROOT, "tools", "summarize_profiles.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    ok = {"roofline": {"frac": 0.41, "hbm_kernel": {"frac": 0.68}}, "kernels": {"k_fdl_mac": {"achieved_gbs": 5400.0}}}
+    assert sp.check_fractions(ok) == []
+    bad = {"roofline": {"frac": 3.68}, "kernels": {"k_fdl_mac": {"achieved_gbs": 29451.7}}}
+    assert len(sp.check_fractions(bad)) == 2

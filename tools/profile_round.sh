@@ -26,8 +26,8 @@ python3 tools/summarize_profiles.py $TAG "$(find $O/stats -name '*kernel_stats.c
     "$(find $O/fetch -name '*counter_collection.csv' | head -1)" "$(find $O/write -name '*counter_collection.csv' | head -1)" \
     $O/stats.log > $O/summary.log 2>&1
 SQ=$(find $O/sq -name '*counter_collection.csv' | head -1)
-if [ -n "$SQ" ]; then python3 tools/summarize_sq.py "$SQ" > $CPQ_PROFILES_OUT/${TAG}_sq_counters.json 2>> $O/summary.log || true; fi
+if [ -n "$SQ" ]; then python3 tools/summarize_sq.py "$SQ" $O/sq.log > $CPQ_PROFILES_OUT/${TAG}_sq_counters.json 2>> $O/summary.log || true; fi
 LDS=$(find $O/lds -name '*counter_collection.csv' | head -1)
-if [ -n "$LDS" ]; then python3 tools/summarize_sq.py "$LDS" > $CPQ_PROFILES_OUT/${TAG}_lds_counters.json 2>> $O/summary.log || true; fi
+if [ -n "$LDS" ]; then python3 tools/summarize_sq.py "$LDS" $O/lds.log > $CPQ_PROFILES_OUT/${TAG}_lds_counters.json 2>> $O/summary.log || true; fi
 grep -h '"metric"' $O/stats.log > $CPQ_PROFILES_OUT/${TAG}_bench_profiled.json || true
 ls -la $CPQ_PROFILES_OUT

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Mean per launch of every SQ counter per kernel from a rocprofv3 --pmc counter_collection.csv (stdout: JSON)."""
+"""Mean per launch of every SQ counter per kernel from a rocprofv3 --pmc counter_collection.csv (stdout: JSON).
+usage: summarize_sq.py <counter_collection.csv> [bench_log_with_the_json_line]
+The optional bench log (stdout of the profiled bench.py run) tags the summary with the workload and the hash of the kernel
+sources (`_config`, as tools/summarize_profiles.py does): bench.py reports roofline.valu_issue_util only from a summary whose
+tag matches the run."""
 import collections
 import csv
 import json
@@ -21,6 +25,13 @@ def main():
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
            for k, cs in sorted(agg.items())}
+    if len(sys.argv) > 2:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from summarize_profiles import config_tag
+        tag = config_tag(sys.argv[2])
+        if tag:
+            out["_config"] = tag
     json.dump(out, sys.stdout, indent=1)
 
 

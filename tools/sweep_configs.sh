@@ -32,3 +32,4 @@ for l in open(sys.argv[1]):
     print(c["streams_per_gpu"], c["ir_taps"], "B", c["block"], "T", c["blocks_per_call"], "P", c["partition"], c["schedule"][:24], "|", c["workload"][60:120], "->", d["value"], "M/s", d["ms_per_step"], "ms",
           {k: v for k, v in d["kernels_ms_per_step"].items() if v}, "parity", (d.get("parity") or {}).get("rms_err"))
 PY
+python tools/summarize_profiles.py --check $OUT || echo "[sweep] a roofline fraction above 1: accounting error in bench.py"

@@ -25,3 +25,4 @@ for l in open("$OUT"):
     print(c.get("schedule", "")[:60], "|", d["call_mode"], "B", c.get("block"), "T", c.get("blocks_per_call"), "|", d["value"], "M/s", d["ms_per_step"], "ms/step",
           "scopes", d["kernel_scopes_per_step"], "host us", d["host_enqueue_us_per_step"], {k: v for k, v in d["kernels_ms_per_step"].items() if v})
 PY
+python tools/summarize_profiles.py --check $OUT || echo "[sweep] a roofline fraction above 1: accounting error in bench.py"
