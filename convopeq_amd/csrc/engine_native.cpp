@@ -165,6 +165,7 @@ int sizeGroup(cpq_engine* e, PlanGroup& g, int capPairs)
     int* irSlotNew = nullptr;
     long long* tabNew = nullptr;
     auto undo = [&](int rc) {
+        (void)hipStreamSynchronize(e->stream);      // row copies into the fresh buffers may still be in flight
         for (NativeLayer& t : fresh) if (t.mem) (void)hipFree(t.mem);
         if (chMapNew) (void)hipFree(chMapNew);
         if (irSlotNew) (void)hipFree(irSlotNew);

@@ -76,13 +76,28 @@ int enqueueConvProc(cpq_engine* e, const double* dIn, double* dOut, int n)
 {
     if (!e->procGains) { const int rc = uploadProcParams(e); if (rc != CPQ_OK) return rc; }
     {
-        // feasibility first, before the ramp replay below consumes samples: resting ONE convolver needs that stream in a plan group
+        // feasibility first, before the ramp replay below consumes samples: resting ONE convolver needs that stream in a plan
+        // group.  Which convolvers rest in THIS call is predicted from the ramps exactly as the replay below will decide it (a
+        // dry-only stream keeps convolving while its mix ramp runs: streams set dry-only together can still differ for a call or
+        // two when their ramps have different lengths left) -- nothing is mutated here.
         const int Sn = e->desc.n_streams;
         bool allWant = true, anyWant = false;
-        for (int s = 0; s < Sn; ++s) { const bool w = e->procBypass[s] || e->procDryOnly[s]; allWant = allWant && w; anyWant = anyWant || w; }
+        std::vector<char> want((size_t)Sn, 0);
+        for (int s = 0; s < Sn; ++s) {
+            bool willRamp = false;
+            if (!e->procBypass[s]) {
+                const auto& r = e->mixRamp[s];
+                const double tgt = (double)e->procParams[s].mix;
+                const bool retarget = std::fabs(r.target - tgt) > 1.0e-5 && tgt != r.target;
+                willRamp = (retarget ? (r.remaining > 0 ? r.remaining : r.totalSteps) : r.remaining) > 0;
+            }
+            want[(size_t)s] = e->procBypass[s] || (e->procDryOnly[s] && !willRamp);
+            allWant = allWant && want[(size_t)s];
+            anyWant = anyWant || want[(size_t)s];
+        }
         if (anyWant && !allWant)
             for (int s = 0; s < Sn; ++s)
-                if ((e->procBypass[s] || e->procDryOnly[s]) && e->groupOf[(size_t)s] < 0)
+                if (want[(size_t)s] && e->groupOf[(size_t)s] < 0)
                     return fail(e, CPQ_ERR_UNSUPPORTED, "stream %d: a per-stream bypass / dry-only needs the stream on the reference's own "
                                 "layer plan (CPQ_CALLS_ANY, CPQ_SCHED_REFERENCE_NUC or a FilterSpec plan with tail layers); on the "
                                 "uniform path set it for CPQ_ALL_STREAMS", s);

@@ -1,8 +1,11 @@
 #!/bin/bash
 # A/B timing of versions of one kernel source on the GPU box (same box, alternating):
 #   tools/ab_files.sh <rounds> convopeq_amd/csrc/svf_kernels.hip <version A> <version B> ...
-# Prints the kernel times of the default bench per build; restores the LAST version at the end.
+# Prints the kernel times of the default bench per build.  The tracked file is put back (and the library rebuilt from it)
+# however the script ends.
 ROUNDS=$1; TARGET=$2; shift 2
+KEEP=$(mktemp); cp "$TARGET" "$KEEP"
+trap 'cp "$KEEP" "$TARGET"; rm -f "$KEEP"; make -C convopeq_amd/csrc >/dev/null 2>&1' EXIT
 for r in $(seq $ROUNDS); do
   for v in "$@"; do
     cp "$v" "$TARGET"
@@ -13,5 +16,3 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$v:', d['value'], 'M/s', {k: v for k, v in d['kernels_ms_per_step'].items() if v}, 'step', d['ms_per_step'])"
   done
 done
-for last in "$@"; do :; done
-cp "$last" "$TARGET"; make -C convopeq_amd/csrc >/dev/null 2>&1
