@@ -2053,3 +2053,40 @@ def test_two_engines_interleaved_and_no_device_memory_leak(amd, oracle):
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
     assert abs(free[3] - free[15]) < 4 << 20, free
+
+
+def test_processor_level_dry_only_with_unequal_ramps_fails_before_any_state_moves(amd, oracle):
+    """Two streams on the uniform path are set dry-only together while one of them is in the middle of a mix ramp (it keeps
+    its remaining step count): when its ramp has run out and the other one's has not, one convolver would rest and the other
+    not -- which the uniform path cannot do (a per-stream rest needs a plan group).  The call must be refused BEFORE the ramp replay has consumed anything: refused twice with the same
+    status, and after stream 0 is given a mix again the engine continues exactly like a twin that never made the refused calls
+    (the reference keeps convolving while a ramp runs: isSmoothing || mix > 0.001, ConvolverProcessor.Runtime.cpp:373-375)."""
+    O = oracle
+    S, T = 2, 4
+    irs = [O.gen_ir(3000, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    x = make_inputs(O, S, 6 * T * B)
+
+    def run(with_refused_calls):
+        eng = amd.BatchedEngine(S, max_ir_len=3000, max_blocks_per_call=T)
+        for s in range(S):
+            eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+        call = lambda k: eng.convproc_process(x[:, k * T * B:(k + 1) * T * B])
+        out = [call(0)]                                          # both wet (the first call snaps)
+        eng.set_convproc_params(0, mix=0.5)
+        out.append(call(1))                                      # stream 0 ramps (4800 samples = 2.3 calls): 2752 left
+        eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=0.0)    # both dry-only: stream 0 keeps its 2752 steps, stream 1 starts 4800
+        out.append(call(2))
+        out.append(call(3))                                      # stream 0's ramp ends inside this call
+        if with_refused_calls:
+            for _ in range(2):                                   # stream 0 would rest, stream 1 still ramps
+                with pytest.raises(amd.CpqError) as ei:
+                    call(4)
+                assert ei.value.status == -5          # CPQ_ERR_UNSUPPORTED
+        eng.set_convproc_params(amd.CPQ_ALL_STREAMS, mix=0.6)
+        out.append(call(4))
+        out.append(call(5))
+        eng.close()
+        return np.concatenate(out, axis=1)
+
+    a, b = run(True), run(False)
+    assert np.array_equal(a, b)
