@@ -10,7 +10,7 @@ int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t strid
                    const double* coef, const int* flags, const double* satGain, double* state, const double* tables,
                    bool streamPairs = false)
 {
-    const int nTp = tp ? (n & ~1) : 0;            // the time-parallel kernels take any even number of samples (chunks of two at the least); a last odd sample goes to the sequential kernel
+    const int nTp = tp ? n : 0;                   // the time-parallel kernels take any number of samples
     if (nTp > 0) {
         ProfScope p(e, idTp);
         cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables,

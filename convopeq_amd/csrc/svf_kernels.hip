@@ -351,12 +351,14 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 // zero-state (or continuing) recurrence of one band over N samples held in registers: v[j] <- y_lin[j]
 // KIND: 0 = SVF, packed stereo arithmetic (FMA), 1 = SVF scalar arithmetic (Left/Right modes), 2 = DF-II-T biquad
 // of the OutputFilter (coefficients b0 b1 b2 a1 a2 in a1 a2 a3 m0 m1; state w1 w2 in ic1 ic2)
-template <int KIND, int N>
+// CAP: the state behind sample capAt is copied to (c1, c2) -- the end state of a span whose last chunk is partly padding
+template <int KIND, int N, bool CAP = false>
 __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic2, double a1, double a2, double a3,
-                                         double m0, double m1, double m2)
+                                         double m0, double m1, double m2, int capAt = -1, double* c1 = nullptr, double* c2 = nullptr)
 {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
+        if (CAP && j > 0) { *c1 = (capAt == j - 1) ? ic1 : *c1; *c2 = (capAt == j - 1) ? ic2 : *c2; }
         const double v0 = v[j];
         if (KIND == 2) {
             const double yy = fma(a1, v0, ic1);
@@ -391,6 +393,7 @@ __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic
             v[j] = fma(m0, v0, fma(m1, v1, m2 * v2));
         }
     }
+    if (CAP) { *c1 = (capAt == N - 1) ? ic1 : *c1; *c2 = (capAt == N - 1) ? ic2 : *c2; }
 }
 
 // per-workgroup LDS copy of the channel's per-band constants (one chunk length at a time)
@@ -585,13 +588,13 @@ __device__ __forceinline__ void tp_scan(double ic1, double ic2, double& s0x, dou
 // guarded sequential fallback for one band over the span held in LDS (one thread): the reference recurrence
 // with every guard, used when the span input or the carried state is outside the proven-safe range.
 template <int KIND>
-__device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sat, double* sState, int nChunks = kTpChunks)
+__device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sat, double* sState, int nSamples)
 {
     const double a1 = cf[0], a2 = cf[1], a3 = cf[2], m0 = cf[3], m1 = cf[4], m2 = cf[5];
     const double oneMinusSat = 1.0 - sat;
     double ic1 = sState[0], ic2 = sState[1];
-    for (int c = 0; c < nChunks; ++c)
-        for (int i = 0; i < lc; ++i) {
+    for (int c = 0; c * lc < nSamples; ++c)
+        for (int i = 0; i < lc && c * lc + i < nSamples; ++i) {
             double y[1] = { buf[c * kTpStride + i] };
             tp_recur<KIND, 1>(y, ic1, ic2, a1, a2, a3, m0, m1, m2);
             if (KIND == 2) {          // OutputFilter: no output stage, denormal flush of the state (OutputFilter.cpp:154-162)
@@ -670,9 +673,9 @@ __device__ __forceinline__ void tp_span(const double* in, double* out, double* b
             const int flag = fl[b];
             if (!(flag & 1)) continue;
             if (tid == 0) {
-                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid / LC);
-                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid / LC);
-                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid / LC);
+                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid);
+                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid);
+                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid);
             }
             __syncthreads();
         }
@@ -871,17 +874,20 @@ struct TpvShared {
 // scalar fastTanh's hard +-1 on the rare large-signal output stage), KIND 2: DF-II-T biquad of the OutputFilter.
 // The recurrence runs over all 16 samples first: the output stage does not feed back into the state, so it follows as
 // independent evaluations behind ONE wave-uniform test for the small-signal form.  En = the NEXT band's E rows in LDS.
-template <int KIND, bool SAT>
+// CAP (spans whose last chunk is partly padding): the lane with capAt >= 0 also returns the band's state behind its sample
+// capAt in (c1, c2).
+template <int KIND, bool SAT, bool CAP = false>
 __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2, const double* __restrict__ cfb, bool mono,
                                          const double* En, double& e0o, double& e1o,
-                                         double sat, double oneMinusSat, bool smallOk, double smallC1)
+                                         double sat, double oneMinusSat, bool smallOk, double smallC1,
+                                         int capAt = -1, double* c1 = nullptr, double* c2 = nullptr)
 {
     {
         const double a1 = cfb[0], a2 = cfb[1], a3 = cfb[2], m0 = cfb[3], m1 = cfb[4], m2 = cfb[5];
         if (KIND == 3)          // m0 == 1 and m2 == 0 (peaking bands)
-            tp_recur<3, 16>(x, ic1, ic2, 2.0 * a2, 2.0 * a3, 0.0, a2, m1, a1);
+            tp_recur<3, 16, CAP>(x, ic1, ic2, 2.0 * a2, 2.0 * a3, 0.0, a2, m1, a1, capAt, c1, c2);
         else
-        tp_recur<KIND, 16>(x, ic1, ic2, a1, a2, a3, m0, m1, m2);
+        tp_recur<KIND, 16, CAP>(x, ic1, ic2, a1, a2, a3, m0, m1, m2, capAt, c1, c2);
     }
     double e0 = 0.0, e1 = 0.0;
     bool done = false;
@@ -960,6 +966,54 @@ __device__ __forceinline__ void tpv_span_load(const double* src, double* buf, in
         wave_lds_sync();
     }
 }
+// The same for a span with nValid (< 1024 possible, any count) samples in this wave's part: 8-byte accesses, nothing read or
+// written behind sample nValid - 1 (the padding reads as silence); rows of any alignment (a 441-sample call has odd rows).
+__device__ __forceinline__ void tpv_span_load_partial(const double* src, double* buf, int lane, double (&x)[16], int nValid)
+{
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = k * 128 + lane * 2;
+        t[2 * k] = (i < nValid) ? src[i] : 0.0;
+        t[2 * k + 1] = (i + 1 < nValid) ? src[i + 1] : 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (((lane >> 1) & 3) == h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1)) = make_double2(t[2 * k], t[2 * k + 1]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double2 v = *reinterpret_cast<const double2*>(buf + lane * kTpvQStride + 2 * j);
+            x[4 * h + 2 * j] = v.x;
+            x[4 * h + 2 * j + 1] = v.y;
+        }
+        wave_lds_sync();
+    }
+}
+__device__ __forceinline__ void tpv_span_store_partial(double* dst, double* buf, int lane, const double (&x)[16], double gain, int nValid)
+{
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<double2*>(buf + lane * kTpvQStride + 2 * j) = make_double2(x[4 * h + 2 * j] * gain, x[4 * h + 2 * j + 1] * gain);
+        wave_lds_sync();
+        if (((lane >> 1) & 3) == h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double2 v = *reinterpret_cast<const double2*>(buf + (8 * k + (lane >> 3)) * kTpvQStride + 2 * (lane & 1));
+                const int i = k * 128 + lane * 2;
+                if (i < nValid) dst[i] = v.x;
+                if (i + 1 < nValid) dst[i + 1] = v.y;
+            }
+        }
+        wave_lds_sync();
+    }
+}
 // The lanes of quarter h pick their eight 16-byte pieces out of the exchange buffer into t[8], assigned under `if (quarter
 // == mine)`.  t[] would enter the quarter loop undefined, and the compiler then keeps a 32-register "don't care" tuple alive
 // across the whole SPAN loop, spilled and reloaded per span (as much HBM traffic again as the span itself:
@@ -1004,9 +1058,9 @@ __device__ void tpv_guarded_span(SH& sh, int spanLen, const double* src, double*
             for (unsigned m = activeMask; m; m &= m - 1) {
                 const int b = __builtin_ctz(m);
                 const int kind = (int)((kinds >> (2 * b)) & 3);
-                if (kind == 2)      tp_band_guarded<2>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
-                else if (kind == 1) tp_band_guarded<1>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
-                else                tp_band_guarded<0>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt / 16);
+                if (kind == 2)      tp_band_guarded<2>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt);
+                else if (kind == 1) tp_band_guarded<1>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt);
+                else                tp_band_guarded<0>(sh.scratch, 16, cf + b * 6, sat, sState + 2 * b, cnt);
             }
         }
         __syncthreads();
@@ -1034,10 +1088,11 @@ __device__ __forceinline__ int tpv_lane_id()
 // The bands of `run` (one class: CLS 0 = SVF, 3 = SVF with output v0 + m1 v1, 2 = DF-II-T) over the span held in x: per band the scan of the chunk end
 // states, then the pass.  e0 / e1: E x of the run's first band on entry, of the first band of `rest` (the bands behind
 // the run) on exit.
-template <int CLS, bool SAT, int NT, bool CHAINED, class SH>
+// endTid >= 0 (PARTIAL spans only): the span ends behind sample capAt of chunk endTid (its tail is padding).
+template <int CLS, bool SAT, int NT, bool CHAINED, bool PARTIAL, class SH>
 __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double& e1, int& par, unsigned run, unsigned rest,
                                              unsigned monoMask, SH& sh, double* sState, double* sNext, const double* __restrict__ cf,
-                                             double sat, int waveU, int nThreads, const TpvLink& link)
+                                             double sat, int waveU, int nThreads, const TpvLink& link, int endTid = -1, int capAt = 15)
 {
     const double oneMinusSat = tpv_uniform(1.0 - sat);
     const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
@@ -1051,9 +1106,18 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
         double s0x, s0y;
         // (the thread index and the LDS addresses derived from it are rebuilt per band: tpv_lane_id)
         const int tidL = (waveU << 6) + tpv_lane_id();
-        tp_scan<NT, CHAINED>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tidL, &sh.P[b][0][0], -1, &link);
+        tp_scan<NT, CHAINED>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tidL, &sh.P[b][0][0], PARTIAL ? endTid : -1, &link);
         par ^= 1;
-        tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1);
+        if (PARTIAL) {
+            // the band's end state is the one behind the span's last valid sample, which the pass meets inside chunk endTid
+            // (the scan above left there the state behind that chunk's padding)
+            double c1 = 0.0, c2 = 0.0;
+            tpv_pass<CLS, SAT, true>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1,
+                                     tidL == endTid ? capAt : -1, &c1, &c2);
+            if (tidL == endTid) { sNext[2 * b] = c1; sNext[2 * b + 1] = c2; }
+        } else {
+            tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1);
+        }
     }
 }
 
@@ -1101,18 +1165,23 @@ __device__ __forceinline__ void tpv_load_tables(SH& sh, const TpBandTables* __re
 // checkStates, a start state in sState) is outside the proven range: nothing has been stored or published; CHAINED: 2 + b
 // when the start state of band b arrived out of range: the bands from b
 // on have not been published, nothing has been stored -- the caller runs the span again on the guarded path.
-template <int NT, bool CHAINED, class SH>
+// PARTIAL: the span holds nValid samples (1 ... 1024 x waves, any count): nValidW of them in this wave's part, the rest of the
+// span is padding (read as silence, not written); the band states end behind sample nValid - 1.
+template <int NT, bool CHAINED, bool PARTIAL, class SH>
 __device__ __forceinline__ int tpv_fast_span(SH& sh, const double* srcW, double* dstW, const TpvBands& bm, const double* __restrict__ cf,
                                              double sat, double gain, double* sState, double* sNext, bool checkStates, int waveU,
-                                             int nThreads, const TpvLink& link)
+                                             int nThreads, const TpvLink& link, int nValid = 0)
 {
+    const int nValidW = PARTIAL ? max(0, min(1024, nValid - waveU * 1024)) : 1024;
+    const int endTid = PARTIAL ? (nValid - 1) >> 4 : -1, capAt = PARTIAL ? ((nValid - 1) & 15) : 15;
     double* buf = sh.scratch + waveU * 64 * kTpvQStride;
     double x[16];
     // (the per-lane addresses of the span I/O are rebuilt per span, like the thread index inside the band loop: kept across
     // the band loops they were the kernel's last spilled registers)
     int laneIo = tpv_lane_id();
     const int tidS = (waveU << 6) + laneIo;           // (= threadIdx.x, for the same reason)
-    tpv_span_load(srcW, buf, laneIo, x);
+    if (PARTIAL) tpv_span_load_partial(srcW, buf, laneIo, x, nValidW);
+    else         tpv_span_load(srcW, buf, laneIo, x);
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
@@ -1146,7 +1215,7 @@ __device__ __forceinline__ int tpv_fast_span(SH& sh, const double* srcW, double*
             const unsigned other = mask & ~same;
             const unsigned run = other ? (same & ((other & (0u - other)) - 1u)) : same;     // bands below the first one of another class
             const unsigned rest = mask & ~run;
-#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, NT, CHAINED>(x, e0, e1, par, run, rest, bm.mono, sh, sState, sNext, cf, sat, waveU, nThreads, link)
+#define CPQ_RUN(CLS, SAT) tpv_band_run<CLS, SAT, NT, CHAINED, PARTIAL>(x, e0, e1, par, run, rest, bm.mono, sh, sState, sNext, cf, sat, waveU, nThreads, link, endTid, capAt)
             if (cls == 2)        CPQ_RUN(2, false);
             else if (sat > 0.0) { if (cls == 3) CPQ_RUN(3, true); else CPQ_RUN(0, true); }
             else                { if (cls == 3) CPQ_RUN(3, false); else CPQ_RUN(0, false); }
@@ -1161,21 +1230,25 @@ __device__ __forceinline__ int tpv_fast_span(SH& sh, const double* srcW, double*
         if (f != 0) { __syncthreads(); return 1 + f; }
     }
     laneIo = tpv_lane_id();
-    tpv_span_store(dstW, buf, laneIo, x, gain);
+    if (PARTIAL) tpv_span_store_partial(dstW, buf, laneIo, x, gain, nValidW);
+    else         tpv_span_store(dstW, buf, laneIo, x, gain);
     __syncthreads();                      // the last thread's end states are in sNext; every wave's stores are out
     return 0;
 }
 
-template <int WAVES, bool CHAINED>
-__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
+template <int WAVES, bool CHAINED, bool PARTIAL = false>
+__global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_svf_cascade_tpv(const double* in, double* out, int64_t chStride,
                                                                               int nSpans, int nCh, const double* __restrict__ coef,
                                                                               const int* __restrict__ flags,
                                                                               const double* __restrict__ satGain,
                                                                               double* __restrict__ state,
                                                                               const TpBandTables* __restrict__ tables,
                                                                               unsigned long long* chain, int chainSpans,
-                                                                              unsigned bandFilter)
+                                                                              unsigned bandFilter, int nValid)
 {
+    // WAVES == 0: ONE span of blockDim.x / 64 (1 ... 7) waves x 1024 samples -- what a call leaves behind its whole 8192-sample
+    // spans; PARTIAL: of nValid samples, any count from 1 to that (the span's tail is padding)
+    constexpr bool kPartial = PARTIAL;
     constexpr int kMaxWaves = WAVES ? WAVES : 7;
     constexpr int kNT = WAVES * 64;                           // 0: blockDim.x
     __shared__ TpvShared<kMaxWaves> sh;
@@ -1201,15 +1274,15 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
         int sp = 0;
 #pragma unroll 1
         for (; sp < nSpans; ++sp) {
-            if (tpv_fast_span<kNT, false>(sh, inCh + (int64_t)sp * spanLen + waveU * 1024, outCh + (int64_t)sp * spanLen + waveU * 1024,
-                                          bm, cf, sat, gain, sState, sNext, true, waveU, nThreads, link) != 0)
+            if (tpv_fast_span<kNT, false, kPartial>(sh, inCh + (int64_t)sp * spanLen + waveU * 1024, outCh + (int64_t)sp * spanLen + waveU * 1024,
+                                                    bm, cf, sat, gain, sState, sNext, true, waveU, nThreads, link, nValid) != 0)
                 break;
             { double* t = sState; sState = sNext; sNext = t; }
         }
         const int tidE = (waveU << 6) + tpv_lane_id();            // (= tid, rebuilt: see tpv_lane_id)
         // cold: this span and the later ones through the guarded recurrence (states advance in sState)
         for (; sp < nSpans; ++sp)
-            tpv_guarded_span(sh, spanLen, inCh + (int64_t)sp * spanLen, outCh + (int64_t)sp * spanLen, sState, cf, bm.active, bm.kinds,
+            tpv_guarded_span(sh, kPartial ? nValid : spanLen, inCh + (int64_t)sp * spanLen, outCh + (int64_t)sp * spanLen, sState, cf, bm.active, bm.kinds,
                              sat, gain, tidE, nThreads);
         __syncthreads();
         // the call's end states (only this launch's bands are written)
@@ -1245,8 +1318,8 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, 4) void k_svf_cascade_tpv
             const TpvLink link = { sp > 0 ? g - kBands * 4 : nullptr, sp + 1 < nSpans ? g : nullptr, epoch, &sh.flag, &hdr->error };
             const double* src = in + (int64_t)c * chStride + (int64_t)sp * spanLen;
             double* dst = out + (int64_t)c * chStride + (int64_t)sp * spanLen;
-            const int r = tpv_fast_span<kNT, true>(sh, src + waveU * 1024, dst + waveU * 1024, bm, cf, sat, gain, sh.stateA, sh.stateB,
-                                                   sp == 0, waveU, nThreads, link);
+            const int r = tpv_fast_span<kNT, true, false>(sh, src + waveU * 1024, dst + waveU * 1024, bm, cf, sat, gain, sh.stateA, sh.stateB,
+                                                          sp == 0, waveU, nThreads, link);
             const int tidE = (waveU << 6) + tpv_lane_id();
             if (r != 0) {
                 // cold: the span on the guarded path.  Its start states: all of them from the span before (that workgroup has
@@ -1329,21 +1402,36 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
             const int nTasks = nSpans8 * nCh;
             hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, true>), dim3(nTasks < chainGrid ? nTasks : chainGrid), dim3(kTpvWaves * 64), 0, stream,
                                in, out, chStride, nSpans8, nCh, coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain),
-                               chainSpans, kAllBands);
+                               chainSpans, kAllBands, 0);
         } else {
             hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8, nCh,
-                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands);
+                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands, 0);
         }
         done = nSpans8 * kTpvSpan;
     }
-    const int nWaves = (nSamples - done) / 1024;
-    if (nWaves > 0) {
-        hipLaunchKernelGGL((k_svf_cascade_tpv<0, false>), dim3(nCh), dim3(nWaves * 64), 0, stream, in + done, out + done, chStride, 1, nCh,
-                           coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands);
-        done += nWaves * 1024;
+    // What is left behind the whole spans (and calls shorter than one).  From 1024 samples up: ONE span of up to seven waves x
+    // 1024 samples on the same kernel, its tail padding where the count is not a multiple of 1024 (two launches for 7169 ... 8191
+    // samples).  Below 1024 samples the chain of 20 dependent bands is all a launch costs, and 256 chunks of two samples walk it
+    // faster than 32 chunks of sixteen (0.034 against 0.067 ms per 512-sample callback, profiles/r04f_eq_short_calls.txt):
+    // k_svf_cascade_tp over the even part (a last span padded), a last odd sample on the lane-skewed kernel.
+    while (nSamples - done >= 1024) {
+        int cnt = nSamples - done;
+        if (cnt > 7 * 1024) cnt = 4 * 1024;
+        const dim3 block(((cnt + 1023) / 1024) * 64);
+        if (cnt % 1024 == 0)
+            hipLaunchKernelGGL((k_svf_cascade_tpv<0, false, false>), dim3(nCh), block, 0, stream, in + done, out + done, chStride, 1, nCh,
+                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands, cnt);
+        else
+            hipLaunchKernelGGL((k_svf_cascade_tpv<0, false, true>), dim3(nCh), block, 0, stream, in + done, out + done, chStride, 1, nCh,
+                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands, cnt);
+        done += cnt;
+    }
+    const int even = (nSamples - done) & ~1;
+    if (even > 0) {
+        hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in + done, out + done, chStride, even, coef, flags, satGain, state, tb);
+        done += even;
     }
     if (nSamples > done)
-        hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in + done, out + done, chStride,
-                           nSamples - done, coef, flags, satGain, state, tb);
+        launch_svf_cascade(stream, in + done, out + done, chStride, nCh, nSamples - done, coef, flags, satGain, state, false);
 }
 }  // namespace cpq
