@@ -70,6 +70,8 @@ struct PlanGroup {
     std::vector<long long> tabHost;
     std::vector<size_t> tabOffs;
     std::vector<int> nbOf;
+    long long callW0 = 0, callR0 = 0;           // layer 0's write / read positions before the call in flight was replayed
+    bool tabOnDevice = false;                   // the call's tables went out with its gather launch (kernel arguments)
     long long samplesSinceReset = 0;
     int lastGot = 0, lastCall = 0;              // Get()'s return value summed over the chunks of the last call
 };

@@ -582,6 +582,13 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
         // call's rows: its forward transforms run right here, straight from the call's input (before anything can write
         // dOut, which may alias dIn), and runLayerBlocks continues behind them.
         const bool rowsAreCallRows = g.identityMap && g.usedCh == e->nCh;
+        // the reference's Add / Get bookkeeping of this call, replayed here so that a small table can leave with the gather
+        // launch below (kernel arguments) instead of a host -> device copy of its own in front of layer 0
+        g.callW0 = g.layers[0].wPos;
+        g.callR0 = g.layers[0].rPos;
+        replayCall(e, g, n, g.tabHost, g.tabOffs, g.nbOf);
+        g.tabOnDevice = false;
+        if ((int)g.tabHost.size() > g.tabCap) return fail(e, CPQ_ERR_INVALID_ARG, "call of %d samples exceeds the engine's call capacity", n);
         double* dst[3];
         int64_t stride[3], off[3];
         int nl = 0, li = 0;
@@ -602,7 +609,10 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
         }
         if (nl > 0) {
             ProfScope p(e, CPQ_K_MIX);
-            cpq::launch_rows_gather_multi(e->stream, dIn, n, g.chMapDev, nl, dst, stride, off, n, g.usedCh);
+            const bool ride = (int)g.tabHost.size() <= cpq::kGatherTabMax && g.usedCh > 0 && n > 0;
+            cpq::launch_rows_gather_multi(e->stream, dIn, n, g.chMapDev, nl, dst, stride, off, n, g.usedCh,
+                                          ride ? g.tabDev : nullptr, g.tabHost.data(), ride ? (int)g.tabHost.size() : 0);
+            g.tabOnDevice = ride;
         }
     }
     CPQ_HIP(e, hipGetLastError());
@@ -662,10 +672,8 @@ int groupsRunLayer0(cpq_engine* e, double* dOut, int n)
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
         if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
-        const long long w0 = g.layers[0].wPos, r0 = g.layers[0].rPos;
-        replayCall(e, g, n, g.tabHost, g.tabOffs, g.nbOf);
-        if ((int)g.tabHost.size() > g.tabCap) return fail(e, CPQ_ERR_INVALID_ARG, "call of %d samples exceeds the engine's call capacity", n);
-        { const int rc = stageUpload(e, g.tabDev, g.tabHost.data(), g.tabHost.size() * sizeof(long long)); if (rc != CPQ_OK) return rc; }
+        const long long w0 = g.callW0, r0 = g.callR0;        // (replayed in groupsAppend)
+        if (!g.tabOnDevice) { const int rc = stageUpload(e, g.tabDev, g.tabHost.data(), g.tabHost.size() * sizeof(long long)); if (rc != CPQ_OK) return rc; }
         // Whole-block call on an empty ring, every chunk's Get() taking exactly the chunk this call's blocks produce, members =
         // all channels in order: the inverse FFT writes the output rows directly, no ring put / get (two passes and two
         // launches less; the ring stays empty, its positions advanced on the host by the replay above)

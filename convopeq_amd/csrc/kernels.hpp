@@ -139,8 +139,12 @@ void launch_tail_schedule(hipStream_t stream, void* state, long long* sched, int
 void launch_rows_gather(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, double* dst,
                         int64_t dstStride, int64_t dstOff, int n, int nCh);
 // up to three layers' accumulators in one pass over the input; both tail layers' read-add in one pass over the output
+// tabDst / tab / nTab: a small table (<= kGatherTabMax entries) that rides along as kernel arguments and is stored to tabDst by
+// the launch -- the call's chunk schedule of a plan group without a host -> device copy of its own
+constexpr int kGatherTabMax = 64;
 void launch_rows_gather_multi(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, int nLayers,
-                              double* const* dst, const int64_t* dstStride, const int64_t* dstOff, int n, int nCh);
+                              double* const* dst, const int64_t* dstStride, const int64_t* dstOff, int n, int nCh,
+                              long long* tabDst = nullptr, const long long* tab = nullptr, int nTab = 0);
 void launch_ring_add_chunks2(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
                              const double* ringA, int ringSizeA, const long long* schedA, double gainA,
                              const double* ringB, int ringSizeB, const long long* schedB, double gainB, int nCh);

@@ -301,9 +301,12 @@ __global__ __launch_bounds__(256) void k_ring_put_blocks(const double* __restric
 // the call's input into the accumulators of up to three layers of a plan group at once (Add(): every layer accumulates the
 // same input, src/MKLNonUniformConvolver.cpp:1431-1446): the input row is read once
 struct GatherDst { double* dst[3]; long long stride[3]; long long off[3]; int n; };
+struct GatherTab { long long* dst; int n; long long v[kGatherTabMax]; };
 __global__ __launch_bounds__(256) void k_rows_gather_multi(const double* __restrict__ src, int64_t srcStride,
-                                                           const int* __restrict__ chMap, GatherDst d, int n)
+                                                           const int* __restrict__ chMap, GatherDst d, int n, GatherTab tab)
 {
+    // the call's chunk tables (kernel arguments) into device memory for the kernels behind this one
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < tab.n) tab.dst[threadIdx.x] = tab.v[threadIdx.x];
     const int g = chMap[blockIdx.y];
     if (g < 0) return;
     const double* s = src + (int64_t)g * srcStride;
@@ -587,13 +590,16 @@ void launch_rows_gather(hipStream_t stream, const double* src, int64_t srcStride
 }
 
 void launch_rows_gather_multi(hipStream_t stream, const double* src, int64_t srcStride, const int* chMap, int nLayers,
-                              double* const* dst, const int64_t* dstStride, const int64_t* dstOff, int n, int nCh)
+                              double* const* dst, const int64_t* dstStride, const int64_t* dstOff, int n, int nCh,
+                              long long* tabDst, const long long* tab, int nTab)
 {
     if (n <= 0 || nCh <= 0 || nLayers <= 0) return;
     GatherDst d{};
     d.n = nLayers > 3 ? 3 : nLayers;
     for (int l = 0; l < d.n; ++l) { d.dst[l] = dst[l]; d.stride[l] = dstStride[l]; d.off[l] = dstOff[l]; }
-    hipLaunchKernelGGL(k_rows_gather_multi, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, chMap, d, n);
+    GatherTab gt{};
+    if (tabDst && tab && nTab > 0 && nTab <= kGatherTabMax) { gt.dst = tabDst; gt.n = nTab; for (int i = 0; i < nTab; ++i) gt.v[i] = tab[i]; }
+    hipLaunchKernelGGL(k_rows_gather_multi, rowsGrid(n, nCh), dim3(256), 0, stream, src, srcStride, chMap, d, n, gt);
 }
 
 void launch_ring_add_chunks2(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
