@@ -302,9 +302,9 @@ bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, ld D, d
         for (int q = 0; q < 4; ++q) r[q] = acc[q];
     };
     // layout: struct TpLcTables { Mk[6][4]; Mw[4]; P[64][4]; G[16][2]; } for LC = 16 then LC = 2 (svf_kernels.hip)
-    const int lcs[2] = { kSvfTpLc[0], kSvfTpLc[1] };
+    const int* lcs = kSvfTpLc;
     constexpr int kPerLc = 6 * 4 + 4 + 64 * 4 + 16 * 2;
-    for (int li = 0; li < 2; ++li) {
+    for (int li = 0; li < kSvfTpLcCount; ++li) {
         double* o = out + li * kPerLc;
         const int lc = lcs[li];
         ld M[4];
@@ -328,7 +328,7 @@ bool buildTpTablesFromStateSpace(const ld* A, const ld* C, const ld* Bv, ld D, d
     // matrix form of a 16-sample chunk (MFMA path of the time-parallel kernel): zero-state impulse response
     // h[0] = D, h[n] = C A^(n-1) B behind 15 zeros, and the chunk's end-state map e[:, k] = A^(15-k) B
     {
-        double* o = out + 2 * kPerLc;
+        double* o = out + kSvfTpLcCount * kPerLc;
         for (int i = 0; i < kSvfTpMfmaDoubles; ++i) o[i] = 0.0;
         ld v[2] = { Bv[0], Bv[1] };                     // A^n B
         o[15] = (double)D;

@@ -7,17 +7,16 @@
 
 namespace cpq {
 
-// geometry of the time-parallel SVF kernel (svf_kernels.hip), shared with buildSvfTpTables()
-#ifndef CPQ_TP_WAVES
-#define CPQ_TP_WAVES 4          // waves per channel in k_svf_cascade_tp (512-sample spans of 64*W chunks; table slot 1)
-#endif
-constexpr int kSvfTpWaves = CPQ_TP_WAVES;
-constexpr int kSvfTpLc[2] = { 4096 / (64 * kSvfTpWaves), 512 / (64 * kSvfTpWaves) };
+// geometry of the time-parallel SVF kernels (svf_kernels.hip), shared with buildSvfTpTables()
+// chunk lengths with a table block each: 16 (spans of 8192 / 1024 x waves samples: k_svf_cascade_tpv), 8 (spans below 1024
+// samples on one or two waves: k_svf_cascade_short)
+constexpr int kSvfTpLcCount = 2;
+constexpr int kSvfTpLc[kSvfTpLcCount] = { 16, 8 };
 constexpr int kSvfTpLcDoubles = 6 * 4 + 4 + 64 * 4 + 16 * 2;
 // after the two per-chunk-length blocks: the matrix form of one 16-sample chunk for the MFMA path (chunk length 16 only):
 // ht[32] = 15 zeros, h[0..15], 0 (zero-state impulse response; T[m][k] = ht[15 + m - k]),  e[2][16] = A^(15-k) B
 constexpr int kSvfTpMfmaDoubles = 32 + 2 * 16;
-constexpr int kSvfTpTableDoubles = 2 * kSvfTpLcDoubles + kSvfTpMfmaDoubles;
+constexpr int kSvfTpTableDoubles = kSvfTpLcCount * kSvfTpLcDoubles + kSvfTpMfmaDoubles;
 
 int    computeNucPlan(int irLen, int blockSize, bool enableDirectHead, const cpq_filter_spec* spec,
                       cpq_nuc_plan* out);

@@ -72,12 +72,12 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
                         int nSamples, const double* coef, const int* flags, const double* satGain,
                         double* state, bool streamPairs);
 
-// Time-parallel SVF cascade: one 4-wave workgroup per channel, 256 chunks of a span in flight per band
-// (zero-state chunk runs + state scan + linear state response), span resident in LDS across the 20 bands.
-// nSamples: any even number.  tables: kSvfTpTableDoubles doubles per (stream, band):
-// for each chunk length LC in kSvfTpLc ({16, 2} at 4 waves per channel): Mk[6][4] = A^(LC 2^k), Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)),
-// G[16][2] = C A^i.
-// geometry constants kSvfTpWaves / kSvfTpLc / kSvfTpTableDoubles: host_design.hpp (shared with the table builder)
+// Time-parallel SVF cascade (svf_kernels.hip): whole 8192-sample spans on k_svf_cascade_tpv<8> (one workgroup per channel, or
+// chained spans, below), what is left from 1024 samples up as one span of 1 ... 7 waves x 1024 samples whose tail may be
+// padding, the rest (and calls below 1024 samples) on k_svf_cascade_short.  nSamples: any number.
+// tables: kSvfTpTableDoubles doubles per (stream, band): for each chunk length LC in kSvfTpLc ({16, 8}): Mk[6][4] = A^(LC 2^k),
+// Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)), G[16][2] = C A^i; then the chunk's end-state map e[2][16] = A^(15-k) B.
+// geometry constants kSvfTpLc / kSvfTpTableDoubles: host_design.hpp (shared with the table builder)
 // chain / chainSpans / chainGrid: chained spans for engines with fewer channels than the chip holds workgroups of the span
 // kernel (chainGrid = 2 per CU): the (span, channel) pairs of a call are dealt to chainGrid workgroups, a band's state is
 // handed from span to span through `chain` (svf_chain_bytes(channels, largest call) bytes, zero-initialised once,

@@ -215,10 +215,8 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
 // Result differs from the sequential recurrence by rounding only (measured <= 3e-15 abs over 20 bands).
 
 constexpr double kTpInputBound = 1.0e9;
-constexpr int kTpWaves = kSvfTpWaves;        // waves per channel
-constexpr int kTpChunks = 64 * kTpWaves;     // chunks (= threads) per span
-constexpr int kTpLcMain = kSvfTpLc[0];       // samples per chunk, main spans (4096 samples)
-constexpr int kTpLcTail = kSvfTpLc[1];       // samples per chunk, 512-sample remainder spans
+constexpr int kTpChunks = 256;               // (default thread count of tp_scan)
+constexpr int kTpLcMain = kSvfTpLc[0];       // samples per chunk of the span kernels
 constexpr int kTpStride = kTpLcMain + 2;     // LDS row stride in doubles: rows 16-byte aligned for b128 access, 36 dwords
                                              // apart so that 16 consecutive rows cover all 64 banks
 
@@ -235,7 +233,7 @@ struct TpMfmaTables {
     double ht[32];
     double e[2][16];
 };
-struct TpBandTables { TpLcTables t[2]; TpMfmaTables mm; };
+struct TpBandTables { TpLcTables t[kSvfTpLcCount]; TpMfmaTables mm; };
 
 // num / den for the fastTanh Pade: den in [27, 209.25], |num| <= 212.7, so the range scaling and special-case
 // fix-up of the generic fp64 division (v_div_scale / v_div_fmas / v_div_fixup, which serialise on VCC) are
@@ -396,13 +394,6 @@ __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic
     if (CAP) { *c1 = (capAt == N - 1) ? ic1 : *c1; *c2 = (capAt == N - 1) ? ic2 : *c2; }
 }
 
-// per-workgroup LDS copy of the channel's per-band constants (one chunk length at a time)
-struct alignas(16) TpLds {
-    double cf[kBands][6];        // a1 a2 a3 m0 m1 m2
-    double M[kBands][28];        // Mk[6][4], Mw[4]
-    double G[kBands][32];        // G[16][2]
-};
-
 // cross-lane move of a double through the DPP network (2 x v_mov_b32_dpp, no LDS traffic); lanes whose source is
 // outside the row / wave, and rows disabled by ROWMASK, receive +0.0
 template <int CTRL, int ROWMASK>
@@ -461,6 +452,8 @@ struct TpvLink {
 };
 
 // lanes 0 ... 3 of the calling wave read one granule each until all four carry this launch's epoch
+// (requesting the granules a band ahead of the poll was measured: 30 spilled registers in the chained kernel, 1.53 against
+// 1.50 ms at 64 streams -- not kept)
 __device__ __forceinline__ void tpv_poll_state(const unsigned long long* g, unsigned epoch, int lane, double& sx, double& sy, unsigned* error)
 {
     unsigned long long v = 0;
@@ -612,152 +605,6 @@ __device__ void tp_band_guarded(double* buf, int lc, const double* cf, double sa
     sState[1] = ic2;
 }
 
-// U samples of a chunk row <-> registers; rows are 16-byte aligned (kTpStride even), so pairs move as one b128 access
-template <int U>
-__device__ __forceinline__ void tp_row_load(double (&v)[U], const double* p)
-{
-    if (U % 2 == 0) {
-#pragma unroll
-        for (int j = 0; j < U; j += 2) { const double2 t = *reinterpret_cast<const double2*>(p + j); v[j] = t.x; v[j + (U > 1)] = t.y; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < U; ++j) v[j] = p[j];
-    }
-}
-template <int U>
-__device__ __forceinline__ void tp_row_store(const double (&v)[U], double* p)
-{
-    if (U % 2 == 0) {
-#pragma unroll
-        for (int j = 0; j < U; j += 2) *reinterpret_cast<double2*>(p + j) = make_double2(v[j], v[j + (U > 1)]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < U; ++j) p[j] = v[j];
-    }
-}
-
-// One span (kTpChunks chunks of LC samples) through all active bands.  Every thread owns one chunk = one LDS
-// row, so between bands no barrier is needed for the sample data; per band the only exchange is the 4 wave
-// totals of the state scan.  The output stage of band b and the zero-state run of the next active band are
-// fused over the same registers (the next band consumes what the output stage just produced).
-template <int LC, bool SAT>
-__device__ __forceinline__ void tp_span(const double* in, double* out, double* buf, double* wtot, double*& sState,
-                                        double*& sNext, int* sFlag, const TpLds* L, int tid, const int* __restrict__ fl,
-                                        const TpBandTables* __restrict__ tb, double sat, double gain, int nValid = LC * kTpChunks)
-{
-    // nValid < LC * kTpChunks (a multiple of LC): the span's tail is padding -- read as silence, not written, and the
-    // span's end state is the one behind sample nValid - 1
-    constexpr int LCI = (LC == kTpLcMain) ? 0 : 1;
-    constexpr int U = (LC < 8) ? LC : 8;
-    const double oneMinusSat = 1.0 - sat;
-    const bool smallOk = (sat >= 0.0) && (sat <= 1.0);      // |out| <= |y| on the small-signal output stage
-    const double smallC1 = 9.0 - 8.0 * sat;
-    // span -> LDS, coalesced; sample j of the span sits at row j / LC, column j % LC
-    bool bad = false;
-#pragma unroll 4
-    for (int it = 0; it < LC; ++it) {
-        const int j = it * kTpChunks + tid;
-        const double x = (j < nValid) ? in[j] : 0.0;
-        bad |= !(fabs(x) < kTpInputBound);
-        buf[(j / LC) * kTpStride + (j % LC)] = x;
-    }
-    if (tid < kBands * 2) bad |= !(fabs(sState[tid]) < kTpInputBound);
-    if (tid == 0) *sFlag = 0;
-    __syncthreads();
-    if (__any(bad) && (tid & 63) == 0) atomicOr(sFlag, 1);
-    __syncthreads();
-    const bool unsafe = (*sFlag != 0);
-
-    if (unsafe) {
-        for (int b = 0; b < kBands; ++b) {
-            const int flag = fl[b];
-            if (!(flag & 1)) continue;
-            if (tid == 0) {
-                if (flag & 4)      tp_band_guarded<2>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid);
-                else if (flag & 2) tp_band_guarded<1>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid);
-                else               tp_band_guarded<0>(buf, LC, L->cf[b], sat, sState + 2 * b, nValid);
-            }
-            __syncthreads();
-        }
-    } else {
-        double* row = buf + tid * kTpStride;
-        int par = 0;
-        int b = 0;
-        while (b < kBands && !(fl[b] & 1)) ++b;              // first active band (uniform)
-        if (b < kBands) {
-            // zero-state run of the first active band on the raw input
-            double ic1 = 0.0, ic2 = 0.0;
-            {
-                const double a1 = L->cf[b][0], a2 = L->cf[b][1], a3 = L->cf[b][2];
-                const double m0 = L->cf[b][3], m1 = L->cf[b][4], m2 = L->cf[b][5];
-                const int kind = (fl[b] >> 1) & 3;      // 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
-#pragma unroll 1
-                for (int i0 = 0; i0 < LC; i0 += U) {
-                    double v[U];
-                    tp_row_load<U>(v, row + i0);
-                    if (kind == 2)      tp_recur<2, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                    else if (kind == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                    else                tp_recur<0, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                    tp_row_store<U>(v, row + i0);
-                }
-            }
-            while (b < kBands) {
-                int nb = b + 1;
-                while (nb < kBands && !(fl[nb] & 1)) ++nb;     // next active band (uniform)
-                double s0x, s0y;
-                tp_scan(ic1, ic2, s0x, s0y, &L->M[0][0], b, tp_load_powers(&tb[b].t[LCI].P[0][0], tid & 63),
-                        wtot + par * 2 * kTpWaves, sState, sNext, tid, nullptr, nValid / LC - 1);
-                par ^= 1;
-                // response table row of band b through a VGPR base: reads below are base + immediate offset
-                uint32_t gOff = (uint32_t)b * (uint32_t)sizeof(L->G[0]);
-                asm volatile("" : "+v"(gOff));
-                const double* Gb = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&L->G[0][0]) + gOff);
-                const int kindB = (fl[b] >> 1) & 3;
-                const bool hasNext = nb < kBands;
-                const int kindN = hasNext ? ((fl[nb] >> 1) & 3) : 0;
-                double a1 = 0, a2 = 0, a3 = 0, m0 = 1, m1 = 0, m2 = 0;
-                if (hasNext) {
-                    a1 = L->cf[nb][0]; a2 = L->cf[nb][1]; a3 = L->cf[nb][2];
-                    m0 = L->cf[nb][3]; m1 = L->cf[nb][4]; m2 = L->cf[nb][5];
-                }
-                ic1 = 0.0; ic2 = 0.0;
-#pragma unroll 1
-                for (int i0 = 0; i0 < LC; i0 += U) {
-                    double v[U];
-                    tp_row_load<U>(v, row + i0);
-#pragma unroll
-                    for (int j = 0; j < U; ++j)
-                        v[j] = fma(Gb[2 * (i0 + j) + 1], s0y, fma(Gb[2 * (i0 + j)], s0x, v[j]));
-                    if (kindB != 2) {     // kindB == 2 (OutputFilter biquad): linear section, no output stage
-                        double big = fabs(v[0]);
-#pragma unroll
-                        for (int j = 1; j < U; ++j) big = fmax(big, fabs(v[j]));
-                        if (smallOk && __all(big < 4.5)) {          // wave-uniform: the usual case at audio levels
-                            if (SAT) tp_nonlinear_small<U>(v, smallC1);
-                        } else if (kindB == 1) tp_nonlinear<true, SAT, U, false>(v, sat, oneMinusSat);
-                        else                   tp_nonlinear<false, SAT, U, false>(v, sat, oneMinusSat);
-                    }
-                    if (hasNext) {
-                        if (kindN == 2)      tp_recur<2, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                        else if (kindN == 1) tp_recur<1, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                        else                 tp_recur<0, U>(v, ic1, ic2, a1, a2, a3, m0, m1, m2);
-                    }
-                    tp_row_store<U>(v, row + i0);
-                }
-                b = nb;
-            }
-        }
-        __syncthreads();
-        { double* t = sState; sState = sNext; sNext = t; }      // the span's end states become the next span's start states
-    }
-#pragma unroll 4
-    for (int it = 0; it < LC; ++it) {
-        const int j = it * kTpChunks + tid;
-        if (j < nValid) out[j] = buf[(j / LC) * kTpStride + (j % LC)] * gain;
-    }
-    __syncthreads();
-}
-
 // LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this keeps the compiler
 // from moving them across each other
 __device__ __forceinline__ void wave_lds_sync()
@@ -765,60 +612,6 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ void tp_load_tables(TpLds* L, const double* __restrict__ cf,
-                                               const TpBandTables* __restrict__ tb, int lci, int tid)
-{
-    for (int i = tid; i < kBands * 6; i += kTpChunks) L->cf[i / 6][i % 6] = cf[i];
-    for (int i = tid; i < kBands * 28; i += kTpChunks) {
-        const int b = i / 28, q = i % 28;
-        L->M[b][q] = (q < 24) ? tb[b].t[lci].Mk[q / 4][q % 4] : tb[b].t[lci].Mw[q - 24];
-    }
-    for (int i = tid; i < kBands * 32; i += kTpChunks) L->G[i / 32][i % 32] = tb[i / 32].t[lci].G[(i % 32) / 2][i % 2];
-    __syncthreads();
-}
-
-// Spans of 512 samples (256 chunks of 2) in VALU form: the last block of a call with an odd block count, and calls of
-// one block.
-__global__ __launch_bounds__(kTpChunks) void k_svf_cascade_tp(const double* in, double* out, int64_t chStride,
-                                                              int nSamples, const double* __restrict__ coef,
-                                                              const int* __restrict__ flags,
-                                                              const double* __restrict__ satGain,
-                                                              double* __restrict__ state,
-                                                              const TpBandTables* __restrict__ tables)
-{
-    __shared__ double buf[kTpChunks * kTpStride];
-    __shared__ TpLds L;
-    __shared__ double sStateA[kBands * 2], sStateB[kBands * 2];     // start / end states of the current span (swapped per span)
-    __shared__ __align__(16) double wtot[2 * 2 * kTpWaves];         // wave totals, two parities
-    double* sState = sStateA;
-    double* sNext = sStateB;
-    __shared__ int sFlag;
-    const int tid = threadIdx.x;
-    const int c = blockIdx.x;
-    const double* cf = coef + (int64_t)c * kBands * 6;
-    const int* fl = flags + c * kBands;
-    const TpBandTables* tb = tables + (int64_t)(c >> 1) * kBands;     // tables are per stream
-    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
-    if (tid < kBands * 2) { sStateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sStateB[tid] = sStateA[tid]; }
-
-    const double* src = in + (int64_t)c * chStride;
-    double* dst = out + (int64_t)c * chStride;
-    tp_load_tables(&L, cf, tb, 1, tid);
-    for (int done = 0; nSamples - done >= kTpChunks * kTpLcTail; done += kTpChunks * kTpLcTail) {
-        if (sat > 0.0) tp_span<kTpLcTail, true>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
-        else           tp_span<kTpLcTail, false>(src + done, dst + done, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain);
-    }
-    // what is left of the call (480- and 441-sample callbacks, ragged calls): one more span, its tail padding
-    const int doneAll = nSamples / (kTpChunks * kTpLcTail) * (kTpChunks * kTpLcTail);
-    const int rest = (nSamples - doneAll) / kTpLcTail * kTpLcTail;
-    if (rest > 0) {
-        if (sat > 0.0) tp_span<kTpLcTail, true>(src + doneAll, dst + doneAll, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain, rest);
-        else           tp_span<kTpLcTail, false>(src + doneAll, dst + doneAll, buf, wtot, sState, sNext, &sFlag, &L, tid, fl, tb, sat, gain, rest);
-    }
-    __syncthreads();
-    if (tid < kBands * 2) state[(int64_t)c * kBands * 2 + tid] = sState[tid];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1362,6 +1155,270 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_s
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Spans below 1024 samples: one 512- / 480- / 441-sample callback per call -- the reference's own call pattern
+// (src/convolver/ConvolverProcessor.Runtime.cpp:659-682) -- and what a ragged call leaves.  A launch of this size is nothing but
+// the latency of 20 dependent bands, so the kernel is built for latency: ONE wave per channel up to 512 samples (two up to 1023)
+// with the lane's chunk of 8 samples in registers, vector form as above (scan of the E x sums, then one pass from the true start
+// state), no barrier and no cross-wave chain on one wave, no occupancy target (the whole register file is the wave's), every
+// per-band constant in LDS or requested a band ahead.  Any sample count: the tail of the last chunk is padding, the band
+// states are taken behind the last valid sample inside the pass.
+template <int LC>
+struct ShortShared {
+    alignas(16) double M[kBands][28];
+    alignas(16) double E[kBands][LC][2];
+    alignas(16) double cf[kBands][6];
+    alignas(16) double stateA[kBands * 2];
+    alignas(16) double stateB[kBands * 2];
+    alignas(16) double wtot[2 * 2 * 4];
+    alignas(16) double buf[(1024 / 16) * kTpStride];      // guarded path: the span as [chunk of 16][sample]
+    int flag;
+};
+
+// A band's constants in registers: the scan's matrix powers, the band's coefficients, the NEXT active band's E rows.  One
+// batch of LDS reads per band, issued a band ahead of its use: with one wave per SIMD nothing else hides an LDS round trip
+// (~130 cycles), and read where they are used the ~40 reads of a band were most of its time (SQ_WAIT_ANY 53 %).
+template <int LC>
+struct ShortConsts { double2 m[14]; double2 cf[3]; double2 e[LC]; double2 s0; };      // s0: the band's state at the start of the span
+template <int LC>
+__device__ __forceinline__ ShortConsts<LC> short_load_consts(const ShortShared<LC>& sh, int b, int nb)
+{
+    ShortConsts<LC> k;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) k.m[i] = *reinterpret_cast<const double2*>(&sh.M[b][2 * i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) k.cf[i] = *reinterpret_cast<const double2*>(&sh.cf[b][2 * i]);
+#pragma unroll
+    for (int i = 0; i < LC; ++i) k.e[i] = *reinterpret_cast<const double2*>(&sh.E[nb][i][0]);
+    k.s0 = *reinterpret_cast<const double2*>(&sh.stateA[2 * b]);
+    return k;
+}
+
+// tp_scan for one to four waves with the matrix powers in registers (k.m: Mk[6][4], Mw[4] as 14 pairs)
+template <int LC>
+__device__ __forceinline__ void short_scan(double ic1, double ic2, double& s0x, double& s0y, const ShortConsts<LC>& k, const TpLanePowers& pw,
+                                           double* wtot, double* sNext, int b, int tid, int nWaves, int endTid)
+{
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double sx = ic1, sy = ic2;
+#define CPQ_ROW_STEP(K)                                                                                       \
+    {                                                                                                         \
+        const double2 k01 = k.m[2 * (K)], k23 = k.m[2 * (K) + 1];                                             \
+        const double px = dpp_f64<kDppRowShr + (1 << (K)), 0xF>(sx);                                          \
+        const double py = dpp_f64<kDppRowShr + (1 << (K)), 0xF>(sy);                                          \
+        const double nx = fma(k01.y, py, fma(k01.x, px, sx));                                                 \
+        const double ny = fma(k23.y, py, fma(k23.x, px, sy));                                                 \
+        sx = nx;                                                                                              \
+        sy = ny;                                                                                              \
+    }
+    CPQ_ROW_STEP(0)
+    CPQ_ROW_STEP(1)
+    CPQ_ROW_STEP(2)
+    CPQ_ROW_STEP(3)
+#undef CPQ_ROW_STEP
+    {   // rows 1 and 3 <- total of the row below
+        const double px = dpp_f64<kDppRowBcast15, 0xA>(sx);
+        const double py = dpp_f64<kDppRowBcast15, 0xA>(sy);
+        const double nx = fma(pw.pa01.y, py, fma(pw.pa01.x, px, sx));
+        const double ny = fma(pw.pa23.y, py, fma(pw.pa23.x, px, sy));
+        sx = nx;
+        sy = ny;
+    }
+    {   // rows 2 and 3 <- total of the lower half
+        const double px = dpp_f64<kDppRowBcast31, 0xC>(sx);
+        const double py = dpp_f64<kDppRowBcast31, 0xC>(sy);
+        const double nx = fma(pw.pb01.y, py, fma(pw.pb01.x, px, sx));
+        const double ny = fma(pw.pb23.y, py, fma(pw.pb23.x, px, sy));
+        sx = nx;
+        sy = ny;
+    }
+    double bx = k.s0.x, by = k.s0.y;          // the span's start state
+    if (nWaves > 1) {
+        if (lane == 63) { wtot[2 * wave] = sx; wtot[2 * wave + 1] = sy; }
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) {          // (wave-uniform)
+            const double tx = wtot[2 * w], ty = wtot[2 * w + 1];
+            const double nx = fma(k.m[12].y, by, fma(k.m[12].x, bx, tx));
+            const double ny = fma(k.m[13].y, by, fma(k.m[13].x, bx, ty));
+            bx = nx;
+            by = ny;
+        }
+    }
+    sx = fma(pw.pc01.y, by, fma(pw.pc01.x, bx, sx));
+    sy = fma(pw.pc23.y, by, fma(pw.pc23.x, bx, sy));
+    s0x = dpp_f64<kDppWaveShr1, 0xF>(sx);
+    s0y = dpp_f64<kDppWaveShr1, 0xF>(sy);
+    if (lane == 0) { s0x = bx; s0y = by; }
+    if (tid == endTid) { sNext[2 * b] = sx; sNext[2 * b + 1] = sy; }
+}
+
+template <int CLS, bool SAT, int LC>
+__device__ __forceinline__ void short_pass(double (&x)[LC], double ic1, double ic2, const ShortConsts<LC>& k, bool mono,
+                                           double& e0, double& e1, double sat, int capAt, double& c1, double& c2)
+{
+    const double a1 = k.cf[0].x, a2 = k.cf[0].y, a3 = k.cf[1].x, m0 = k.cf[1].y, m1 = k.cf[2].x, m2 = k.cf[2].y;
+    if (CLS == 3) tp_recur<3, LC, true>(x, ic1, ic2, 2.0 * a2, 2.0 * a3, 0.0, a2, m1, a1, capAt, &c1, &c2);
+    else          tp_recur<CLS, LC, true>(x, ic1, ic2, a1, a2, a3, m0, m1, m2, capAt, &c1, &c2);
+    if (CLS != 2) {           // class 2: linear section (OutputFilter), no output stage
+        int small = 1;
+#pragma unroll
+        for (int j = 0; j < LC; ++j) small &= (int)(fabs(x[j]) < 4.5);
+        if (sat >= 0.0 && sat <= 1.0 && __all(small)) {
+            if (SAT) {
+                const double c1s = 9.0 - 8.0 * sat;
+#pragma unroll
+                for (int h = 0; h < LC / 2; ++h) {
+                    double v[2] = { x[2 * h], x[2 * h + 1] };
+                    tp_nonlinear_small<2, 2>(v, c1s);
+                    x[2 * h] = v[0];
+                    x[2 * h + 1] = v[1];
+                }
+            }
+        } else {
+            const double oneMinusSat = 1.0 - sat;
+#pragma unroll
+            for (int h = 0; h < LC / 4; ++h) {
+                double v[4] = { x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3] };
+                if (mono) tp_nonlinear<true, SAT, 4, false>(v, sat, oneMinusSat);
+                else      tp_nonlinear<false, SAT, 4, false>(v, sat, oneMinusSat);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[4 * h + j] = v[j];
+            }
+        }
+    }
+    double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LC; ++j) {
+        f0 = fma(k.e[j].x, x[j], f0);
+        f1 = fma(k.e[j].y, x[j], f1);
+    }
+    e0 = f0;
+    e1 = f1;
+}
+
+template <int LC>
+__global__ __launch_bounds__(256, 1) void k_svf_cascade_short(const double* in, double* out, int64_t chStride, int n,
+                                                             const double* __restrict__ coef, const int* __restrict__ flags,
+                                                             const double* __restrict__ satGain, double* __restrict__ state,
+                                                             const TpBandTables* __restrict__ tables)
+{
+    constexpr int LI = 1;                          // table block of the chunk length (host_design.hpp: kSvfTpLc)
+    static_assert(kSvfTpLc[LI] == LC, "chunk length without a table block");
+    __shared__ ShortShared<LC> sh;
+    const int tid = threadIdx.x, nThreads = blockDim.x, lane = tid & 63;
+    const int c = blockIdx.x;
+    const double* __restrict__ cfg = coef + (int64_t)c * kBands * 6;
+    const TpBandTables* __restrict__ tb = tables + (int64_t)(c >> 1) * kBands;
+    const double sat = satGain[c * 2], gain = satGain[c * 2 + 1];
+    const double* src = in + (int64_t)c * chStride;
+    double* dst = out + (int64_t)c * chStride;
+    // the lane's chunk first (the longest latency), the tables behind it
+    double x[LC];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < LC; ++j) {
+        const int i = tid * LC + j;
+        x[j] = (i < n) ? src[i] : 0.0;
+    }
+    for (int i = tid; i < kBands * 28; i += nThreads) {
+        const int b = i / 28, q = i % 28;
+        sh.M[b][q] = (q < 24) ? tb[b].t[LI].Mk[q / 4][q % 4] : tb[b].t[LI].Mw[q - 24];
+    }
+    for (int i = tid; i < kBands * LC * 2; i += nThreads) {
+        const int b = i / (LC * 2), k = (i % (LC * 2)) >> 1, r = i & 1;
+        sh.E[b][k][r] = tb[b].mm.e[r][16 - LC + k];          // A^(LC - 1 - k) B: the last LC columns of the 16-sample map
+    }
+    for (int i = tid; i < kBands * 6; i += nThreads) sh.cf[i / 6][i % 6] = cfg[i];
+    if (tid < kBands * 2) { sh.stateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sh.stateB[tid] = sh.stateA[tid]; }
+    if (tid == 0) sh.flag = 0;
+    unsigned active = 0, dfMask = 0, monoMask = 0;
+    for (int b = 0; b < kBands; ++b) {
+        const int f = flags[c * kBands + b];
+        active |= (unsigned)(f & 1) << b;
+        dfMask |= (unsigned)(((f >> 1) & 3) == 2) << b;
+        monoMask |= (unsigned)(((f >> 1) & 3) == 1) << b;
+    }
+    active = __builtin_amdgcn_readfirstlane(active);
+    dfMask = __builtin_amdgcn_readfirstlane(dfMask);
+    monoMask = __builtin_amdgcn_readfirstlane(monoMask);
+#pragma unroll
+    for (int j = 0; j < LC; ++j) bad |= !(fabs(x[j]) < kTpInputBound);
+    __syncthreads();
+    if (tid < kBands * 2) bad |= !(fabs(sh.stateA[tid]) < kTpInputBound);
+    if (__any(bad) && lane == 0) atomicOr(&sh.flag, 1);
+    __syncthreads();
+    if (sh.flag != 0) {
+        // cold: input or a start state outside the range the host proved guard-free -- the reference recurrence with every guard
+        for (int j = tid; j < n; j += nThreads) sh.buf[(j >> 4) * kTpStride + (j & 15)] = src[j];
+        __syncthreads();
+        if (tid == 0) {
+            for (unsigned m = active; m; m &= m - 1) {
+                const int b = __builtin_ctz(m);
+                if ((dfMask >> b) & 1)        tp_band_guarded<2>(sh.buf, 16, sh.cf[b], sat, sh.stateA + 2 * b, n);
+                else if ((monoMask >> b) & 1) tp_band_guarded<1>(sh.buf, 16, sh.cf[b], sat, sh.stateA + 2 * b, n);
+                else                          tp_band_guarded<0>(sh.buf, 16, sh.cf[b], sat, sh.stateA + 2 * b, n);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += nThreads) dst[j] = sh.buf[(j >> 4) * kTpStride + (j & 15)] * gain;
+        if (tid < kBands * 2 && ((active >> (tid >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tid] = sh.stateA[tid];
+        return;
+    }
+    if (active) {
+        const int endTid = (n - 1) / LC, capAt = (n - 1) % LC;
+        double e0 = 0.0, e1 = 0.0;
+        {
+            const double* E = &sh.E[__builtin_ctz(active)][0][0];
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {
+                const double2 ee = *reinterpret_cast<const double2*>(E + 2 * j);
+                e0 = fma(ee.x, x[j], e0);
+                e1 = fma(ee.y, x[j], e1);
+            }
+        }
+        int par = 0;
+        const int nWaves = nThreads >> 6;
+        const int first = __builtin_ctz(active);
+        const unsigned rest0 = active & (active - 1);
+        TpLanePowers pw = tp_load_powers(&tb[first].t[LI].P[0][0], lane);
+        ShortConsts<LC> kc = short_load_consts<LC>(sh, first, rest0 ? __builtin_ctz(rest0) : first);
+#pragma unroll 1
+        for (unsigned m = active; m; m &= m - 1) {
+            const int b = __builtin_ctz(m);
+            const unsigned rest = m & (m - 1);
+            const int nb = rest ? __builtin_ctz(rest) : b;
+            const unsigned rest2 = rest & (rest - 1);
+            // the next band's constants and per-lane powers, requested now (used a band from here)
+            const TpLanePowers pwNext = tp_load_powers(&tb[nb].t[LI].P[0][0], lane);
+            const ShortConsts<LC> kn = short_load_consts<LC>(sh, nb, rest2 ? __builtin_ctz(rest2) : nb);
+            double s0x, s0y;
+            short_scan(e0, e1, s0x, s0y, kc, pw, sh.wtot + par * 2 * 4, sh.stateB, b, tid, nWaves, endTid);
+            par ^= 1;
+            const bool peak = !((dfMask >> b) & 1) && kc.cf[1].y == 1.0 && kc.cf[2].y == 0.0;
+            const bool mono = (monoMask >> b) & 1;
+            const int cap = (tid == endTid) ? capAt : -1;
+            double c1 = 0.0, c2 = 0.0;
+            if ((dfMask >> b) & 1)   short_pass<2, false, LC>(x, s0x, s0y, kc, mono, e0, e1, sat, cap, c1, c2);
+            else if (sat > 0.0) { if (peak) short_pass<3, true, LC>(x, s0x, s0y, kc, mono, e0, e1, sat, cap, c1, c2);
+                                  else      short_pass<0, true, LC>(x, s0x, s0y, kc, mono, e0, e1, sat, cap, c1, c2); }
+            else                { if (peak) short_pass<3, false, LC>(x, s0x, s0y, kc, mono, e0, e1, sat, cap, c1, c2);
+                                  else      short_pass<0, false, LC>(x, s0x, s0y, kc, mono, e0, e1, sat, cap, c1, c2); }
+            pw = pwNext;
+            kc = kn;
+            // the band's end state: behind the last valid sample (the scan left there the state behind the chunk's padding)
+            if (tid == endTid) { sh.stateB[2 * b] = c1; sh.stateB[2 * b + 1] = c2; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LC; ++j) {
+        const int i = tid * LC + j;
+        if (i < n) dst[i] = x[j] * gain;
+    }
+    __syncthreads();
+    if (tid < kBands * 2 && ((active >> (tid >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tid] = sh.stateB[tid];
+}
 }  // namespace
 
 void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
@@ -1426,12 +1483,12 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
                                coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands, cnt);
         done += cnt;
     }
-    const int even = (nSamples - done) & ~1;
-    if (even > 0) {
-        hipLaunchKernelGGL(k_svf_cascade_tp, dim3(nCh), dim3(kTpChunks), 0, stream, in + done, out + done, chStride, even, coef, flags, satGain, state, tb);
-        done += even;
+    if (nSamples > done) {
+        // (a chunk of 4 samples on two to four waves measured the same 0.034 ms per 512-sample callback as this chunk of 8 on
+        // one or two: profiles/r04f_eq_short_calls.txt)
+        const int cnt = nSamples - done;
+        hipLaunchKernelGGL(k_svf_cascade_short<8>, dim3(nCh), dim3(((cnt + 511) / 512) * 64), 0, stream, in + done, out + done, chStride, cnt,
+                           coef, flags, satGain, state, tb);
     }
-    if (nSamples > done)
-        launch_svf_cascade(stream, in + done, out + done, chStride, nCh, nSamples - done, coef, flags, satGain, state, false);
 }
 }  // namespace cpq
