@@ -173,3 +173,48 @@ def test_two_engines_on_two_host_threads_share_the_device(amd, oracle):
         assert launches == calls and gave_up == 0
         assert both[i] is not None and np.array_equal(both[i], alone[i])
         engines[i][0].close()
+
+
+def test_chained_spans_output_filter_and_whole_chain(amd, oracle):
+    """The OutputFilter's three DF-II-T sections (src/OutputFilter.cpp:143-165) run on the same cascade kernels: calls of
+    five spans + a ragged remainder on 2 streams chain their spans too (band classes: linear sections only); then conv -> EQ ->
+    output filter in one call (DSPCore order), EQ and filter both chained, against the oracle's chain."""
+    O = oracle
+    S, T = 2, 85                     # 43520 samples = 5 spans + 2560
+    n = T * B
+    x = _inputs(O, S, 3 * n)
+    q = O.outfilter_design(0, 1, 0, 1, 48000.0)
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    y = np.concatenate([eng.outfilter_process(x[:, o:o + n]) for o in range(0, 3 * n, n)], axis=1)
+    launches, gave_up = eng.eq_chain_status()
+    assert launches == 3 and gave_up == 0
+    err2 = 0.0
+    for s in range(S):
+        yl, yr, _ = O.outfilter_process_stereo(x[2 * s], x[2 * s + 1], q)
+        err2 += np.sum((y[2 * s] - yl) ** 2) + np.sum((y[2 * s + 1] - yr) ** 2)
+    assert np.sqrt(err2 / y.size) <= 1e-12          # (its 20 Hz high-pass: any fp64 evaluation order is ~2e-13 from exact)
+    eng.close()
+
+    L = 6000
+    irs = [O.gen_ir(L, stream=c // 2, channel=c % 2) for c in range(2 * S)]
+    po = O.eq_params_bench(0.2)
+    eng = amd.BatchedEngine(S, max_ir_len=L, max_blocks_per_call=T)
+    for s in range(S):
+        eng.set_impulse(s, irs[2 * s], irs[2 * s + 1])
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    eng.set_outfilter_params(amd.CPQ_ALL_STREAMS, 0, 1, 0, 1)
+    eng.enable_output_filter(True)
+    y = np.concatenate([eng.process(x[:, o:o + n]) for o in range(0, 2 * n, n)], axis=1)
+    launches, gave_up = eng.eq_chain_status()
+    assert launches == 4 and gave_up == 0           # two calls x (EQ + output filter)
+    for s in range(S):
+        w = []
+        for ch in range(2):
+            nuc = O.Nuc()
+            nuc.set_impulse(irs[2 * s + ch], B)
+            w.append(nuc.run(x[2 * s + ch, :2 * n], B))
+        el, er, _ = O.eq_process_stereo(w[0], w[1], po)
+        fl, fr, _ = O.outfilter_process_stereo(el, er, q)
+        assert np.sqrt(np.mean((y[2 * s] - fl) ** 2)) <= 1e-12 and np.sqrt(np.mean((y[2 * s + 1] - fr) ** 2)) <= 1e-12
+    eng.close()
