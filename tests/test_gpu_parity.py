@@ -2092,3 +2092,30 @@ def test_processor_level_dry_only_with_unequal_ramps_fails_before_any_state_move
 
     a, b = run(True), run(False)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("blk", [300, 441, 512, 1000])
+def test_eq_short_spans_guarded_path_and_state_hand_over(amd, oracle, blk):
+    """Calls below 1024 samples run on k_svf_cascade_short (one wave up to 512 samples, two above; the last chunk of 8 partly
+    padding at 300 / 441 / 1000).  Twelve one-callback calls: the band states pass from call to call through the state array; a
+    NaN, an Inf and a 1e12 sample send three of the calls through the kernel's guarded recurrence (bit-faithful), the call
+    behind the 1e12 sample starts from out-of-range states (guarded by its states, not its input)."""
+    O = oracle
+    S, calls = 2, 12
+    x = make_inputs(O, S, calls * blk)
+    x[0, 2 * blk + 17] = np.nan
+    x[3, 5 * blk + blk - 1] = np.inf
+    x[1, 8 * blk + blk - 3] = 1.0e12
+    po = O.eq_params_bench(0.2)
+    po.bands[2].channelMode = 1
+    po.bands[11].type = 4
+    eng = amd.BatchedEngine(S, block_size=blk, max_ir_len=512, max_blocks_per_call=1, call_mode=amd.CPQ_CALLS_ANY)
+    eng.set_eq_params(amd.CPQ_ALL_STREAMS, _copy_params(po, amd.eq_params_default()))
+    y = np.concatenate([eng.eq_process(x[:, k * blk:(k + 1) * blk]) for k in range(calls)], axis=1)
+    assert np.all(np.isfinite(y))
+    for s in range(S):
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], po, block=blk)
+        d = np.maximum(np.abs(y[2 * s] - yl), np.abs(y[2 * s + 1] - yr))
+        big = 8 * blk + blk - 3            # behind the 1e12 sample the states decay from 1e11 through fast-path rounding
+        assert d[:big].max() <= 1e-12 and d.max() <= (1e-4 if s == 0 else 1e-12), (s, d[:big].max(), d.max())
+    eng.close()
