@@ -71,7 +71,8 @@ struct PlanGroup {
     std::vector<size_t> tabOffs;
     std::vector<int> nbOf;
     long long callW0 = 0, callR0 = 0;           // layer 0's write / read positions before the call in flight was replayed
-    bool tabOnDevice = false;                   // the call's tables went out with its gather launch (kernel arguments)
+    bool tabOnDevice = false;                   // the call's tables went out with its first launch (kernel arguments)
+    bool tailsDone = false;                     // the call's tail layers ran ahead of layer 0, whose transform adds their blocks
     long long samplesSinceReset = 0;
     int lastGot = 0, lastCall = 0;              // Get()'s return value summed over the chunks of the last call
 };

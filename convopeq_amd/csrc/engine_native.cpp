@@ -592,14 +592,19 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
         double* dst[3];
         int64_t stride[3], off[3];
         int nl = 0, li = 0;
+        auto straight = [&](const NativeLayer& t) { return rowsAreCallRows && t.fill == 0 && n % t.P == 0 && n / t.P <= t.nbMax; };
+        // layer 0 at 512 samples, transformed straight from the input, is held back: its launch can carry the other layers'
+        // accumulation and the call's tables (one launch instead of two and a copy)
+        const bool hold0 = straight(g.layers[0]) && g.layers[0].P == cpq::kP;
         for (NativeLayer& t : g.layers) {
             if (li++ == 3) break;
             t.fftAhead = 0;
-            if (rowsAreCallRows && t.fill == 0 && n % t.P == 0 && n / t.P <= t.nbMax) {
+            if (straight(t)) {
+                t.fftAhead = n / t.P;
+                if (hold0 && &t == &g.layers[0]) continue;
                 ProfScope p(e, CPQ_K_RFFT_FWD);
                 cpq::launch_rfft_fwd_ols(e->stream, dIn, (int64_t)n, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN,
                                          cpq::FftTables{ t.tw, t.tw2, t.twCol, t.twSplit }, t.P, g.usedCh, n / t.P, t.head, t.ringSlots, t.scratch);
-                t.fftAhead = n / t.P;
                 continue;
             }
             dst[nl] = t.acc[t.accSel];
@@ -607,9 +612,24 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
             off[nl] = t.fill;
             ++nl;
         }
-        if (nl > 0) {
+        const bool ride = (int)g.tabHost.size() <= cpq::kGatherTabMax && g.usedCh > 0 && n > 0;
+        bool gathered = nl == 0;
+        if (hold0) {
+            NativeLayer& t = g.layers[0];
+            ProfScope p(e, CPQ_K_RFFT_FWD);
+            if (cpq::rfft_fwd_can_carry_side(t.P, nl, off, ride ? (int)g.tabHost.size() : 0)) {
+                cpq::launch_rfft_fwd_ols_side(e->stream, dIn, (int64_t)n, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN,
+                                              cpq::FftTables{ t.tw, t.tw2, t.twCol, t.twSplit }, g.usedCh, n / t.P, t.head, t.ringSlots, nl, dst,
+                                              stride, off, ride ? g.tabDev : nullptr, g.tabHost.data(), ride ? (int)g.tabHost.size() : 0);
+                gathered = true;
+                g.tabOnDevice = ride;
+            } else {
+                cpq::launch_rfft_fwd_ols(e->stream, dIn, (int64_t)n, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN,
+                                         cpq::FftTables{ t.tw, t.tw2, t.twCol, t.twSplit }, t.P, g.usedCh, n / t.P, t.head, t.ringSlots, t.scratch);
+            }
+        }
+        if (!gathered) {
             ProfScope p(e, CPQ_K_MIX);
-            const bool ride = (int)g.tabHost.size() <= cpq::kGatherTabMax && g.usedCh > 0 && n > 0;
             cpq::launch_rows_gather_multi(e->stream, dIn, n, g.chMapDev, nl, dst, stride, off, n, g.usedCh,
                                           ride ? g.tabDev : nullptr, g.tabHost.data(), ride ? (int)g.tabHost.size() : 0);
             g.tabOnDevice = ride;
@@ -623,8 +643,10 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
 // IFFT; NUC.cpp:1245-1336 / :1456-1544) and stored in the layer's output ring / delay line
 // directOut != nullptr (layer 0 only): the inverse transform writes the members' output rows themselves and the output ring is
 // passed by -- the caller has checked that this call's Get() reads exactly what this call's blocks produce
+// addTails (with directOut, layer 0 at 512 samples): the transform also adds the delay-line blocks of the tail layers, which
+// the caller has run ahead of layer 0 (groupsRunLayer0)
 static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, const long long* putPos, long long ringPos0,
-                          double* directOut = nullptr)
+                          double* directOut = nullptr, bool addTails = false)
 {
     const int total = t.fill + n;
     const int nb = total / t.P;
@@ -652,7 +674,13 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
             // the output ring is passed by -- read and write positions advanced together on the host), otherwise into the
             // layer's output ring / delay line at the replayed positions, written by the transform itself
             ProfScope p(e, CPQ_K_RFFT_INV);
-            if (directOut) cpq::launch_rfft_inv_ols(e->stream, t.Y, directOut, (int64_t)n, tw, t.P, nCh, nb, t.scratch);
+            if (directOut && addTails) {
+                NativeLayer& a = g.layers[1];
+                NativeLayer* b = g.layers.size() == 3 ? &g.layers[2] : nullptr;
+                cpq::launch_rfft_inv_ols_add(e->stream, t.Y, directOut, (int64_t)n, tw, nCh, nb, a.ring, a.outRing, g.tabDev + g.tabOffs[2], a.gain,
+                                             b ? b->ring : nullptr, b ? b->outRing : 2, b ? g.tabDev + g.tabOffs[4] : nullptr, b ? b->gain : 0.0);
+            }
+            else if (directOut) cpq::launch_rfft_inv_ols(e->stream, t.Y, directOut, (int64_t)n, tw, t.P, nCh, nb, t.scratch);
             else           cpq::launch_rfft_inv_ols_ring(e->stream, t.Y, t.ring, t.outRing, putPos, ringPos0, tw, t.P, nCh, nb, t.scratch);
         }
         ProfScope p(e, CPQ_K_MIX);
@@ -685,7 +713,19 @@ int groupsRunLayer0(cpq_engine* e, double* dOut, int n)
                 direct = g.tabHost[g.tabOffs[0] + c] == w0 + (long long)c * e->B && g.tabHost[g.tabOffs[1] + c] == want;
             }
         }
-        { const int rc = runLayerBlocks(e, g, g.layers[0], n, nullptr, w0, direct ? dOut : nullptr); if (rc != CPQ_OK) return rc; }
+        // Layer 0's transform can add the tail layers' delay-line blocks as it stores the output rows (no read-modify-write pass
+        // over the output behind it) when every 512-sample block is one chunk of the call and nothing sits between layer 0 and
+        // the tails in Get() (no direct head): the tail layers then run FIRST.  Same additions in the same order: bit-identical.
+        g.tailsDone = false;
+        const bool addTails = direct && g.layers.size() >= 2 && g.layers.size() <= 3 && g.layers[0].P == cpq::kP && e->B == cpq::kP && !e->anyDirect;
+        if (addTails) {
+            for (size_t l = 1; l < g.layers.size(); ++l) {
+                const int rc = runLayerBlocks(e, g, g.layers[l], n, g.tabDev + g.tabOffs[2 * l + 1], 0);
+                if (rc != CPQ_OK) return rc;
+            }
+            g.tailsDone = true;
+        }
+        { const int rc = runLayerBlocks(e, g, g.layers[0], n, nullptr, w0, direct ? dOut : nullptr, addTails); if (rc != CPQ_OK) return rc; }
         if (!direct) {
             ProfScope p(e, CPQ_K_MIX);
             cpq::launch_ring_get_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, g.layers[0].ring, g.layers[0].outRing,
@@ -706,6 +746,7 @@ int groupsRunTails(cpq_engine* e, double* dOut, int n)
     for (PlanGroup* gp : e->groups) {
         PlanGroup& g = *gp;
         if (g.frozen && e->honourFrozen) continue;      // only the processor-level call rests a stream (ConvolverProcessor does not call its NUC then); a NUC-level call runs every stream
+        if (g.tailsDone) { g.tailsDone = false; continue; }     // (ran ahead of layer 0, whose transform added their blocks: groupsRunLayer0)
         for (size_t l = 1; l < g.layers.size(); ++l) {
             const int rc = runLayerBlocks(e, g, g.layers[l], n, g.tabDev + g.tabOffs[2 * l + 1], 0);
             if (rc != CPQ_OK) return rc;

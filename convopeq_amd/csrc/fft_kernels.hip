@@ -176,11 +176,16 @@ __device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, 
     }
 }
 
+// side: a plan group's call on its first launch -- the block also goes into the input accumulators of the group's other layers
+// (Add()'s per-layer accumulation, src/MKLNonUniformConvolver.cpp:1431-1446: what k_rows_gather_multi would do in a launch of
+// its own) and the call's chunk tables, riding along as kernel arguments, are stored for the kernels behind this one.
+struct FwdSide { double* dst[2]; long long stride[2], off[2]; int n; long long* tabDst; int nTab; long long tab[kGatherTabMax]; };
+template <bool SIDE>
 __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ in, int64_t chStride,
                                                      const double* __restrict__ histOld,
                                                      double* __restrict__ histNew, double2* __restrict__ X,
                                                      double2* __restrict__ XDN, FftTables tw, int T, int head,
-                                                     int ringMask)
+                                                     int ringMask, FwdSide side)
 {
     __shared__ double2 lds[kLdsPerWave];
     const int lane = threadIdx.x;
@@ -199,6 +204,14 @@ __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ 
         double* hn = histNew + (int64_t)c * kP;
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(hn + 2 * (lane + 64 * j)) = v[4 + j];
+    }
+    if (SIDE) {
+        if (blockIdx.x == 0 && lane < side.nTab) side.tabDst[lane] = side.tab[lane];
+        for (int a = 0; a < side.n; ++a) {          // (offsets even: 16-byte stores)
+            double* d = side.dst[a] + (int64_t)c * side.stride[a] + side.off[a] + (int64_t)t * kP;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(d + 2 * (lane + 64 * j)) = v[4 + j];
+        }
     }
     wave_cfft512<false>(v, lds, lane, wa, wb);
     const int slot = (head + t) & ringMask;
@@ -234,8 +247,12 @@ __global__ __launch_bounds__(64) void k_ir_spectra(const double* __restrict__ he
 //           mode, mix_kernels.hip: k_tail_schedule has filled sched for the call; the additions come from this call's
 //           natural-time tail outputs where the sample lies inside the call, from the layer's ring where it is older) --
 //           the read-modify-write pass over the call's output that k_layer_combine would make is gone.
+//   MODE 3: the output rows PLUS the delay-line read-add of a plan group's tail layers (Get(), :1620-1633: layer 1 first, then
+//           layer 2, `dst += src` or `dst += src * gain`) where every block is one chunk of the call: what k_ring_add_chunks[2]
+//           would do in a pass of its own over the output.
 struct OutSpec {
-    double* ring; int mask; const long long* pos; long long pos0;                                  // MODE 1
+    double* ring; int mask; const long long* pos; long long pos0;                                  // MODE 1; MODE 3: ring A, its mask, its schedule
+    const double* ringB; int maskB; const long long* schedB;                                      // MODE 3: ring B (or null)
     const double* layerOut; const double* tailRing; const long long* tailState; const long long* sched;      // MODE 2
     int nCb, B, log2B, tailMask, nTail, nChAll, nSamples; double g1, g2;
 };
@@ -263,6 +280,25 @@ __device__ __forceinline__ void store_block2(double* out, int64_t chStride, cons
         const int n0 = t * P + i;
         v.x = tail(n0, v.x);
         v.y = tail(n0 + 1, v.y);
+        *reinterpret_cast<double2*>(out + (int64_t)c * chStride + (int64_t)t * P + i) = v;
+        return;
+    }
+    if (MODE == 3) {
+        const long long sa = ro.pos[t], sb = ro.ringB ? ro.schedB[t] : -1;
+        if (sa >= 0) {
+            const double* ra = ro.ring + (int64_t)c * (ro.mask + 1);
+            const double a0 = ra[(sa + i) & ro.mask], a1 = ra[(sa + i + 1) & ro.mask];
+            const bool unity = fabs(ro.g1 - 1.0) < 1.0e-12;
+            v.x = unity ? (v.x + a0) : (v.x + a0 * ro.g1);
+            v.y = unity ? (v.y + a1) : (v.y + a1 * ro.g1);
+        }
+        if (sb >= 0) {
+            const double* rb = ro.ringB + (int64_t)c * (ro.maskB + 1);
+            const double b0 = rb[(sb + i) & ro.maskB], b1 = rb[(sb + i + 1) & ro.maskB];
+            const bool unity = fabs(ro.g2 - 1.0) < 1.0e-12;
+            v.x = unity ? (v.x + b0) : (v.x + b0 * ro.g2);
+            v.y = unity ? (v.y + b1) : (v.y + b1 * ro.g2);
+        }
         *reinterpret_cast<double2*>(out + (int64_t)c * chStride + (int64_t)t * P + i) = v;
         return;
     }
@@ -1137,8 +1173,8 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
         return;
     }
     if (P == kP)
-        hipLaunchKernelGGL(k_rfft_fwd_ols, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
-                           tw, T, head, ringSlots - 1);
+        hipLaunchKernelGGL(k_rfft_fwd_ols<false>, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN,
+                           tw, T, head, ringSlots - 1, FwdSide{});
     else if (P == kP4) {
         const int split = p4Split(nCh, T);
         allowLargeLds(k_rfft_fwd_ols_p4, wgLdsBytes(P));
@@ -1151,6 +1187,25 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
     } else
         hipLaunchKernelGGL(k_rfft_fwd_ols_generic, dim3(nCh * T), dim3(genericThreads(P)), 2 * P * sizeof(double2),
                            stream, in, chStride, histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
+}
+
+bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* off, int nTab)
+{
+    if (P != kP || nSide < 0 || nSide > 2 || nTab < 0 || nTab > kGatherTabMax || nTab > 64) return false;
+    for (int a = 0; a < nSide; ++a) if (off[a] & 1) return false;
+    return true;
+}
+
+void launch_rfft_fwd_ols_side(hipStream_t stream, const double* in, int64_t chStride, const double* histOld, double* histNew, double2* X,
+                              double2* XDN, FftTables tw, int nCh, int T, int head, int ringSlots, int nSide, double* const* dst,
+                              const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab)
+{
+    FwdSide s{};
+    s.n = nSide;
+    for (int a = 0; a < nSide; ++a) { s.dst[a] = dst[a]; s.stride[a] = dstStride[a]; s.off[a] = dstOff[a]; }
+    if (tabDst && tab && nTab > 0) { s.tabDst = tabDst; s.nTab = nTab; for (int i = 0; i < nTab; ++i) s.tab[i] = tab[i]; }
+    hipLaunchKernelGGL(k_rfft_fwd_ols<true>, dim3(nCh * T), dim3(64), 0, stream, in, chStride, histOld, histNew, X, XDN, tw, T, head,
+                       ringSlots - 1, s);
 }
 
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN, FftTables tw,
@@ -1216,6 +1271,16 @@ void launch_rfft_inv_ols(hipStream_t stream, const double2* Y, double* out, int6
                          int nCh, int T, double2* scratch)
 {
     launch_inv<0>(stream, Y, out, chStride, tw, P, nCh, T, scratch, OutSpec{});
+}
+
+void launch_rfft_inv_ols_add(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int nCh, int T,
+                             const double* ringA, int ringSizeA, const long long* schedA, double gainA,
+                             const double* ringB, int ringSizeB, const long long* schedB, double gainB)
+{
+    OutSpec os{};
+    os.ring = const_cast<double*>(ringA); os.mask = ringSizeA - 1; os.pos = schedA; os.g1 = gainA;
+    os.ringB = ringB; os.maskB = ringSizeB - 1; os.schedB = schedB; os.g2 = gainB;
+    hipLaunchKernelGGL(k_rfft_inv_ols<3>, dim3(nCh * T), dim3(64), 0, stream, Y, out, chStride, tw, T, os);
 }
 
 void launch_rfft_inv_ols_ring(hipStream_t stream, const double2* Y, double* ring, int ringSize, const long long* pos,

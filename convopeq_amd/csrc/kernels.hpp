@@ -32,6 +32,19 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
                          double* histNew, double2* X, double2* XDN, FftTables tw, int P, int nCh, int T,
                          int head, int ringSlots, double2* scratch = nullptr);
 
+// P = 512 only (rfft_fwd_can_carry_side): the same launch also copies every block into up to two other accumulators
+// (dst[a] + channel * dstStride[a] + dstOff[a], offsets even) and stores a table of <= kGatherTabMax entries to tabDst -- a plan
+// group's input accumulation and chunk tables on the call's first launch instead of a k_rows_gather_multi launch of their own.
+bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* dstOff, int nTab);
+void launch_rfft_fwd_ols_side(hipStream_t stream, const double* in, int64_t chStride, const double* histOld, double* histNew, double2* X,
+                              double2* XDN, FftTables tw, int nCh, int T, int head, int ringSlots, int nSide, double* const* dst,
+                              const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab);
+// P = 512 inverse transform that also adds the delay-line blocks of up to two tail layers to the rows it stores: block t reads
+// ring X at schedX[t] (negative: nothing to add), out = out + ring (gain within 1e-12 of 1) or out + ring * gain, A before B
+void launch_rfft_inv_ols_add(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int nCh, int T,
+                             const double* ringA, int ringSizeA, const long long* schedA, double gainA,
+                             const double* ringB, int ringSizeB, const long long* schedB, double gainB);
+
 // IR partition spectra: frames [h[k*P .. (k+1)*P) | 0] for k < nParts.
 void launch_ir_spectra(hipStream_t stream, const double* heff, int heffLen, double2* H, double2* HDN,
                        FftTables tw, int P, int nParts, double2* scratch = nullptr);
