@@ -379,11 +379,14 @@ def mac_launch_bytes(n_ch, ir_rows_mult, pl, kl, nb):
     return (n_ch * (kl + nb - 1) + ir_rows_mult * kl + n_ch * nb) * pl * 16
 
 
-def algorithmic_bytes_per_step(n_ch, n, ir_rows_mult, fft_layers, mac_layers, layered_tail=None, native_tails=0):
+def algorithmic_bytes_per_step(n_ch, n, ir_rows_mult, fft_layers, mac_layers, layered_tail=None, native_tails=0, native_fused=False):
     """HBM bytes one call (step) of n samples needs per kernel family if every row / sample is moved once.
     fft_layers / mac_layers: launch_plan() lists (they differ in layered mode: one transform grid, one MAC per layer).
     layered_tail: (n_tail, [min(n, output_delay + 2 P) per tail layer]) in layered mode; native_tails: tail layers of a plan
-    group (their delay-line read-add passes over the call's output)."""
+    group (their delay-line read-add passes over the call's output); native_fused: whole 512-sample-block calls of a plan
+    group -- layer 0's forward transform also writes the input into the accumulators of the layers whose partition has not
+    filled (8 B per sample each), its inverse transform also reads the tail layers' delay lines (8 B per sample each), and no
+    pass over the output is left."""
     b = {
         "k_rfft_fwd_ols": sum(lps * n_ch * nb * (pl * 8 + pl * 16) for pl, _, nb, lps in fft_layers),
         "k_fdl_mac": sum(lps * mac_launch_bytes(n_ch, ir_rows_mult, pl, kl, nb) for pl, kl, nb, lps in mac_layers),
@@ -399,6 +402,9 @@ def algorithmic_bytes_per_step(n_ch, n, ir_rows_mult, fft_layers, mac_layers, la
         # only what later calls may still read is appended to the rings
         b["k_rfft_inv_ols"] += n_ch * n * 8 * n_tail
         b["k_convproc_mix"] = n_ch * 16 * sum(spans)
+    elif native_tails > 0 and native_fused:
+        b["k_rfft_inv_ols"] += n_ch * n * 8 * native_tails
+        b["k_rfft_fwd_ols"] += n_ch * n * 8 * sum(1 for pl, _, _, _ in fft_layers[1:] if pl > n)
     elif native_tails > 0:
         # the delay-line read-add of the tail layers over the call's output (read + write once, 8 B per sample and tail layer
         # from the rings; the ring writes are inside the inverse transforms)
@@ -707,7 +713,8 @@ def main():
         alg_bytes = algorithmic_bytes_per_step(
             n_ch, n, ir_mult, layers, mac_layers,
             layered_tail=(n_tail, [min(n, plan.output_delay[l] + 2 * plan.part_size[l]) for l in range(1, plan.num_layers)]) if layered else None,
-            native_tails=0 if layered else max(0, len(layers) - 1))
+            native_tails=0 if layered else max(0, len(layers) - 1),
+            native_fused=(args.schedule == "nuc" and args.call_mode == "blocks" and B == 512 and not layered))
         # fp64 operations per step (FMA = 2): the cooperative MAC kernel (>= 48 rows per call) spends 3 real FMAs per complex
         # MAC (Gauss), the tile kernels 4; SVF: svf_flop_model()
         mac_flop = lambda nb: 6.0 if nb >= 48 else 8.0
@@ -725,6 +732,8 @@ def main():
             per_kernel[name] = {"launches": cnt, "avg_launch_ms": round(avg_s * 1e3, 4),
                                 "algorithmic_bytes_per_launch": per_launch,
                                 "achieved_gbs": round(alg_bytes[name] / step_s / 1e9, 1)}
+            if alg_bytes[name] == 0:      # small bookkeeping launches only (no pass over the samples): no bandwidth figure
+                per_kernel[name]["achieved_gbs"] = None
             if name in alg_flops:
                 per_kernel[name]["fp64_tflops"] = round(alg_flops[name] / step_s / 1e12, 2)
             if name == "k_svf_cascade_tp":
@@ -743,7 +752,9 @@ def main():
         hbm_regime = None
         if prof1 and prof1.get("k_fdl_mac", (0, 0.0))[0] > 0:
             cnt1, ms1 = prof1["k_fdl_mac"]
-            b1 = (n_ch * k_parts + ir_rows + n_ch) * spec_bytes
+            lp1 = launch_plan(P, [(P, (plan.len[l] + P - 1) // P) for l in range(plan.num_layers)] if layered else [(P, k_parts)])
+            # (40 calls of one partition each: bytes of one call / MAC launches per call)
+            b1 = int(algorithmic_bytes_per_step(n_ch, P, ir_mult, lp1, lp1)["k_fdl_mac"] * 40 / cnt1)
             gbs1 = b1 / (ms1 / cnt1 * 1e-3) / 1e9
             tr1, src1 = load_pmc_traffic(pmc_path, "k_fdl_mac:tile", running)
             hbm_regime = {"kernel": "k_fdl_mac", "blocks_per_call": P // B, "algorithmic_bytes_per_launch": b1,

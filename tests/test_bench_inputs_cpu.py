@@ -71,3 +71,21 @@ def test_fraction_check_flags_accounting_errors():
     assert sp.check_fractions(ok) == []
     bad = {"roofline": {"frac": 3.68}, "kernels": {"k_fdl_mac": {"achieved_gbs": 29451.7}}}
     assert len(sp.check_fractions(bad)) == 2
+
+
+def test_bench_bytes_of_the_fused_native_path():
+    """Whole 512-sample-block calls of a plan group: layer 0's forward transform also fills the accumulators of the layers whose
+    partition has not filled, its inverse transform also reads the tail layers' delay lines -- no pass over the output is left
+    (profiles/r04z_sweep_configs.jsonl line 16 charged the removed pass: 18 x the HBM peak)."""
+    b = _bench()
+    n_ch = 128
+    lp = b.launch_plan(524288, [(512, 12), (4096, 64), (32768, 8)])
+    fused = b.algorithmic_bytes_per_step(n_ch, 524288, n_ch, lp, lp, native_tails=2, native_fused=True)
+    plain = b.algorithmic_bytes_per_step(n_ch, 524288, n_ch, lp, lp, native_tails=2)
+    assert fused["k_convproc_mix"] == 0 and plain["k_convproc_mix"] == n_ch * 524288 * 32
+    assert fused["k_rfft_inv_ols"] - plain["k_rfft_inv_ols"] == n_ch * 524288 * 16
+    assert fused["k_rfft_fwd_ols"] == plain["k_rfft_fwd_ols"]                 # every layer's partition fills: nothing to accumulate
+    lp1 = b.launch_plan(512, [(512, 12), (4096, 31)])
+    f1 = b.algorithmic_bytes_per_step(512, 512, 512, lp1, lp1, native_tails=1, native_fused=True)
+    p1 = b.algorithmic_bytes_per_step(512, 512, 512, lp1, lp1, native_tails=1)
+    assert f1["k_rfft_fwd_ols"] - p1["k_rfft_fwd_ols"] == 512 * 512 * 8       # the block into layer 1's accumulator

@@ -72,7 +72,7 @@ def check_fractions(line, where=""):
              "roofline.hbm_regime.frac": (r.get("hbm_regime") or {}).get("frac"),
              "roofline.frac_of_pmc_traffic": r.get("frac_of_pmc_traffic")}
     for k, v in (line.get("kernels") or {}).items():
-        if "achieved_gbs" in v:
+        if v.get("achieved_gbs") is not None:
             cands[f"kernels.{k}.achieved_gbs/8000"] = v["achieved_gbs"] / 8000.0
     return [(where + k, v) for k, v in cands.items() if v is not None and v > 1.0]
 
