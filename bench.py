@@ -828,7 +828,7 @@ def main():
                 "streams_per_gpu": S, "ir_taps": L, "block": B, "blocks_per_call": T,
                 "schedule": (f"uniform overlap-save, FFT partition P={P}, K={k_parts} partitions of "
                              f"{'h' if args.exact else 'h_eff (reference NUC semantics at blk 512)'}, "
-                             f"{T} blocks ({n} samples) per call = {Tp} partitions per FDL pass") if args.schedule == "uniform"
+                             f"{T} blocks ({n} samples) per call = {Tp} partitions per FDL pass") if (args.schedule == "uniform" and args.call_mode == "blocks")
                             else ("non-uniform (the reference's own layer plan run natively): " +
                                   " + ".join(f"{kl} x {pl}" for pl, kl, _, _ in layers) + f" partitions, {T} blocks per call"),
                 "partition": P,
