@@ -617,7 +617,7 @@ int groupsAppend(cpq_engine* e, const double* dIn, int n)
         if (hold0) {
             NativeLayer& t = g.layers[0];
             ProfScope p(e, CPQ_K_RFFT_FWD);
-            if (cpq::rfft_fwd_can_carry_side(t.P, nl, off, ride ? (int)g.tabHost.size() : 0)) {
+            if (cpq::rfft_fwd_can_carry_side(t.P, nl, stride, off, ride ? (int)g.tabHost.size() : 0)) {
                 cpq::launch_rfft_fwd_ols_side(e->stream, dIn, (int64_t)n, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN,
                                               cpq::FftTables{ t.tw, t.tw2, t.twCol, t.twSplit }, g.usedCh, n / t.P, t.head, t.ringSlots, nl, dst,
                                               stride, off, ride ? g.tabDev : nullptr, g.tabHost.data(), ride ? (int)g.tabHost.size() : 0);

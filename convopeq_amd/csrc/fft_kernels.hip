@@ -1189,10 +1189,10 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
                            stream, in, chStride, histOld, histNew, X, XDN, tw, P, T, head, ringSlots - 1);
 }
 
-bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* off, int nTab)
+bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* stride, const int64_t* off, int nTab)
 {
     if (P != kP || nSide < 0 || nSide > 2 || nTab < 0 || nTab > kGatherTabMax || nTab > 64) return false;
-    for (int a = 0; a < nSide; ++a) if (off[a] & 1) return false;
+    for (int a = 0; a < nSide; ++a) if ((off[a] | stride[a]) & 1) return false;      // 16-byte stores into every channel's row
     return true;
 }
 

@@ -35,7 +35,7 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
 // P = 512 only (rfft_fwd_can_carry_side): the same launch also copies every block into up to two other accumulators
 // (dst[a] + channel * dstStride[a] + dstOff[a], offsets even) and stores a table of <= kGatherTabMax entries to tabDst -- a plan
 // group's input accumulation and chunk tables on the call's first launch instead of a k_rows_gather_multi launch of their own.
-bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* dstOff, int nTab);
+bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* dstStride, const int64_t* dstOff, int nTab);
 void launch_rfft_fwd_ols_side(hipStream_t stream, const double* in, int64_t chStride, const double* histOld, double* histNew, double2* X,
                               double2* XDN, FftTables tw, int nCh, int T, int head, int ringSlots, int nSide, double* const* dst,
                               const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab);
