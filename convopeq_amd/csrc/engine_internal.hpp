@@ -73,6 +73,7 @@ struct PlanGroup {
     long long callW0 = 0, callR0 = 0;           // layer 0's write / read positions before the call in flight was replayed
     bool tabOnDevice = false;                   // the call's tables went out with its first launch (kernel arguments)
     bool tailsDone = false;                     // the call's tail layers ran ahead of layer 0, whose transform adds their blocks
+    bool getDeferred = false;                   // layer 0's chunk-wise ring read waits for the tails' read-add: one pass does both
     long long samplesSinceReset = 0;
     int lastGot = 0, lastCall = 0;              // Get()'s return value summed over the chunks of the last call
 };

@@ -726,7 +726,10 @@ int groupsRunLayer0(cpq_engine* e, double* dOut, int n)
             g.tailsDone = true;
         }
         { const int rc = runLayerBlocks(e, g, g.layers[0], n, nullptr, w0, direct ? dOut : nullptr, addTails); if (rc != CPQ_OK) return rc; }
-        if (!direct) {
+        // Get() reads layer 0's ring chunk by chunk and then adds the tail layers' delay-line blocks: with nothing in between (no
+        // direct head) the read waits for groupsRunTails, whose pass over the output does both
+        g.getDeferred = !direct && !e->anyDirect && g.layers.size() >= 2 && g.layers.size() <= 3;
+        if (!direct && !g.getDeferred) {
             ProfScope p(e, CPQ_K_MIX);
             cpq::launch_ring_get_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, g.layers[0].ring, g.layers[0].outRing,
                                         g.tabDev + g.tabOffs[0], g.tabDev + g.tabOffs[1], g.usedCh);
@@ -752,6 +755,16 @@ int groupsRunTails(cpq_engine* e, double* dOut, int n)
             if (rc != CPQ_OK) return rc;
         }
         ProfScope p(e, CPQ_K_MIX);
+        if (g.getDeferred) {
+            g.getDeferred = false;
+            NativeLayer& z = g.layers[0];
+            NativeLayer& a = g.layers[1];
+            NativeLayer* b = g.layers.size() == 3 ? &g.layers[2] : nullptr;
+            cpq::launch_ring_get_add_chunks(e->stream, dOut, n, g.chMapDev, n, e->B, z.ring, z.outRing, g.tabDev + g.tabOffs[0], g.tabDev + g.tabOffs[1],
+                                            a.ring, a.outRing, g.tabDev + g.tabOffs[2], a.gain,
+                                            b ? b->ring : nullptr, b ? b->outRing : 2, b ? g.tabDev + g.tabOffs[4] : nullptr, b ? b->gain : 0.0, g.usedCh);
+            continue;
+        }
         if (g.layers.size() == 3) {          // both delay lines in one pass over the output (layer 1 first, as Get() adds them)
             NativeLayer& a = g.layers[1];
             NativeLayer& b = g.layers[2];

@@ -163,6 +163,11 @@ void launch_ring_add_chunks2(hipStream_t stream, double* out, int64_t outStride,
                              const double* ringB, int ringSizeB, const long long* schedB, double gainB, int nCh);
 void launch_ring_put_blocks(hipStream_t stream, const double* z, int64_t zStride, int P, int nb, double* ring, int ringSize,
                             const long long* pos, int nCh);
+// launch_ring_get_chunks and launch_ring_add_chunks[2] in one pass over the output (ringB may be null)
+void launch_ring_get_add_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                                const double* ring0, int ringSize0, const long long* pos, const long long* cnt,
+                                const double* ringA, int ringSizeA, const long long* schedA, double gainA,
+                                const double* ringB, int ringSizeB, const long long* schedB, double gainB, int nCh);
 void launch_ring_get_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
                             const double* ring, int ringSize, const long long* pos, const long long* cnt, int nCh);
 void launch_ring_add_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,

@@ -361,6 +361,34 @@ __global__ __launch_bounds__(256) void k_ring_get_chunks(double* __restrict__ ou
     }
 }
 
+// Get() of a whole call in ONE pass over the members' output rows: the chunk-wise read of layer 0's ring with its zero-fill
+// (k_ring_get_chunks) and behind it the delay-line read-add of one or two tail layers (k_ring_add_chunks[2]); ringB may be null
+__global__ __launch_bounds__(256) void k_ring_get_add_chunks(double* __restrict__ out, int64_t outStride,
+                                                             const int* __restrict__ chMap, int n, int q,
+                                                             const double* __restrict__ ring0, int mask0,
+                                                             const long long* __restrict__ pos, const long long* __restrict__ cnt,
+                                                             const double* __restrict__ ringA, int maskA,
+                                                             const long long* __restrict__ schedA, double gainA,
+                                                             const double* __restrict__ ringB, int maskB,
+                                                             const long long* __restrict__ schedB, double gainB)
+{
+    const int g = chMap[blockIdx.y];
+    if (g < 0) return;
+    double* o = out + (int64_t)g * outStride;
+    const double* r0 = ring0 + (int64_t)blockIdx.y * (mask0 + 1);
+    const double* ra = ringA + (int64_t)blockIdx.y * (maskA + 1);
+    const double* rb = ringB ? ringB + (int64_t)blockIdx.y * (maskB + 1) : nullptr;
+    const bool unityA = fabs(gainA - 1.0) < 1.0e-12, unityB = fabs(gainB - 1.0) < 1.0e-12;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cb = i / q, j = i - cb * q;
+        double v = (j < cnt[cb]) ? r0[(pos[cb] + j) & mask0] : 0.0;
+        const long long sa = schedA[cb], sb = rb ? schedB[cb] : -1;
+        if (sa >= 0) { const double a = ra[(sa + j) & maskA]; v = unityA ? (v + a) : (v + a * gainA); }
+        if (sb >= 0) { const double b = rb[(sb + j) & maskB]; v = unityB ? (v + b) : (v + b * gainB); }
+        o[i] = v;
+    }
+}
+
 // delayLineReadAdd per chunk (sched[cb] < 0: the writer is not far enough ahead, nothing is added)
 __global__ __launch_bounds__(256) void k_ring_add_chunks(double* __restrict__ out, int64_t outStride,
                                                          const int* __restrict__ chMap, int n, int q,
@@ -609,6 +637,16 @@ void launch_ring_add_chunks2(hipStream_t stream, double* out, int64_t outStride,
     if (n <= 0 || nCh <= 0) return;
     hipLaunchKernelGGL(k_ring_add_chunks2, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, chMap, n, q, ringA,
                        ringSizeA - 1, schedA, gainA, ringB, ringSizeB - 1, schedB, gainB);
+}
+
+void launch_ring_get_add_chunks(hipStream_t stream, double* out, int64_t outStride, const int* chMap, int n, int q,
+                                const double* ring0, int ringSize0, const long long* pos, const long long* cnt,
+                                const double* ringA, int ringSizeA, const long long* schedA, double gainA,
+                                const double* ringB, int ringSizeB, const long long* schedB, double gainB, int nCh)
+{
+    if (n <= 0 || nCh <= 0) return;
+    hipLaunchKernelGGL(k_ring_get_add_chunks, rowsGrid(n, nCh), dim3(256), 0, stream, out, outStride, chMap, n, q, ring0, ringSize0 - 1, pos, cnt,
+                       ringA, ringSizeA - 1, schedA, gainA, ringB, ringSizeB - 1, schedB, gainB);
 }
 
 void launch_ring_put_blocks(hipStream_t stream, const double* z, int64_t zStride, int P, int nb, double* ring, int ringSize,
