@@ -654,10 +654,17 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
     const int nCh = g.usedCh;
     if (nb > 0) {
         const cpq::FftTables tw{ t.tw, t.tw2, t.twCol, t.twSplit };
+        bool remMoved = false;
         if (t.fftAhead != nb) {        // (else: transformed straight from the call's input in groupsAppend)
             ProfScope p(e, CPQ_K_RFFT_FWD);
-            cpq::launch_rfft_fwd_ols(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN, tw,
-                                     t.P, nCh, nb, t.head, t.ringSlots, t.scratch);
+            if (t.P == cpq::kP) {      // the 512-sample transform also moves the accumulator's remainder (no copy launch behind it)
+                cpq::launch_rfft_fwd_ols_side(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN, tw, nCh, nb,
+                                              t.head, t.ringSlots, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, t.acc[t.accSel ^ 1], t.accCap, rem);
+                remMoved = true;
+            } else {
+                cpq::launch_rfft_fwd_ols(e->stream, t.acc[t.accSel], t.accCap, t.hist[t.histSel], t.hist[t.histSel ^ 1], t.X, t.XDN, tw,
+                                         t.P, nCh, nb, t.head, t.ringSlots, t.scratch);
+            }
         }
         t.fftAhead = 0;
         {
@@ -683,8 +690,10 @@ static int runLayerBlocks(cpq_engine* e, PlanGroup& g, NativeLayer& t, int n, co
             else if (directOut) cpq::launch_rfft_inv_ols(e->stream, t.Y, directOut, (int64_t)n, tw, t.P, nCh, nb, t.scratch);
             else           cpq::launch_rfft_inv_ols_ring(e->stream, t.Y, t.ring, t.outRing, putPos, ringPos0, tw, t.P, nCh, nb, t.scratch);
         }
-        ProfScope p(e, CPQ_K_MIX);
-        cpq::launch_rows_copy(e->stream, t.acc[t.accSel], t.accCap, (int64_t)nb * t.P, t.acc[t.accSel ^ 1], t.accCap, 0, rem, nCh);
+        if (!remMoved && rem > 0) {
+            ProfScope p(e, CPQ_K_MIX);
+            cpq::launch_rows_copy(e->stream, t.acc[t.accSel], t.accCap, (int64_t)nb * t.P, t.acc[t.accSel ^ 1], t.accCap, 0, rem, nCh);
+        }
         t.head = (t.head + nb) & (t.ringSlots - 1);
         t.histSel ^= 1;
         t.accSel ^= 1;

@@ -179,7 +179,13 @@ __device__ __forceinline__ void wave_split_store(double2 (&v)[8], double2* lds, 
 // side: a plan group's call on its first launch -- the block also goes into the input accumulators of the group's other layers
 // (Add()'s per-layer accumulation, src/MKLNonUniformConvolver.cpp:1431-1446: what k_rows_gather_multi would do in a launch of
 // its own) and the call's chunk tables, riding along as kernel arguments, are stored for the kernels behind this one.
-struct FwdSide { double* dst[2]; long long stride[2], off[2]; int n; long long* tabDst; int nTab; long long tab[kGatherTabMax]; };
+// tail*: the samples behind the last whole block of the source rows (a layer's input accumulator) go to the front of the other
+// accumulator buffer -- the remainder move that would be a k_rows_copy launch of its own.
+struct FwdSide {
+    double* dst[2]; long long stride[2], off[2]; int n;
+    long long* tabDst; int nTab; long long tab[kGatherTabMax];
+    double* tailDst; long long tailStride; int tailLen;
+};
 template <bool SIDE>
 __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ in, int64_t chStride,
                                                      const double* __restrict__ histOld,
@@ -207,6 +213,11 @@ __global__ __launch_bounds__(64) void k_rfft_fwd_ols(const double* __restrict__ 
     }
     if (SIDE) {
         if (blockIdx.x == 0 && lane < side.nTab) side.tabDst[lane] = side.tab[lane];
+        if (t == T - 1 && side.tailLen > 0) {
+            const double* ts = in + (int64_t)c * chStride + (int64_t)T * kP;
+            double* td = side.tailDst + (int64_t)c * side.tailStride;
+            for (int i = lane; i < side.tailLen; i += 64) td[i] = ts[i];
+        }
         for (int a = 0; a < side.n; ++a) {          // (offsets even: 16-byte stores)
             double* d = side.dst[a] + (int64_t)c * side.stride[a] + side.off[a] + (int64_t)t * kP;
 #pragma unroll
@@ -1198,9 +1209,11 @@ bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* stride, const int6
 
 void launch_rfft_fwd_ols_side(hipStream_t stream, const double* in, int64_t chStride, const double* histOld, double* histNew, double2* X,
                               double2* XDN, FftTables tw, int nCh, int T, int head, int ringSlots, int nSide, double* const* dst,
-                              const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab)
+                              const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab,
+                              double* tailDst, int64_t tailStride, int tailLen)
 {
     FwdSide s{};
+    s.tailDst = tailDst; s.tailStride = tailStride; s.tailLen = tailDst ? tailLen : 0;
     s.n = nSide;
     for (int a = 0; a < nSide; ++a) { s.dst[a] = dst[a]; s.stride[a] = dstStride[a]; s.off[a] = dstOff[a]; }
     if (tabDst && tab && nTab > 0) { s.tabDst = tabDst; s.nTab = nTab; for (int i = 0; i < nTab; ++i) s.tab[i] = tab[i]; }

@@ -38,7 +38,8 @@ void launch_rfft_fwd_ols(hipStream_t stream, const double* in, int64_t chStride,
 bool rfft_fwd_can_carry_side(int P, int nSide, const int64_t* dstStride, const int64_t* dstOff, int nTab);
 void launch_rfft_fwd_ols_side(hipStream_t stream, const double* in, int64_t chStride, const double* histOld, double* histNew, double2* X,
                               double2* XDN, FftTables tw, int nCh, int T, int head, int ringSlots, int nSide, double* const* dst,
-                              const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab);
+                              const int64_t* dstStride, const int64_t* dstOff, long long* tabDst, const long long* tab, int nTab,
+                              double* tailDst = nullptr, int64_t tailStride = 0, int tailLen = 0);      // tail*: the tailLen samples behind the T blocks of every source row -> tailDst rows
 // P = 512 inverse transform that also adds the delay-line blocks of up to two tail layers to the rows it stores: block t reads
 // ring X at schedX[t] (negative: nothing to add), out = out + ring (gain within 1e-12 of 1) or out + ring * gain, A before B
 void launch_rfft_inv_ols_add(hipStream_t stream, const double2* Y, double* out, int64_t chStride, FftTables tw, int nCh, int T,
