@@ -308,7 +308,7 @@ def load_pmc_traffic(path, kernel, running):
     # the profiler id k_fdl_mac covers the workgroup-cooperative variant of long calls (k_fdl_mac_wg in rocprof names)
     # and the register-tile variants of short ones (k_fdl_mac<TT, PF>, summarised as "k_fdl_mac")
     names = {"k_fdl_mac": ["k_fdl_mac_wg", "k_fdl_mac"], "k_fdl_mac:tile": ["k_fdl_mac"],
-             "k_svf_cascade_tp": ["k_svf_cascade_tpv", "k_svf_cascade_tp8", "k_svf_cascade_tp"]}.get(kernel, [kernel])
+             "k_svf_cascade_tp": ["k_svf_cascade_tpv", "k_svf_cascade_tp"]}.get(kernel, [kernel])
     for nme in names:
         if nme in d and isinstance(d[nme], dict):
             src["match"] = True

@@ -195,23 +195,23 @@ __global__ __launch_bounds__(64) void k_svf_cascade(const double* in, double* ou
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Time-parallel variant.
+// Time-parallel kernels.
 //
 // Inside one band the state update is LINEAR in (v0, ic1eq, ic2eq): the fastTanh blend, the +-100 clamp and
 // the output guard act on the band OUTPUT only and never feed back into the state (Processing.cpp:228-262).
-// So one band over a span of 64*W chunks of LC samples can be run as
-//   1. every lane runs the reference recurrence over its own chunk from ZERO state  -> y_zs, end state e
-//   2. chunk start states by a scan of S_c = M S_(c-1) + e_c, M = A^LC: 6 Kogge-Stone steps inside each wave,
-//      then the W wave totals are chained (W-1 2x2 products) and folded in with per-lane powers A^(LC (c+1));
-//      all matrix powers are precomputed on the host in extended precision
-//   3. y_lin[i] = y_zs[i] + (C A^i) . s0_chunk, then saturation blend / guard / clamp exactly as the reference.
-// Bands remain sequential (the nonlinearity sits between them); the span lives in LDS for all 20 bands, so
-// HBM sees one read and one write per sample.  One workgroup of W waves per channel: 64*W-way time
-// parallelism per band, W*channels waves in flight (2 per SIMD at 256 streams, W = 4).
+// So one band over a span of chunks of LC samples (one chunk per lane, held in registers) is run as
+//   1. the chunks' zero-state end states e_c = E x_c (two FMAs per sample, accumulated by the pass of the band before),
+//   2. chunk start states by a scan of S_c = M S_(c-1) + e_c, M = A^LC: DPP shift-and-combine steps inside each wave,
+//      then the wave totals are chained (2x2 products) and folded in with per-lane powers A^(LC (c+1));
+//      all matrix powers are precomputed on the host in extended precision,
+//   3. ONE pass of the reference recurrence over the chunk from its true start state, then saturation blend / guard / clamp.
+// Bands remain sequential (the nonlinearity sits between them); HBM sees one read and one write per sample.
+// k_svf_cascade_tpv: chunks of 16, eight waves per span of 8192 samples (or 1 ... 7 waves for what a call leaves);
+// k_svf_cascade_short: chunks of 8, one or two waves, spans below 1024 samples.
 //
 // The state guards of the reference (non-finite or >= 1e15 -> 0) cannot trip when the span input is finite and
 // below kTpInputBound and the incoming state is below it too (the host proves state gain * bound < 1e15 per
-// band before enabling this kernel); otherwise the span is run by the guarded sequential path below.
+// band before enabling these kernels); otherwise the span is run by the guarded sequential path.
 // Result differs from the sequential recurrence by rounding only (measured <= 3e-15 abs over 20 bands).
 
 constexpr double kTpInputBound = 1.0e9;
@@ -220,15 +220,15 @@ constexpr int kTpLcMain = kSvfTpLc[0];       // samples per chunk of the span ke
 constexpr int kTpStride = kTpLcMain + 2;     // LDS row stride in doubles: rows 16-byte aligned for b128 access, 36 dwords
                                              // apart so that 16 consecutive rows cover all 64 banks
 
-// per (stream, band); one block per chunk length (kTpLcMain, kTpLcTail); must match host buildSvfTpTables()
+// per (stream, band); one block per chunk length (host_design.hpp: kSvfTpLc = {16, 8}); must match host buildSvfTpTables()
 struct TpLcTables {
     double Mk[6][4];     // A^(LC*2^k), row-major 2x2: in-wave scan steps
     double Mw[4];        // A^(LC*64): one whole wave of chunks
     double P[64][4];     // A^(LC*(c+1)): carries the wave's start state to the end of chunk c
-    double G[16][2];     // C*A^i, i < LC
+    double G[16][2];     // C*A^i, i < LC (state-to-output response; not read by the kernels of this file any more)
 };
-// matrix form of one 16-sample chunk for the MFMA path: T[m][k] = ht[15 + m - k] (zero-state response, lower triangular
-// Toeplitz), e[:, k] = A^(15-k) B (end state of the chunk)
+// e[:, k] = A^(15-k) B: end state of a 16-sample chunk's zero-state run (its last LC columns serve a chunk of LC);
+// ht: the chunk's zero-state impulse response in matrix form (round 2's MFMA path, tools/variants/; not read here)
 struct TpMfmaTables {
     double ht[32];
     double e[2][16];
@@ -1468,9 +1468,9 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
     }
     // What is left behind the whole spans (and calls shorter than one).  From 1024 samples up: ONE span of up to seven waves x
     // 1024 samples on the same kernel, its tail padding where the count is not a multiple of 1024 (two launches for 7169 ... 8191
-    // samples).  Below 1024 samples the chain of 20 dependent bands is all a launch costs, and 256 chunks of two samples walk it
-    // faster than 32 chunks of sixteen (0.034 against 0.067 ms per 512-sample callback, profiles/r04f_eq_short_calls.txt):
-    // k_svf_cascade_tp over the even part (a last span padded), a last odd sample on the lane-skewed kernel.
+    // samples).  Below 1024 samples the chain of 20 dependent bands is all a launch costs, and 64 chunks of eight samples on one
+    // wave walk it faster than 32 chunks of sixteen (0.034 against 0.067 ms per 512-sample callback,
+    // profiles/r04f_eq_short_calls.txt): k_svf_cascade_short, any sample count in one launch.
     while (nSamples - done >= 1024) {
         int cnt = nSamples - done;
         if (cnt > 7 * 1024) cnt = 4 * 1024;

@@ -441,7 +441,7 @@ typedef enum {
     CPQ_K_DCNYQ    = 2,   /* k_fdl_mac_dcnyq */
     CPQ_K_RFFT_INV = 3,   /* k_rfft_inv_ols */
     CPQ_K_SVF      = 4,   /* k_svf_cascade (lane-skewed sequential recurrence) */
-    CPQ_K_SVF_TP   = 5,   /* k_svf_cascade_tp (time-parallel, default) */
+    CPQ_K_SVF_TP   = 5,   /* the time-parallel cascade kernels (k_svf_cascade_tpv / _short; default) */
     CPQ_K_MIX      = 6,   /* k_convproc_mix (processor-level dry/wet stage) */
     CPQ_K_OUTFILT  = 7,   /* output-filter biquad cascade (k_svf_cascade_tp / k_svf_cascade running DF-II-T sections) */
     CPQ_K_COUNT    = 8

@@ -1008,9 +1008,9 @@ def test_ragged_call_lengths_across_ring_wraps(amd, oracle, schedule):
 def test_eq_time_parallel_kernels_hand_over_state(amd, oracle, sat):
     """One call of 59 blocks = three 8192-sample spans on the eight-wave vector-form kernel (k_svf_cascade_tpv<8>; with 4
     channels they run as chained spans: three workgroups per channel, band states handed over inside the launch) + one span
-    of five waves x 1024 samples (k_svf_cascade_tpv<0>) + one 512-sample span (k_svf_cascade_tp, chunk length 2); band states
-    pass between the three kernels through the state array.  The second call carries an Inf in its third span, the third a
-    NaN in its second span (guarded path in staged pieces of 2048 samples)."""
+    of 5632 samples on six waves whose tail is padding (k_svf_cascade_tpv<0, false, PARTIAL>); band states pass between the
+    two kernels and from call to call through the state array.  The second call carries an Inf in its third span, the third
+    a NaN in its second span (guarded path in staged pieces of 2048 samples)."""
     O = oracle
     S, T = 2, 59
     x = make_inputs(O, S, 3 * T * B)
