@@ -372,9 +372,10 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->ofSatGain, nCh * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofState, nCh * kBands * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
-        // chained spans of the time-parallel cascade (svf_kernels.hip): header + the band states handed from span to span;
-        // only engines with fewer channels than the chip holds workgroups of that kernel (two per CU) use them
-        { (void**)&e->svfChain, chained ? (int64_t)cpq::svf_chain_bytes((int)nCh, e->maxCall) : 0 },
+        // scheduling words of the time-parallel cascade (svf_kernels.hip): header, the arrival counters of the CUs, and -- only
+        // for engines with fewer channels than the chip holds workgroups of that kernel (two per CU) -- the band states handed
+        // from span to span (chained spans)
+        { (void**)&e->svfChain, (int64_t)cpq::svf_chain_bytes((int)nCh, chained ? e->maxCall : 0) },
     };
     e->svfChainSpans = chained ? cpq::svf_chain_spans(e->maxCall) : 0;
     int64_t total = 0;

@@ -14,7 +14,7 @@ int enqueueCascade(cpq_engine* e, const double* dIn, double* dOut, int64_t strid
     if (nTp > 0) {
         ProfScope p(e, idTp);
         cpq::launch_svf_cascade_tp(e->stream, dIn, dOut, stride, e->nCh, nTp, coef, flags, satGain, state, tables,
-                                   e->svfChainSpans > 0 ? e->svfChain : nullptr, e->svfChainSpans, e->svfChainGrid);
+                                   e->svfChain, e->svfChainSpans, e->svfChainGrid);
     }
     if (n > nTp) {
         ProfScope p(e, idSeq);

@@ -147,7 +147,8 @@ struct cpq_engine {
     double* ofSatGain = nullptr;
     double* ofState = nullptr;  // [nCh][20][2]  w1 w2
     double* ofTp = nullptr;     // [streams][20][kSvfTpTableDoubles]
-    void* svfChain = nullptr;   // chained spans of the time-parallel cascade: header + [channels][svfChainSpans][20][4] granules, or none
+    void* svfChain = nullptr;   // scheduling words of the time-parallel cascade: header, arrival counters of the CUs, and (chained spans
+                                // only: svfChainSpans > 0) the [channels][svfChainSpans][20][4] hand-over granules
     int svfChainSpans = 0;
     int svfChainGrid = 0;       // workgroups of the span kernel the device holds at once (2 per CU)
     unsigned long long uploadSeq = 0;   // staged uploads so far (they are ordered on the engine's stream only)

@@ -95,7 +95,9 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 // chain / chainSpans / chainGrid: chained spans for engines with fewer channels than the chip holds workgroups of the span
 // kernel (chainGrid = 2 per CU): the (span, channel) pairs of a call are dealt to chainGrid workgroups, a band's state is
 // handed from span to span through `chain` (svf_chain_bytes(channels, largest call) bytes, zero-initialised once,
-// chainSpans = svf_chain_spans(largest call); used by one launch at a time).  nullptr / 0: one workgroup per channel.
+// chainSpans = svf_chain_spans(largest call); used by one launch at a time).  chainSpans = 0: one workgroup per channel;
+// `chain` (svf_chain_bytes(channels, 0) bytes, zero-initialised once; may be nullptr) then only holds the arrival counters by
+// which the two workgroups of a CU take turns at raised priority.
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh,
                            int nSamples, const double* coef, const int* flags, const double* satGain,
                            double* state, const void* tables, void* chain = nullptr, int chainSpans = 0,

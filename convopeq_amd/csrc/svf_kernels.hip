@@ -438,9 +438,12 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define CPQ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-// header of the chain buffer (64 bytes), then the granules [channel][chainSpans][band][4]
+// header of the chain buffer (64 bytes), the arrival counters of the CUs, then the granules [channel][chainSpans][band][4]
 struct TpvChainHeader { unsigned gen, done, ticket, error, pad[12]; };
 static_assert(sizeof(TpvChainHeader) == 64, "chain header");
+constexpr int kTpvPlaces = 8 * 256;             // (XCD, shader engine / array / CU of HW_ID): one arrival counter each
+constexpr int kTpvChainPrefix = (int)((sizeof(TpvChainHeader) + kTpvPlaces * sizeof(unsigned)) / sizeof(unsigned long long));
+constexpr int kTpvSliceBit = 12;                // time slices of 2^12 ticks of the 100 MHz real-time counter: 41 us
 
 // hand-over of one task (all wave-uniform)
 struct TpvLink {
@@ -449,7 +452,35 @@ struct TpvLink {
     unsigned epoch;
     int* flag;                        // LDS: != 0 once a start state outside the proven range has arrived (1 + band)
     unsigned* error;                  // header word: a poll gave up
+    int slice;                        // 0 / 1: the time slices in which this workgroup runs at raised priority; -1: none
 };
+
+// Two workgroups of the span kernel share a CU, and the instruction arbiter serves the older wave first: left alone, the
+// workgroup that arrived first runs at the pace it would have alone (55 us per span) and the other one at half of it (108 us),
+// so with one workgroup per channel and as many channels as the chip has room for, half the workgroups finish at 2 / 3 of the
+// launch and the CUs run the last third on two waves per SIMD (profiles/r04w_eq_workgroup_trace.txt).  Each workgroup
+// therefore raises its priority in alternate slices of the (chip-wide) real-time counter, the first arrival on a CU in the even
+// slices, the second in the odd ones: equal shares, both finish together.  A hint only: results do not depend on it.
+// (the counter is read in front of a band's scan and used behind it: a scalar memory read, its latency under the scan)
+__device__ __forceinline__ unsigned tpv_slice_clock(int slice)
+{
+    return slice < 0 ? 0u : (unsigned)__builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void tpv_time_slice(int slice, unsigned clock)
+{
+    if (slice < 0) return;
+    asm volatile("" : "+s"(clock));          // (keeps the compiler from testing -- and waiting for -- the counter where it was read)
+    if (((clock >> kTpvSliceBit) & 1u) == (unsigned)slice) __builtin_amdgcn_s_setprio(2);
+    else                                                    __builtin_amdgcn_s_setprio(0);
+}
+// order of arrival of this workgroup on its CU (one thread): counters that are never reset -- two arrivals per CU and launch
+// keep their parity, and any other sequence still alternates
+__device__ __forceinline__ int tpv_arrival(unsigned* arrivals)
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_ID, XCC_ID
+    const unsigned place = ((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu);          // HW_ID[15:8]: shader engine, array, CU
+    return (int)(__hip_atomic_fetch_add((gu32*)(arrivals + place), 1u, CPQ_RLX_AGENT) & 1u);
+}
 
 // lanes 0 ... 3 of the calling wave read one granule each until all four carry this launch's epoch
 // (requesting the granules a band ahead of the poll was measured: 30 spilled registers in the chained kernel, 1.53 against
@@ -899,7 +930,9 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
         double s0x, s0y;
         // (the thread index and the LDS addresses derived from it are rebuilt per band: tpv_lane_id)
         const int tidL = (waveU << 6) + tpv_lane_id();
+        const unsigned clock = tpv_slice_clock(link.slice);
         tp_scan<NT, CHAINED>(e0, e1, s0x, s0y, &sh.M[0][0], b, pw, sh.wtot + par * 2 * (nThreads >> 6), sState, sNext, tidL, &sh.P[b][0][0], PARTIAL ? endTid : -1, &link);
+        tpv_time_slice(link.slice, clock);
         par ^= 1;
         if (PARTIAL) {
             // the band's end state is the one behind the span's last valid sample, which the pass meets inside chunk endTid
@@ -1060,9 +1093,11 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_s
         double* sState = sh.stateA;
         double* sNext = sh.stateB;
         if (tid < kBands * 2) { sh.stateA[tid] = state[(int64_t)c * kBands * 2 + tid]; sh.stateB[tid] = sh.stateA[tid]; }
+        // whole spans, one workgroup per channel: the two workgroups of a CU take turns at raised priority (tpv_time_slice)
+        if (WAVES != 0 && tid == 0) sh.task = chain ? tpv_arrival(reinterpret_cast<unsigned*>(chain) + sizeof(TpvChainHeader) / sizeof(unsigned)) : -1;
         tpv_load_tables(sh, tb, tid, nThreads);
         __syncthreads();
-        const TpvLink link = { nullptr, nullptr, 0u, nullptr, nullptr };
+        const TpvLink link = { nullptr, nullptr, 0u, nullptr, nullptr, WAVES != 0 ? __builtin_amdgcn_readfirstlane(sh.task) : -1 };
 
         int sp = 0;
 #pragma unroll 1
@@ -1082,7 +1117,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_s
         if (nSpans > 0 && tidE < kBands * 2 && ((bm.active >> (tidE >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tidE] = sState[tidE];
     } else {
         TpvChainHeader* hdr = reinterpret_cast<TpvChainHeader*>(chain);
-        unsigned long long* gran = chain + sizeof(TpvChainHeader) / sizeof(unsigned long long);
+        unsigned long long* gran = chain + kTpvChainPrefix;
         if (tid == 0) sh.epoch = __hip_atomic_load((const gu32*)&hdr->gen, CPQ_RLX_AGENT) + 1u;
         const int nTasks = nSpans * nCh;
         int cur = -1;                     // channel whose tables are in LDS
@@ -1108,7 +1143,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_s
             if (sp == 0 && tidT < kBands * 2) sh.stateA[tidT] = state[(int64_t)c * kBands * 2 + tidT];
             __syncthreads();
             unsigned long long* g = gran + ((int64_t)c * chainSpans + sp) * (kBands * 4);
-            const TpvLink link = { sp > 0 ? g - kBands * 4 : nullptr, sp + 1 < nSpans ? g : nullptr, epoch, &sh.flag, &hdr->error };
+            const TpvLink link = { sp > 0 ? g - kBands * 4 : nullptr, sp + 1 < nSpans ? g : nullptr, epoch, &sh.flag, &hdr->error, -1 };
             const double* src = in + (int64_t)c * chStride + (int64_t)sp * spanLen;
             double* dst = out + (int64_t)c * chStride + (int64_t)sp * spanLen;
             const int r = tpv_fast_span<kNT, true, false>(sh, src + waveU * 1024, dst + waveU * 1024, bm, cf, sat, gain, sh.stateA, sh.stateB,
@@ -1435,8 +1470,9 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 int svf_chain_spans(int maxSamples) { return maxSamples / kTpvSpan + 1; }
 size_t svf_chain_bytes(int nCh, int maxSamples)
 {
-    // header + granules [channel][span][band][4] of the chained spans
-    return sizeof(TpvChainHeader) + (size_t)nCh * (size_t)svf_chain_spans(maxSamples) * kBands * 4 * sizeof(unsigned long long);
+    // header + arrival counters + granules [channel][span][band][4] of the chained spans (maxSamples = 0: no chained spans)
+    const size_t granules = maxSamples > 0 ? (size_t)nCh * (size_t)svf_chain_spans(maxSamples) * kBands * 4 : 0;
+    return (kTpvChainPrefix + granules) * sizeof(unsigned long long);
 }
 
 void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, int64_t chStride, int nCh, int nSamples,
@@ -1455,14 +1491,14 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
         // channel) tasks dealt to chainGrid workgroups.  Otherwise one workgroup per channel.
         // (with a workgroup per channel already on every slot chaining gains 4 % on the kernel alone, nothing in the pipeline, and
         // loses 4 % at 1024 streams: profiles/r04a_eq_chained_spans.txt)
-        if (chain && nCh < chainGrid && nSpans8 >= 2 && nSpans8 <= chainSpans) {
+        if (chain && chainSpans > 0 && nCh < chainGrid && nSpans8 >= 2 && nSpans8 <= chainSpans) {
             const int nTasks = nSpans8 * nCh;
             hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, true>), dim3(nTasks < chainGrid ? nTasks : chainGrid), dim3(kTpvWaves * 64), 0, stream,
                                in, out, chStride, nSpans8, nCh, coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain),
                                chainSpans, kAllBands, 0);
         } else {
             hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, false>), dim3(nCh), dim3(kTpvWaves * 64), 0, stream, in, out, chStride, nSpans8, nCh,
-                               coef, flags, satGain, state, tb, (unsigned long long*)nullptr, 0, kAllBands, 0);
+                               coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain), 0, kAllBands, 0);
         }
         done = nSpans8 * kTpvSpan;
     }
