@@ -305,18 +305,10 @@ __device__ __forceinline__ void tp_nonlinear(double (&y)[N], double sat, double 
 // 7 operations per sample instead of 10).  Both band kinds share it.
 // ORDER 2: one second-order step instead (r (1 + e): relative error e^2 <= 2.2e-15 in r, <= 0.4 ... 2 e-15 in the result
 // for sat = 0.2 ... 1 -- the size of the other rounding errors of a band; one operation less).
-// (the callers form the two constants once per channel and say that they are wave-uniform: computed here they sat in vector
-// registers across the band loop, at the 128-register limit of the span kernel)
-struct TpSmallConsts { double ca, cb; };
-__device__ __forceinline__ TpSmallConsts tp_small_consts(double sat)
-{
-    const double c1 = 9.0 - 8.0 * sat;
-    return { c1 * (1.0 / 9.0), 3.0 - c1 * (1.0 / 3.0) };
-}
 template <int N, int ORDER = 3>
-__device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], const TpSmallConsts& k)
+__device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], double c1)
 {
-    const double ca = k.ca, cb = k.cb;
+    const double ca = c1 * (1.0 / 9.0), cb = 3.0 - c1 * (1.0 / 3.0);
     double den[N], r[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) den[j] = fma(y[j], y[j], 3.0);
@@ -328,21 +320,19 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], const TpSmall
         const double pp = p01 * p23;
         double q = __builtin_amdgcn_rcp(pp);
         q = fma(fma(-pp, q, 1.0), q, q);
-        q *= cb;                         // (cb folded into the shared reciprocal: every instruction below has ONE scalar operand)
         const double q01 = q * p23, q23 = q * p01;
-        y[0] *= fma(q01, den[1], ca);
-        y[1] *= fma(q01, den[0], ca);
-        y[2 % N] *= fma(q23, den[3 % N], ca);
-        y[3 % N] *= fma(q23, den[2 % N], ca);
+        y[0] *= fma(cb, q01 * den[1], ca);
+        y[1] *= fma(cb, q01 * den[0], ca);
+        y[2 % N] *= fma(cb, q23 * den[3 % N], ca);
+        y[3 % N] *= fma(cb, q23 * den[2 % N], ca);
         return;
     }
-    if (N == 2 && ORDER == 2) {          // the same for a pair: 14 slots for two samples instead of 18
+    if (N == 2 && ORDER == 2) {          // the same for a pair: 15 slots for two samples instead of 18
         const double pp = den[0] * den[1 % N];
         double q = __builtin_amdgcn_rcp(pp);
         q = fma(fma(-pp, q, 1.0), q, q);
-        q *= cb;                         // cb / (den0 den1): one product for the pair, and ONE scalar operand per instruction
-        y[0] *= fma(q, den[1 % N], ca);
-        y[1 % N] *= fma(q, den[0], ca);
+        y[0] *= fma(cb, q * den[1 % N], ca);
+        y[1 % N] *= fma(cb, q * den[0], ca);
         return;
     }
 #pragma unroll
@@ -356,21 +346,11 @@ __device__ __forceinline__ void tp_nonlinear_small(double (&y)[N], const TpSmall
     for (int j = 0; j < N; ++j) y[j] *= fma(cb, r[j], ca);
 }
 
-// a * b + c with a in scalar registers, as the three-address instruction: for the output of a peaking band (m1 v1 + v0, v0 the
-// sample's own register) the compiler's choice was a register copy plus the two-address v_fmac_f64 -- one more issue slot per sample
-__device__ __forceinline__ double fma_sgpr(double a, double b, double c)
-{
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));
-    return d;
-}
-
 // zero-state (or continuing) recurrence of one band over N samples held in registers: v[j] <- y_lin[j]
 // KIND: 0 = SVF, packed stereo arithmetic (FMA), 1 = SVF scalar arithmetic (Left/Right modes), 2 = DF-II-T biquad
 // of the OutputFilter (coefficients b0 b1 b2 a1 a2 in a1 a2 a3 m0 m1; state w1 w2 in ic1 ic2)
 // CAP: the state behind sample capAt is copied to (c1, c2) -- the end state of a span whose last chunk is partly padding
-// UNI: the coefficients are wave-uniform (scalar registers)
-template <int KIND, int N, bool CAP = false, bool UNI = false>
+template <int KIND, int N, bool CAP = false>
 __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic2, double a1, double a2, double a3,
                                          double m0, double m1, double m2, int capAt = -1, double* c1 = nullptr, double* c2 = nullptr)
 {
@@ -394,7 +374,7 @@ __device__ __forceinline__ void tp_recur(double (&v)[N], double& ic1, double& ic
             const double v1 = fma(m2, ic1, m0 * v3);             // m2 = a1, m0 = a2 of the band here
             ic2 = fma(a1, ic1, fma(a2, v3, ic2));
             ic1 = fma(2.0, v1, -ic1);
-            v[j] = UNI ? fma_sgpr(m1, v1, v0) : fma(m1, v1, v0);
+            v[j] = fma(m1, v1, v0);
             continue;
         }
         if (KIND == 1) {
@@ -712,24 +692,6 @@ struct TpvShared {
     unsigned epoch;
 };
 
-// max(|a|, |b|, |c|) of the HIGH words of three doubles, taken as floats: the bit pattern of a double's high word grows with
-// |x| like a float's does, and the fastTanh clip threshold 4.5 has a zero low word, so |x| < 4.5 <=> high word (sign cleared) <
-// 0x40120000 exactly.  One 32-bit instruction for three samples where v_cmp_lt_f64 takes one per sample.  (A high word that is
-// a float NaN -- |x| >= 2^1017, infinities, NaNs -- is passed over by the maximum: the fast path only runs on spans whose inputs
-// and states the host has proven to stay below 1e15, and a span that produced one anyway is met by the state check of the next.)
-__device__ __forceinline__ float tpv_max3_hi(double a, double b, double c)
-{
-    float m;
-    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(__double2hiint(a)), "v"(__double2hiint(b)), "v"(__double2hiint(c)));
-    return m;
-}
-__device__ __forceinline__ float tpv_max3_hi(float m, double b, double c)      // running maximum: one register
-{
-    float r;
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(__double2hiint(b)), "v"(__double2hiint(c)));
-    return r;
-}
-
 // One band over the lane's 16 samples from its true start state.  KIND 0 / 3: SVF band, general / with m0 == 1 and m2 == 0
 // (seven operations per sample in the recurrence instead of ten) (the packed-stereo FMA arithmetic for
 // both arithmetic flavours of the reference -- the time-parallel evaluation is rounding-level anyway; `mono` selects the
@@ -741,25 +703,22 @@ __device__ __forceinline__ float tpv_max3_hi(float m, double b, double c)      /
 template <int KIND, bool SAT, bool CAP = false>
 __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2, const double* __restrict__ cfb, bool mono,
                                          const double* En, double& e0o, double& e1o,
-                                         double sat, bool smallOk, const TpSmallConsts& smallK,
+                                         double sat, double oneMinusSat, bool smallOk, double smallC1,
                                          int capAt = -1, double* c1 = nullptr, double* c2 = nullptr)
 {
     {
         const double a1 = cfb[0], a2 = cfb[1], a3 = cfb[2], m0 = cfb[3], m1 = cfb[4], m2 = cfb[5];
         if (KIND == 3)          // m0 == 1 and m2 == 0 (peaking bands)
-            tp_recur<3, 16, CAP, true>(x, ic1, ic2, 2.0 * a2, 2.0 * a3, 0.0, a2, m1, a1, capAt, c1, c2);
+            tp_recur<3, 16, CAP>(x, ic1, ic2, 2.0 * a2, 2.0 * a3, 0.0, a2, m1, a1, capAt, c1, c2);
         else
         tp_recur<KIND, 16, CAP>(x, ic1, ic2, a1, a2, a3, m0, m1, m2, capAt, c1, c2);
     }
     double e0 = 0.0, e1 = 0.0;
     bool done = false;
     if (KIND != 2) {          // kind 2: linear section, no output stage
-        // every |x[j]| below the clip threshold?  (tpv_max3_hi: nine instructions for the sixteen samples, one register)
-        float mx = tpv_max3_hi(x[0], x[1], x[2]);
+        int small = 1;
 #pragma unroll
-        for (int j = 3; j < 15; j += 2) mx = tpv_max3_hi(mx, x[j], x[j + 1]);
-        mx = tpv_max3_hi(mx, x[15], x[15]);
-        const int small = (int)(__float_as_uint(mx) < 0x40120000u);
+        for (int j = 0; j < 16; ++j) small &= (int)(fabs(x[j]) < 4.5);      // a NaN fails and takes the general code
         if (smallOk && __all(small)) {
             // kTpvU at a time, kept apart in the schedule: sixteen evaluations in flight at once do not fit the registers
 #pragma unroll
@@ -767,7 +726,7 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
                 double v[kTpvU];
 #pragma unroll
                 for (int j = 0; j < kTpvU; ++j) v[j] = x[kTpvU * h + j];
-                if (SAT) tp_nonlinear_small<kTpvU, 2>(v, smallK);
+                if (SAT) tp_nonlinear_small<kTpvU, 2>(v, smallC1);
 #pragma unroll
                 for (int j = 0; j < kTpvU; ++j) {
                     const double2 ee = *reinterpret_cast<const double2*>(En + 2 * (kTpvU * h + j));
@@ -780,11 +739,6 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
             done = true;
         } else {
             // rare: a sample at or above the fastTanh clip threshold somewhere in the wave
-            // (1 - sat formed here, behind a value the compiler cannot see through: hoisted out of the band loop it held two vector
-            // registers through the hot path, which sits at the register limit)
-            double satHere = sat;
-            asm volatile("" : "+s"(satHere));
-            const double oneMinusSat = 1.0 - satHere;
 #pragma unroll 1
             for (int h = 0; h < 4; ++h) {
                 // rotate instead of indexing: x stays in registers
@@ -964,10 +918,9 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
                                              unsigned monoMask, SH& sh, double* sState, double* sNext, const double* __restrict__ cf,
                                              double sat, int waveU, int nThreads, const TpvLink& link, int endTid = -1, int capAt = 15)
 {
+    const double oneMinusSat = tpv_uniform(1.0 - sat);
     const bool smallOk = (sat >= 0.0) && (sat <= 1.0);
-    TpSmallConsts smallK = tp_small_consts(sat);
-    smallK.ca = tpv_uniform(smallK.ca);
-    smallK.cb = tpv_uniform(smallK.cb);
+    const double smallC1 = tpv_uniform(9.0 - 8.0 * sat);
     const TpLanePowers pw = {};                       // the per-lane powers come from LDS where tp_scan uses them
 #pragma unroll 1
     while (run) {
@@ -985,11 +938,11 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
             // the band's end state is the one behind the span's last valid sample, which the pass meets inside chunk endTid
             // (the scan above left there the state behind that chunk's padding)
             double c1 = 0.0, c2 = 0.0;
-            tpv_pass<CLS, SAT, true>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, smallOk, smallK,
+            tpv_pass<CLS, SAT, true>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1,
                                      tidL == endTid ? capAt : -1, &c1, &c2);
             if (tidL == endTid) { sNext[2 * b] = c1; sNext[2 * b + 1] = c2; }
         } else {
-            tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, smallOk, smallK);
+            tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, oneMinusSat, smallOk, smallC1);
         }
     }
 }
@@ -1349,11 +1302,11 @@ __device__ __forceinline__ void short_pass(double (&x)[LC], double ic1, double i
         for (int j = 0; j < LC; ++j) small &= (int)(fabs(x[j]) < 4.5);
         if (sat >= 0.0 && sat <= 1.0 && __all(small)) {
             if (SAT) {
-                const TpSmallConsts ks = tp_small_consts(sat);
+                const double c1s = 9.0 - 8.0 * sat;
 #pragma unroll
                 for (int h = 0; h < LC / 2; ++h) {
                     double v[2] = { x[2 * h], x[2 * h + 1] };
-                    tp_nonlinear_small<2, 2>(v, ks);
+                    tp_nonlinear_small<2, 2>(v, c1s);
                     x[2 * h] = v[0];
                     x[2 * h + 1] = v[1];
                 }
