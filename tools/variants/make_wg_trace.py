@@ -16,7 +16,7 @@ def put(anchor, text, after=True, count=1):
 
 
 put("template <int WAVES, bool CHAINED, bool PARTIAL = false>\n__global__ __launch_bounds__", """
-struct WgTrace { unsigned long long t0, t1, c0, c1; unsigned hw, xcc, block, nSpans; unsigned long long spanT[96]; unsigned spanId[96]; };
+struct WgTrace { unsigned long long t0, t1, c0, c1; unsigned hw, xcc, block, nSpans; unsigned long long spanT[96]; unsigned spanId[96]; unsigned long long spanC[96]; };
 __device__ WgTrace g_wgTrace[4096];
 __device__ __forceinline__ void wg_trace_begin(int tid)
 {
@@ -35,7 +35,7 @@ __device__ __forceinline__ void wg_trace_span(int tid, int id)
     if (tid == 0 && blockIdx.x < 4096) {
         WgTrace& w = g_wgTrace[blockIdx.x];
         const unsigned k = w.nSpans;
-        if (k < 96) { w.spanT[k] = __builtin_amdgcn_s_memrealtime(); w.spanId[k] = (unsigned)id; }
+        if (k < 96) { w.spanT[k] = __builtin_amdgcn_s_memrealtime(); w.spanId[k] = (unsigned)id; w.spanC[k] = __builtin_amdgcn_s_memtime(); }
         w.nSpans = k + 1;
     }
 }

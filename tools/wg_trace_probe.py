@@ -22,8 +22,8 @@ from convopeq_amd import _capi  # noqa: E402
 lib = _capi.load() if hasattr(_capi, "load") else _capi._lib
 NW = 4096
 rec = np.dtype([("t0", "<u8"), ("t1", "<u8"), ("c0", "<u8"), ("c1", "<u8"), ("hw", "<u4"), ("xcc", "<u4"), ("block", "<u4"),
-                ("n", "<u4"), ("spanT", "<u8", (96,)), ("spanId", "<u4", (96,))])
-assert rec.itemsize == 1200
+                ("n", "<u4"), ("spanT", "<u8", (96,)), ("spanId", "<u4", (96,)), ("spanC", "<u8", (96,))])
+assert rec.itemsize == 1968
 buf = np.zeros(NW, dtype=rec)
 fn = lib.cpq_diag_wg_trace
 fn.argtypes = [C.c_void_p, C.c_size_t]
@@ -60,10 +60,16 @@ if n.min() >= 8:
     last = np.array([(sp[i, n[i] - 1] - sp[i, n[i] - 1 - n[i] // 4]) / max(n[i] // 4, 1) for i in range(len(w))]) / 100.0
     print(f"us per span: first quarter mean {first.mean():.2f} (min {first.min():.2f} max {first.max():.2f}); last quarter mean {last.mean():.2f} "
           f"(min {last.min():.2f} max {last.max():.2f})")
+    # shader clock over the launch: s_memtime ticks per us between consecutive span ends, mean over the workgroups
+    k = int(n.min())
+    dT = np.diff(w["spanT"][:, :k].astype(np.int64), axis=1) / 100.0
+    dC = np.diff(w["spanC"][:, :k].astype(np.int64), axis=1)
+    print("us per span by span index (every 4th):", np.round(dT.mean(axis=0)[::4], 1).tolist())
+    print("s_memtime ticks per us by span index (every 4th):", np.round((dC / np.maximum(dT, 1e-9)).mean(axis=0)[::4], 0).tolist())
     # pairs sharing a CU: does the partner's end speed the other one up?
     order = np.argsort(end)
     print("slowest 5 workgroups:", [(int(w['block'][i]), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end[i]), 1)) for i in order[-5:]])
     print("fastest 5 workgroups:", [(int(w['block'][i]), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end[i]), 1)) for i in order[:5]])
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", f"wg_trace_{label}.npz")
 np.savez_compressed(out, t0=w["t0"], t1=w["t1"], c0=w["c0"], c1=w["c1"], hw=w["hw"], xcc=w["xcc"], block=w["block"], n=w["n"],
-                    spanT=w["spanT"], spanId=w["spanId"])
+                    spanT=w["spanT"], spanId=w["spanId"], spanC=w["spanC"])
