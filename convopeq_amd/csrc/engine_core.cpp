@@ -348,7 +348,16 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         if (hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); nCu = 0; }
         e->svfChainGrid = 2 * nCu;          // the span kernel keeps 76 KB of LDS: two workgroups per CU
     }
-    const bool chained = nCh < e->svfChainGrid && e->maxCall >= 2 * 8192;
+    // One workgroup per channel runs whole rounds of svfChainGrid workgroups: a last round of r workgroups costs 0.70 of a full
+    // one up to half the slots (the workgroups are alone on their CUs) and a whole one beyond.  Chained spans deal (span,
+    // channel) tasks to the slots whatever the count, at 6 % more per task (hand-over polls, tables per task).  Measured
+    // (profiles/r04x_eq_stream_counts.txt): 300 streams 7.63 -> chained; 255 / 256 / 512 / 1024 streams stay as they are.
+    bool chained = false;
+    if (e->svfChainGrid > 0 && e->maxCall >= 2 * 8192) {
+        const int64_t full = nCh / e->svfChainGrid, r = nCh % e->svfChainGrid;
+        const double perChannel = (double)full + (r == 0 ? 0.0 : (2 * r <= e->svfChainGrid ? 0.70 : 1.0));
+        chained = 1.06 * (double)nCh / (double)e->svfChainGrid < perChannel;
+    }
     Item items[] = {
         { (void**)&e->X, nCh * e->ringSlots * e->P * (int64_t)sizeof(double2) },
         { (void**)&e->XDN, nCh * e->ringSlots * (int64_t)sizeof(double2) },

@@ -92,8 +92,8 @@ void launch_svf_cascade(hipStream_t stream, const double* in, double* out, int64
 // tables: kSvfTpTableDoubles doubles per (stream, band): for each chunk length LC in kSvfTpLc ({16, 8}): Mk[6][4] = A^(LC 2^k),
 // Mw[4] = A^(64 LC), P[64][4] = A^(LC (c+1)), G[16][2] = C A^i; then the chunk's end-state map e[2][16] = A^(15-k) B.
 // geometry constants kSvfTpLc / kSvfTpTableDoubles: host_design.hpp (shared with the table builder)
-// chain / chainSpans / chainGrid: chained spans for engines with fewer channels than the chip holds workgroups of the span
-// kernel (chainGrid = 2 per CU): the (span, channel) pairs of a call are dealt to chainGrid workgroups, a band's state is
+// chain / chainSpans / chainGrid: chained spans for engines whose channels do not fill whole rounds of the workgroups the chip
+// holds of the span kernel (chainGrid = 2 per CU): the (span, channel) pairs of a call are dealt to chainGrid workgroups, a band's state is
 // handed from span to span through `chain` (svf_chain_bytes(channels, largest call) bytes, zero-initialised once,
 // chainSpans = svf_chain_spans(largest call); used by one launch at a time).  chainSpans = 0: one workgroup per channel;
 // `chain` (svf_chain_bytes(channels, 0) bytes, zero-initialised once; may be nullptr) then only holds the arrival counters by

@@ -1540,11 +1540,9 @@ void launch_svf_cascade_tp(hipStream_t stream, const double* in, double* out, in
     int done = 0;
     const int nSpans8 = nSamples / kTpvSpan;
     if (nSpans8 > 0) {
-        // Fewer channels than the chip holds workgroups of this kernel (chainGrid = 2 per CU): chained spans, the (span,
-        // channel) tasks dealt to chainGrid workgroups.  Otherwise one workgroup per channel.
-        // (with a workgroup per channel already on every slot chaining gains 4 % on the kernel alone, nothing in the pipeline, and
-        // loses 4 % at 1024 streams: profiles/r04a_eq_chained_spans.txt)
-        if (chain && chainSpans > 0 && nCh < chainGrid && nSpans8 >= 2 && nSpans8 <= chainSpans) {
+        // chainSpans > 0 (the engine's choice: channel counts that do not fill whole rounds of chainGrid = 2 per CU workgroups):
+        // chained spans, the (span, channel) tasks dealt to chainGrid workgroups.  Otherwise one workgroup per channel.
+        if (chain && chainSpans > 0 && nSpans8 >= 2 && nSpans8 <= chainSpans) {
             const int nTasks = nSpans8 * nCh;
             hipLaunchKernelGGL((k_svf_cascade_tpv<kTpvWaves, true>), dim3(nTasks < chainGrid ? nTasks : chainGrid), dim3(kTpvWaves * 64), 0, stream,
                                in, out, chStride, nSpans8, nCh, coef, flags, satGain, state, tb, reinterpret_cast<unsigned long long*>(chain),

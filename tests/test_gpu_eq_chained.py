@@ -124,6 +124,41 @@ def test_chained_spans_stream_counts(amd, oracle, S):
     eng.close()
 
 
+def test_chained_spans_more_channels_than_workgroup_slots(amd, oracle):
+    """300 streams = 600 channels on a device that holds 512 workgroups of the span kernel: one workgroup per channel would run
+    a second round of 88 -- the engine chains instead (engine_core.cpp: the rule), tasks outnumber the workgroups from the first
+    span on and a workgroup's next task is always another channel.  Four of the streams against the oracle."""
+    O = oracle
+    S, T = 300, 64
+    eng = amd.BatchedEngine(S, max_ir_len=512, max_blocks_per_call=T)
+    check = [0, 1, 255, 256, 299]
+    rng = np.random.default_rng(7)
+    x = 0.25 * (2.0 * rng.random((2 * S, T * B)) - 1.0)
+    for s in check:
+        x[2 * s], x[2 * s + 1] = O.gen_pcm(T * B, stream=s, channel=0), O.gen_pcm(T * B, stream=s, channel=1)
+    pos = {}
+    for s in range(S):
+        po = O.eq_params_bench(0.2)
+        po.bands[s % 20].gain = 0.5 * (s % 9) - 2.0
+        if s in check:
+            pos[s] = po
+        eng.set_eq_params(s, _copy_params(po, amd.eq_params_default()))
+    y = eng.eq_process(x)
+    launches, gave_up = eng.eq_chain_status()
+    import torch
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert gave_up == 0
+    if n_cu == 256:
+        assert launches == 1        # chained (600 channels on 512 slots): the launch advanced the generation
+    worst = 0.0
+    for s in check:
+        yl, yr, _ = O.eq_process_stereo(x[2 * s], x[2 * s + 1], pos[s])
+        worst = max(worst, np.abs(y[2 * s] - yl).max(), np.abs(y[2 * s + 1] - yr).max())
+    print("chained spans, 300 streams: max abs diff", worst, "launches", launches)
+    assert worst <= 1e-13
+    eng.close()
+
+
 def test_two_engines_on_two_host_threads_share_the_device(amd, oracle):
     """Row (e) of SURVEY.md section 8 in one process: two engines on device 0, each driven by its own host thread (the loop of
     tests/examples/multi_device_host.cpp with both handles on one device), real IRs + PCM through convolver and EQ, several
