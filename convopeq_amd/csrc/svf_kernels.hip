@@ -1002,35 +1002,46 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
 // whose output is v0 + m1 v1 (every peaking band).  Wave-uniform by construction; said so, they live in scalar registers
 // (left in vector registers they were spilled and reloaded inside the band loop).
 struct TpvBands { unsigned active, df, mono, peak; unsigned long long kinds; };
+// (lane b of every wave reads band b's flag word and the two coefficients of the peaking test; the masks are ballots.  A chained
+// workgroup changes channel with every task: read band by band by every thread, this cost 60 dependent uniform loads per task)
 __device__ __forceinline__ TpvBands tpv_band_masks(const int* __restrict__ flags, const double* __restrict__ cf, int c, unsigned bandFilter)
 {
-    TpvBands m = { 0, 0, 0, 0, 0 };      // kinds: 2 bits per band: 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
-    for (int b = 0; b < kBands; ++b) {
-        const int f = flags[c * kBands + b];
-        m.active |= ((unsigned)(f & 1) << b) & bandFilter;      // bandFilter: the bands of this launch
-        m.kinds |= (unsigned long long)((f >> 1) & 3) << (2 * b);
+    const int lane = tpv_lane_id();
+    int f = 0;
+    double c3 = 0.0, c5 = 1.0;
+    if (lane < kBands) {
+        f = flags[c * kBands + lane];
+        c3 = cf[lane * 6 + 3];
+        c5 = cf[lane * 6 + 5];
     }
-    for (int b = 0; b < kBands; ++b) {
-        m.df |= (unsigned)(((m.kinds >> (2 * b)) & 3) == 2) << b;
-        m.mono |= (unsigned)(((m.kinds >> (2 * b)) & 3) == 1) << b;
-        m.peak |= (unsigned)(((m.kinds >> (2 * b)) & 3) != 2 && cf[b * 6 + 3] == 1.0 && cf[b * 6 + 5] == 0.0) << b;
-    }
+    const int kind = (f >> 1) & 3;          // 0 SVF stereo, 1 SVF scalar, 2 DF-II-T
+    const unsigned k0 = (unsigned)__ballot(kind & 1), k1 = (unsigned)__ballot(kind & 2);
+    TpvBands m;
+    m.active = (unsigned)__ballot(f & 1) & bandFilter;      // bandFilter: the bands of this launch
+    m.df = k1 & ~k0;
+    m.mono = k0 & ~k1;
+    m.peak = (unsigned)__ballot(lane < kBands && kind != 2 && c3 == 1.0 && c5 == 0.0);
+    m.kinds = 0;                             // 2 bits per band (the guarded path reads them)
+    for (int b = 0; b < kBands; ++b)
+        m.kinds |= (unsigned long long)(((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1)) << (2 * b);
     m.active = __builtin_amdgcn_readfirstlane(m.active);
     m.df = __builtin_amdgcn_readfirstlane(m.df);
     m.mono = __builtin_amdgcn_readfirstlane(m.mono);
     m.peak = __builtin_amdgcn_readfirstlane(m.peak);
     return m;
 }
+// the tables of one stream into LDS: 16-byte pieces (Mk and Mw are contiguous in TpLcTables: 14 pieces per band; the E rows are
+// paired up from the two rows of the host's e[2][16]), every load independent of the others
 template <class SH>
 __device__ __forceinline__ void tpv_load_tables(SH& sh, const TpBandTables* __restrict__ tb, int tid, int nThreads)
 {
-    for (int i = tid; i < kBands * 28; i += nThreads) {
-        const int b = i / 28, q = i % 28;
-        sh.M[b][q] = (q < 24) ? tb[b].t[0].Mk[q / 4][q % 4] : tb[b].t[0].Mw[q - 24];
+    for (int i = tid; i < kBands * 14; i += nThreads) {
+        const int b = i / 14, q = i % 14;
+        reinterpret_cast<double2*>(&sh.M[b][0])[q] = reinterpret_cast<const double2*>(&tb[b].t[0].Mk[0][0])[q];
     }
-    for (int i = tid; i < kBands * 32; i += nThreads) {
-        const int b = i / 32, k = (i % 32) >> 1, r = i & 1;
-        sh.E[b][k][r] = tb[b].mm.e[r][k];
+    for (int i = tid; i < kBands * 16; i += nThreads) {
+        const int b = i >> 4, k = i & 15;
+        *reinterpret_cast<double2*>(&sh.E[b][k][0]) = make_double2(tb[b].mm.e[0][k], tb[b].mm.e[1][k]);
     }
     for (int i = tid; i < kBands * 128; i += nThreads) {       // 16-byte pieces of P[64][4]
         const int b = i >> 7, q = i & 127;

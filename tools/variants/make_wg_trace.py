@@ -15,8 +15,8 @@ def put(anchor, text, after=True, count=1):
     src = src.replace(anchor, anchor + text if after else text + anchor)
 
 
-put("template <int WAVES, bool CHAINED, bool PARTIAL = false>\n__global__ __launch_bounds__", """
-struct WgTrace { unsigned long long t0, t1, c0, c1; unsigned hw, xcc, block, nSpans; unsigned long long spanT[96]; unsigned spanId[96]; unsigned long long spanC[96]; };
+put("template <int NT, bool CHAINED, bool PARTIAL, class SH>\n__device__ __forceinline__ int tpv_fast_span", """
+struct WgTrace { unsigned long long t0, t1, c0, c1; unsigned hw, xcc, block, nSpans; unsigned long long spanT[96]; unsigned spanId[96]; unsigned long long spanC[96]; unsigned long long last; unsigned long long phase[8]; };
 __device__ WgTrace g_wgTrace[4096];
 __device__ __forceinline__ void wg_trace_begin(int tid)
 {
@@ -28,6 +28,8 @@ __device__ __forceinline__ void wg_trace_begin(int tid)
         w.xcc = __builtin_amdgcn_s_getreg(63508);       // HW_REG_XCC_ID
         w.block = blockIdx.x;
         w.nSpans = 0;
+        w.last = w.t0;
+        for (int k = 0; k < 8; ++k) w.phase[k] = 0;
     }
 }
 __device__ __forceinline__ void wg_trace_span(int tid, int id)
@@ -37,6 +39,17 @@ __device__ __forceinline__ void wg_trace_span(int tid, int id)
         const unsigned k = w.nSpans;
         if (k < 96) { w.spanT[k] = __builtin_amdgcn_s_memrealtime(); w.spanId[k] = (unsigned)id; w.spanC[k] = __builtin_amdgcn_s_memtime(); }
         w.nSpans = k + 1;
+    }
+}
+// time since the workgroup's last stamp, added to phase k (0: between tasks, 1: ticket, 2: tables and masks, 3: span load and
+// range check, 4: band loop, 5: span store)
+__device__ __forceinline__ void wg_trace_phase(int tid, int k)
+{
+    if (tid == 0 && blockIdx.x < 4096) {
+        WgTrace& w = g_wgTrace[blockIdx.x];
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        w.phase[k] += now - w.last;
+        w.last = now;
     }
 }
 __device__ __forceinline__ void wg_trace_end(int tid)
@@ -57,6 +70,14 @@ put("        int cur = -1;                     // channel whose tables are in LD
 put("            if (sp + 1 == nSpans && tidE < kBands * 2 && ((bm.active >> (tidE >> 1)) & 1)) state[(int64_t)c * kBands * 2 + tidE] = sh.stateB[tidE];\n",
     "            wg_trace_span(tid, q);\n")
 put("        // the last workgroup to get here resets the ticket and advances the generation for the next launch\n", "        wg_trace_end(tid);\n")
+put("    else         tpv_span_load(srcW, buf, laneIo, x);\n", "    if (NT == 512) wg_trace_phase(tidS, 2);\n", after=False)
+put("    bool bad = false;\n#pragma unroll\n    for (int j = 0; j < 16; ++j) bad |= !(fabs(x[j]) < kTpInputBound);\n", "    if (NT == 512) wg_trace_phase(tidS, 3);\n", after=False)
+put("    laneIo = tpv_lane_id();\n    if (PARTIAL) tpv_span_store_partial(dstW, buf, laneIo, x, gain, nValidW);\n",
+    "    if (NT == 512) wg_trace_phase((waveU << 6) + tpv_lane_id(), 4);\n", after=False)
+put("    __syncthreads();                      // the last thread's end states are in sNext; every wave's stores are out\n",
+    "    if (NT == 512) wg_trace_phase((waveU << 6) + tpv_lane_id(), 5);\n")
+put("            if (q >= nTasks) break;\n", "            wg_trace_phase(tid, 1);\n")
+put("            __syncthreads();              // the task before is done with sh (tables, states, task word)\n", "            wg_trace_phase(tid, 0);\n", after=False)
 src += """
 extern "C" int cpq_diag_wg_trace(void* dst, size_t bytes)
 {

@@ -22,8 +22,8 @@ from convopeq_amd import _capi  # noqa: E402
 lib = _capi.load() if hasattr(_capi, "load") else _capi._lib
 NW = 4096
 rec = np.dtype([("t0", "<u8"), ("t1", "<u8"), ("c0", "<u8"), ("c1", "<u8"), ("hw", "<u4"), ("xcc", "<u4"), ("block", "<u4"),
-                ("n", "<u4"), ("spanT", "<u8", (96,)), ("spanId", "<u4", (96,)), ("spanC", "<u8", (96,))])
-assert rec.itemsize == 1968
+                ("n", "<u4"), ("spanT", "<u8", (96,)), ("spanId", "<u4", (96,)), ("spanC", "<u8", (96,)), ("last", "<u8"), ("phase", "<u8", (8,))])
+assert rec.itemsize == 2040
 buf = np.zeros(NW, dtype=rec)
 fn = lib.cpq_diag_wg_trace
 fn.argtypes = [C.c_void_p, C.c_size_t]
@@ -70,6 +70,10 @@ if n.min() >= 8:
     order = np.argsort(end)
     print("slowest 5 workgroups:", [(int(w['block'][i]), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end[i]), 1)) for i in order[-5:]])
     print("fastest 5 workgroups:", [(int(w['block'][i]), int(xcc[i]), int(se[i]), int(cu[i]), round(float(end[i]), 1)) for i in order[:5]])
+ph = w["phase"].astype(np.float64) / 100.0
+tasks = np.maximum(w["n"], 1)[:, None]
+print("us per task by phase (0 between tasks, 1 ticket, 2 tables / masks / until the span load is issued, 3 span load, 4 band loop, 5 store): "
+      + " ".join(f"{v:.2f}" for v in (ph / tasks).mean(axis=0)[:6]) + f"   sum {(ph / tasks).sum(axis=1).mean():.2f}")
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", f"wg_trace_{label}.npz")
 np.savez_compressed(out, t0=w["t0"], t1=w["t1"], c0=w["c0"], c1=w["c1"], hw=w["hw"], xcc=w["xcc"], block=w["block"], n=w["n"],
                     spanT=w["spanT"], spanId=w["spanId"], spanC=w["spanC"])
