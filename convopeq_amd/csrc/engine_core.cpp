@@ -382,8 +382,7 @@ int32_t cpq_engine_create(const cpq_engine_desc* d, cpq_engine** out)
         { (void**)&e->ofState, nCh * kBands * 2 * (int64_t)sizeof(double) },
         { (void**)&e->ofTp, (nCh / 2) * kBands * cpq::kSvfTpTableDoubles * (int64_t)sizeof(double) },
         // scheduling words of the time-parallel cascade (svf_kernels.hip): header, the arrival counters of the CUs, and -- only
-        // for engines with fewer channels than the chip holds workgroups of that kernel (two per CU) -- the band states handed
-        // from span to span (chained spans)
+        // for engines that chain their spans (the rule above) -- the band states handed from span to span
         { (void**)&e->svfChain, (int64_t)cpq::svf_chain_bytes((int)nCh, chained ? e->maxCall : 0) },
     };
     e->svfChainSpans = chained ? cpq::svf_chain_spans(e->maxCall) : 0;
