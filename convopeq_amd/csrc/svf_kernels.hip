@@ -473,6 +473,7 @@ struct TpvLink {
     int* flag;                        // LDS: != 0 once a start state outside the proven range has arrived (1 + band)
     unsigned* error;                  // header word: a poll gave up
     int slice;                        // 0 / 1: the time slices in which this workgroup runs at raised priority; -1: none
+    const struct TpBandTables* tb;    // the stream's tables in device memory (the pass reads the next band's E rows through the scalar cache)
 };
 
 // Two workgroups of the span kernel share a CU, and the instruction arbiter serves the older wave first: left alone, the
@@ -741,7 +742,7 @@ __device__ __forceinline__ float tpv_max3_hi(float m, double b, double c)      /
 // capAt in (c1, c2).
 template <int KIND, bool SAT, bool CAP = false>
 __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2, const double* __restrict__ cfb, bool mono,
-                                         const double* En, double& e0o, double& e1o,
+                                         const double* En, const double* Eglob, double& e0o, double& e1o,
                                          double sat, bool smallOk, const TpSmallConsts& smallK,
                                          int capAt = -1, double* c1 = nullptr, double* c2 = nullptr)
 {
@@ -762,21 +763,35 @@ __device__ __forceinline__ void tpv_pass(double (&x)[16], double ic1, double ic2
         mx = tpv_max3_hi(mx, x[15], x[15]);
         const int small = (int)(__float_as_uint(mx) < 0x40120000u);
         if (smallOk && __all(small)) {
-            // kTpvU at a time, kept apart in the schedule: sixteen evaluations in flight at once do not fit the registers
+            // kTpvU at a time, kept apart in the schedule: sixteen evaluations in flight at once do not fit the registers.
+            // The next band's E rows are wave-uniform: read from the table in device memory through the scalar cache into scalar
+            // registers, a group ahead of their use (from LDS they were 16 vector reads per band and a wait in every group)
+            typedef const __attribute__((address_space(4))) double* ScalarPtr;
+            const ScalarPtr g0 = (ScalarPtr)Eglob, g1 = g0 + 16;       // e[0][k], e[1][k]
+            double ea[kTpvU], eb[kTpvU];
+#pragma unroll
+            for (int j = 0; j < kTpvU; ++j) { ea[j] = g0[j]; eb[j] = g1[j]; }
 #pragma unroll
             for (int h = 0; h < 16 / kTpvU; ++h) {
+                double na[kTpvU], nb[kTpvU];
+#pragma unroll
+                for (int j = 0; j < kTpvU; ++j) {
+                    na[j] = (h + 1 < 16 / kTpvU) ? g0[kTpvU * (h + 1) + j] : 0.0;
+                    nb[j] = (h + 1 < 16 / kTpvU) ? g1[kTpvU * (h + 1) + j] : 0.0;
+                }
                 double v[kTpvU];
 #pragma unroll
                 for (int j = 0; j < kTpvU; ++j) v[j] = x[kTpvU * h + j];
                 if (SAT) tp_nonlinear_small<kTpvU, 2>(v, smallK);
 #pragma unroll
                 for (int j = 0; j < kTpvU; ++j) {
-                    const double2 ee = *reinterpret_cast<const double2*>(En + 2 * (kTpvU * h + j));
-                    e0 = fma(ee.x, v[j], e0);
-                    e1 = fma(ee.y, v[j], e1);
+                    e0 = fma(ea[j], v[j], e0);
+                    e1 = fma(eb[j], v[j], e1);
                     x[kTpvU * h + j] = v[j];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < kTpvU; ++j) { ea[j] = na[j]; eb[j] = nb[j]; }
             }
             done = true;
         } else {
@@ -989,11 +1004,11 @@ __device__ __forceinline__ void tpv_band_run(double (&x)[16], double& e0, double
             // the band's end state is the one behind the span's last valid sample, which the pass meets inside chunk endTid
             // (the scan above left there the state behind that chunk's padding)
             double c1 = 0.0, c2 = 0.0;
-            tpv_pass<CLS, SAT, true>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, smallOk, smallK,
+            tpv_pass<CLS, SAT, true>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], &link.tb[nb].mm.e[0][0], e0, e1, sat, smallOk, smallK,
                                      tidL == endTid ? capAt : -1, &c1, &c2);
             if (tidL == endTid) { sNext[2 * b] = c1; sNext[2 * b + 1] = c2; }
         } else {
-            tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], e0, e1, sat, smallOk, smallK);
+            tpv_pass<CLS, SAT>(x, s0x, s0y, cf + b * 6, (monoMask >> b) & 1, &sh.E[nb][0][0], &link.tb[nb].mm.e[0][0], e0, e1, sat, smallOk, smallK);
         }
     }
 }
@@ -1159,7 +1174,7 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_s
         if (WAVES != 0 && tid == 0) sh.task = chain ? tpv_arrival(reinterpret_cast<unsigned*>(chain) + sizeof(TpvChainHeader) / sizeof(unsigned)) : -1;
         tpv_load_tables(sh, tb, tid, nThreads);
         __syncthreads();
-        const TpvLink link = { nullptr, nullptr, 0u, nullptr, nullptr, WAVES != 0 ? __builtin_amdgcn_readfirstlane(sh.task) : -1 };
+        const TpvLink link = { nullptr, nullptr, 0u, nullptr, nullptr, WAVES != 0 ? __builtin_amdgcn_readfirstlane(sh.task) : -1, tb };
 
         int sp = 0;
 #pragma unroll 1
@@ -1207,7 +1222,8 @@ __global__ __launch_bounds__((WAVES ? WAVES : 7) * 64, PARTIAL ? 2 : 4) void k_s
             if (sp == 0 && tidT < kBands * 2) sh.stateA[tidT] = state[(int64_t)c * kBands * 2 + tidT];
             __syncthreads();
             unsigned long long* g = gran + ((int64_t)c * chainSpans + sp) * (kBands * 4);
-            const TpvLink link = { sp > 0 ? g - kBands * 4 : nullptr, sp + 1 < nSpans ? g : nullptr, epoch, &sh.flag, &hdr->error, __builtin_amdgcn_readfirstlane(sh.role) };
+            const TpvLink link = { sp > 0 ? g - kBands * 4 : nullptr, sp + 1 < nSpans ? g : nullptr, epoch, &sh.flag, &hdr->error, __builtin_amdgcn_readfirstlane(sh.role),
+                                   tables + (int64_t)(c >> 1) * kBands };
             const double* src = in + (int64_t)c * chStride + (int64_t)sp * spanLen;
             double* dst = out + (int64_t)c * chStride + (int64_t)sp * spanLen;
             const int r = tpv_fast_span<kNT, true, false>(sh, src + waveU * 1024, dst + waveU * 1024, bm, cf, sat, gain, sh.stateA, sh.stateB,
