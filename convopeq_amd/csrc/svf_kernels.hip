@@ -451,7 +451,8 @@ constexpr int kTpvSpan = kTpvWaves * 1024;      // samples per span
 constexpr unsigned kTpvApplyGain = 1u << 31;    // bandFilter bit: this launch applies the channel's output gain
 constexpr int kTpvQStride = 6;          // doubles per row of the quarter-chunk transposition buffer: 48 B, conflict-free b128 rows
 constexpr int kTpvGuardPiece = 2048;    // samples per staged piece of the guarded path
-constexpr int kTpvU = 2;                // samples per group of the small-signal output stage (one v_rcp_f64 per group)
+constexpr int kTpvU = 4;                // samples per group of the small-signal output stage (one v_rcp_f64 per group; 4 fits
+                                        // the registers since the E rows are scalar operands: 26 slots per 4 samples against 2 x 14)
 constexpr unsigned kTpvSpinLimit = 1u << 22;    // polls of a hand-over before the launch gives up (seconds; a guarded span takes milliseconds)
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
